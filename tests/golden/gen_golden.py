@@ -1,0 +1,318 @@
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run in the development container only (the reference does not exist on the
+GPU box):
+
+    cd /tmp && python /root/repo/tests/golden/gen_golden.py
+
+It imports ``/root/reference`` (read-only), rebinding ``vlgp.core.solve`` so the
+removed SciPy keyword ``sym_pos=True`` maps to ``assume_a='pos'`` -- without
+that shim the reference raises TypeError at vlgp/core.py:465 under SciPy>=1.11
+(SURVEY.md section 0).  The outputs are data only: seeded inputs and the arrays
+the reference produced from them.
+"""
+import copy
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+warnings.filterwarnings("ignore")
+
+import scipy.linalg as sl  # noqa: E402
+import vlgp  # noqa: E402,F401
+import vlgp.core as core  # noqa: E402
+import vlgp.gp as gp  # noqa: E402
+from vlgp import api as ref_api  # noqa: E402
+from vlgp.math import ichol_gauss  # noqa: E402
+from vlgp.preprocess import get_config, get_params, fill_trials, fill_params  # noqa: E402
+from vlgp.simulation import lorenz  # noqa: E402
+from vlgp.util import cut_trials  # noqa: E402
+
+from vlgp_amd import synth  # noqa: E402
+
+
+def _solve(a, b, sym_pos=False, **kw):
+    if sym_pos:
+        kw.setdefault("assume_a", "pos")
+    return sl.solve(a, b, **kw)
+
+
+core.solve = _solve
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ---------------------------------------------------------------- 0. generator
+def check_generator():
+    mine = synth.lorenz_path(3000, x0=(0.3, 0.6, 0.9))
+    ref = lorenz(3000, dt=5e-3, s=10, r=28, b=2.667, x0=(0.3, 0.6, 0.9))
+    assert np.array_equal(mine, ref), np.abs(mine - ref).max()
+    print("synth.lorenz_path == reference simulation.lorenz (bitwise)")
+
+
+# ---------------------------------------------------------------- 1. ichol
+def gen_ichol():
+    cases = [(50, 5e-2, 50), (50, 5e-3, 50), (50, 5e-4, 50), (50, 1.3e-2, 50),
+             (200, 5e-3, 50), (200, 4e-2, 50), (1000, 5e-4, 50), (1000, 5e-3, 50),
+             (64, 2e-2, 20), (37, 7e-3, 50)]
+    out = {"cases": np.array(cases, dtype=float)}
+    for i, (n, om, r) in enumerate(cases):
+        G = ichol_gauss(n, om, r)
+        if n > 200:  # keep fixtures small: every 8th row + the full Gram diagonal
+            out["G%d_rows" % i] = G[::8]
+            out["G%d_diag" % i] = np.sum(G * G, axis=1)
+            out["G%d_colsum" % i] = G.sum(axis=0)
+        else:
+            out["G%d" % i] = G
+    save("ichol", **out)
+
+
+# ---------------------------------------------------------------- helpers
+def unit_inputs(rng, M, T, N, L, P=1, n_gauss=0, omega=None, rank=50):
+    """Seeded stage inputs: M units of T bins."""
+    a = 0.4 * rng.standard_normal((L, N))
+    b = np.log(0.3) + 0.2 * rng.standard_normal((P, N))
+    if P > 1:
+        b[1:] *= 0.1
+    noise = 0.5 + rng.random(N)
+    lik = np.array(["poisson"] * (N - n_gauss) + ["gaussian"] * n_gauss)
+    omega = np.array([4e-2, 6e-3, 1.2e-3, 2e-2, 9e-4][:L]) if omega is None else omega
+    sigma = np.array([1.0, 0.9, 1.1, 0.8, 1.0][:L])
+    G = np.array([ichol_gauss(T, omega[l], rank) * sigma[l] for l in range(L)])
+    units = []
+    for _ in range(M):
+        z = np.stack([np.sin(np.linspace(0, (2 + l) * np.pi, T) + rng.random() * 6)
+                      for l in range(L)], axis=1)
+        x = np.ones((T, P, N))
+        if P > 1:
+            x[:, 1:, :] = rng.standard_normal((T, P - 1, N)) * 0.3
+        eta = z @ a + np.einsum("tpn,pn->tn", x, b)
+        y = rng.poisson(np.exp(np.minimum(eta, 3))).astype(float)
+        if n_gauss:
+            y[:, N - n_gauss:] = eta[:, N - n_gauss:] + 0.7 * rng.standard_normal((T, n_gauss))
+        mu = z + 0.3 * rng.standard_normal((T, L))
+        units.append({"y": y, "x": x, "mu": mu})
+    params = {"ydim": N, "zdim": L, "xdim": P, "a": a, "b": b, "noise": noise,
+              "sigma": sigma, "omega": omega, "rank": rank, "gp_noise": 1e-4, "dt": 1,
+              "likelihood": lik, "cholesky": {T: G}}
+    return units, params
+
+
+def ref_init_wv(units, params, config):
+    """w, v as api.fit prepares them (api.py:52-54)."""
+    for u in units:
+        u["w"] = np.zeros_like(u["mu"])
+        u["v"] = np.zeros_like(u["mu"])
+    core.update_w(units, params, config)
+    core.update_v(units, params, config)
+
+
+def stack(units, key):
+    return np.stack([u[key] for u in units])
+
+
+# ---------------------------------------------------------------- 2/3. E-step
+def gen_estep():
+    rng = np.random.default_rng(20240901)
+    for tag, n_gauss in (("pois", 0), ("mixed", 8)):
+        units0, params = unit_inputs(rng, 4, 50, 20, 3, n_gauss=n_gauss)
+        config = get_config()
+        ref_init_wv(units0, params, config)
+        out = {k: params[k] for k in ("a", "b", "noise", "omega", "sigma")}
+        out["gauss"] = params["likelihood"] == "gaussian"
+        out["G"] = params["cholesky"][50]
+        for k in ("y", "x", "mu", "w", "v"):
+            out[k + "0"] = stack(units0, k)
+        # update_w / update_v stage outputs from mu0 with w=v=0 (fixture 3)
+        out["w_stage"] = out["w0"]
+        out["v_stage"] = out["v0"]
+        for method in ("VB", "MAP"):
+            for n_it in (1, 25):
+                units = copy.deepcopy(units0)
+                p = copy.deepcopy(params)
+                cfg = get_config(method=method, Eniter=n_it)
+                fill_trials(units)
+                core.estep(units, p, cfg)
+                for k in ("mu", "w", "v", "dmu"):
+                    out["%s_%s_%d" % (k, method, n_it)] = stack(units, k)
+        save("estep_" + tag, **out)
+
+    # one long unit in the truncated-rank regime, G injected
+    units0, params = unit_inputs(rng, 1, 300, 20, 3, n_gauss=4,
+                                 omega=np.array([3e-2, 8e-3, 2e-3]))
+    config = get_config()
+    ref_init_wv(units0, params, config)
+    out = {k: params[k] for k in ("a", "b", "noise")}
+    out["gauss"] = params["likelihood"] == "gaussian"
+    out["G"] = params["cholesky"][300]
+    for k in ("y", "x", "mu", "w", "v"):
+        out[k + "0"] = stack(units0, k)
+    units = copy.deepcopy(units0)
+    fill_trials(units)
+    core.estep(units, copy.deepcopy(params), get_config(Eniter=5))
+    for k in ("mu", "w", "v", "dmu"):
+        out[k + "_VB_5"] = stack(units, k)
+    save("estep_long", **out)
+
+
+# ---------------------------------------------------------------- 4. M-step
+def gen_mstep():
+    rng = np.random.default_rng(77)
+    for tag, P, n_gauss in (("p1", 1, 0), ("p3", 3, 0), ("mixed", 1, 6)):
+        units, params = unit_inputs(rng, 4, 50, 20, 3, P=P, n_gauss=n_gauss)
+        config = get_config()
+        ref_init_wv(units, params, config)
+        fill_trials(units)
+        out = {k: params[k] for k in ("a", "b", "noise")}
+        out["gauss"] = params["likelihood"] == "gaussian"
+        for k in ("y", "x", "mu", "v"):
+            out[k] = stack(units, k)
+        for hess in (True, False):
+            for n_it in (1, 25):
+                if not hess and n_it == 25:
+                    lr = 1e-4  # plain gradient ascent diverges at lr=1
+                elif not hess:
+                    lr = 1e-3
+                else:
+                    lr = 1.0
+                p = copy.deepcopy(params)
+                fill_params(p)
+                cfg = get_config(Mniter=n_it, use_hessian=hess, learning_rate=lr)
+                core.mstep(copy.deepcopy(units), p, cfg)
+                key = "%s_%d" % ("H" if hess else "G", n_it)
+                out["lr_" + key] = lr
+                for k in ("a", "b", "da", "db", "noise"):
+                    out["%s_%s" % (k, key)] = p[k]
+        save("mstep_" + tag, **out)
+
+
+# ---------------------------------------------------------------- 5. H-step
+def gen_hstep():
+    rng = np.random.default_rng(5)
+    units, params = unit_inputs(rng, 8, 50, 20, 3)
+    config = get_config()
+    ref_init_wv(units, params, config)
+    fill_trials(units)
+    core.estep(units, params, get_config(Eniter=3))
+    mu = stack(units, "mu")
+    w = stack(units, "w")
+    t = np.arange(50) * 1.0
+    mask = np.array([0, 1, 0])
+    pts = np.log(np.array([
+        [1.0, 5e-2, 1e-4], [1.0, 5e-4, 1e-4], [0.81, 6e-3, 1e-4],
+        [1.0, 2.3e-3, 2e-4], [0.5, 1.7e-2, 5e-5]]))
+    lls, dlls = [], []
+    for l in range(3):
+        for p in pts:
+            ex = np.exp(p)
+            S = gp.construct_posterior_cov(t, w[:, :, l].T, ex)
+            ll, dll = gp.elbo(ex, mask, t, mu[:, :, l].T, S)
+            lls.append(ll)
+            dlls.append(dll)
+    p2 = copy.deepcopy(params)
+    for u in units:
+        u["y"] = u["y"]
+    gp.optimize(units, p2, get_config())
+    save("hstep", mu=mu, w=w, logp=pts, ll=np.array(lls).reshape(3, -1),
+         dll=np.array(dlls).reshape(3, len(pts), 3), sigma0=params["sigma"],
+         omega0=params["omega"], omega_opt=p2["omega"], sigma_opt=p2["sigma"],
+         G_opt=p2["cholesky"][50])
+
+
+# ---------------------------------------------------------------- 6/7. vem, fit
+def c1_inputs():
+    n_trials, n_bins, N, L = synth.CONFIGS["C1"]
+    trials = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    rng = np.random.default_rng(11)
+    a0 = 0.3 * rng.standard_normal((L, N))
+    b0 = np.log(np.maximum(np.mean(np.concatenate([t["y"] for t in trials]), axis=0,
+                                   keepdims=True), 1e-8))
+    mu0 = [0.2 * rng.standard_normal((n_bins, L)) for _ in trials]
+    return trials, a0, b0, mu0
+
+
+def gen_vem():
+    trials0, a0, b0, mu0 = c1_inputs()
+    base = {"y": np.stack([t["y"] for t in trials0]).astype(np.uint8), "a0": a0, "b0": b0,
+            "mu0": np.stack(mu0)}
+    assert np.array_equal(base["y"].astype(float), np.stack([t["y"] for t in trials0]))
+    out = dict(base)
+    for hs in (True, False):
+        trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy()}
+                  for t, m in zip(trials0, mu0)]
+        cfg = get_config(Hstep=hs, max_iter=6, min_iter=6)
+        params = get_params(trials, 3, a=a0.copy(), b=b0.copy(), omega_bound=cfg["omega_bound"])
+        for tr in trials:  # what initialize leaves behind when a, b, mu are given
+            T = tr["y"].shape[0]
+            tr["x"] = np.ones((T, 1, 20))
+            tr["w"] = np.zeros((T, 3))
+            tr["v"] = np.zeros((T, 3))
+        fill_params(params)
+        fill_trials(trials)
+        gp.make_cholesky(trials, params, cfg)
+        core.update_w(trials, params, cfg)
+        core.update_v(trials, params, cfg)
+        segs = cut_trials(trials, params, cfg)
+        gp.make_cholesky(segs, params, cfg)
+        fill_trials(segs)
+        traj = {"mu": [], "a": [], "b": [], "omega": []}
+
+        def spy(tr_, p_, c_):
+            traj["mu"].append(sl.norm(np.concatenate([s["mu"] for s in tr_])))
+            traj["a"].append(sl.norm(p_["a"]))
+            traj["b"].append(sl.norm(p_["b"]))
+            traj["omega"].append(np.array(p_["omega"]))
+
+        cfg["callbacks"] = [spy]
+        core.vem(segs, params, cfg)
+        tag = "H1" if hs else "H0"
+        out["norm_mu_" + tag] = np.array(traj["mu"])
+        out["norm_a_" + tag] = np.array(traj["a"])
+        out["norm_b_" + tag] = np.array(traj["b"])
+        out["omega_" + tag] = np.array(traj["omega"])
+        out["a_" + tag] = params["a"]
+        out["b_" + tag] = params["b"]
+        out["noise_" + tag] = params["noise"]
+        out["it_" + tag] = cfg["runtime"]["it"]
+        out["seg_mu_" + tag] = np.stack([s["mu"] for s in segs])
+        out["seg_v_" + tag] = np.stack([s["v"] for s in segs])
+        out["seg_w_" + tag] = np.stack([s["w"] for s in segs])
+    save("vem_c1", **out)
+
+
+def gen_fit():
+    trials0, a0, b0, mu0 = c1_inputs()
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy()}
+              for t, m in zip(trials0, mu0)]
+    np.random.seed(3)
+    res = ref_api.fit(trials, 3, a=a0.copy(), b=b0.copy(), Hstep=False, max_iter=5, min_iter=5)
+    p = res["params"]
+    save("fit_c1", a0=a0, b0=b0, mu0=np.stack(mu0),
+         y=np.stack([t["y"] for t in trials0]).astype(np.uint8),
+         a=p["a"], b=p["b"], noise=p["noise"], omega=p["omega"], sigma=p["sigma"],
+         G200=p["cholesky"][200], it=res["config"]["runtime"]["it"],
+         mu=np.stack([t["mu"] for t in res["trials"]]),
+         v=np.stack([t["v"] for t in res["trials"]]),
+         w=np.stack([t["w"] for t in res["trials"]]),
+         dmu=np.stack([t["dmu"] for t in res["trials"]]))
+
+
+if __name__ == "__main__":
+    os.chdir("/tmp")  # the reference writes vlgp.log into the cwd at import
+    check_generator()
+    gen_ichol()
+    gen_estep()
+    gen_mstep()
+    gen_hstep()
+    gen_vem()
+    gen_fit()

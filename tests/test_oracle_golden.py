@@ -1,0 +1,149 @@
+"""The CPU oracle against golden vectors captured from the real reference
+(tests/golden/gen_golden.py) -- this is what pins the oracle.
+
+Tolerances: the restatement follows the reference's operation order, so stage
+outputs agree to ~1e-13; anything that passes through L-BFGS-B is held to 1e-9.
+"""
+import numpy as np
+import pytest
+from scipy.linalg import toeplitz
+
+from conftest import relerr
+from oracle import vlgp_oracle as O
+
+STAGE_TOL = 1e-12
+
+
+def test_reference_own_ichol_assertion():
+    # the reference's only numeric test on this path: tests/test_math.py:7-14
+    n, omega = 500, 1
+    K = toeplitz(np.exp(-omega * np.arange(n) ** 2))
+    G = O.ichol_gauss(n, omega, n)
+    assert np.allclose(K, G @ G.T)
+
+
+def test_ichol_golden(golden):
+    g = golden("ichol")
+    for i, (n, om, r) in enumerate(g["cases"]):
+        G = O.ichol_gauss(int(n), om, int(r))
+        if n > 200:
+            assert np.array_equal(G[::8], g["G%d_rows" % i])
+            assert relerr(np.sum(G * G, axis=1), g["G%d_diag" % i]) < 1e-14
+            assert relerr(G.sum(axis=0), g["G%d_colsum" % i]) < 1e-13
+        else:
+            assert np.array_equal(G, g["G%d" % i])
+
+
+@pytest.mark.parametrize("tag", ["pois", "mixed"])
+def test_estep_golden(golden, tag):
+    g = golden("estep_" + tag)
+    for method in ("VB", "MAP"):
+        for n_it in (1, 25):
+            for m in range(g["y0"].shape[0]):
+                out = O.estep_unit(g["y0"][m], g["x0"][m], g["mu0"][m], g["v0"][m],
+                                   g["w0"][m], g["a"], g["b"], g["noise"], g["gauss"],
+                                   g["G"], n_it, 5.0, method == "VB")
+                assert out[4] == 0
+                for k, arr in zip(("mu", "v", "w", "dmu"), out):
+                    assert relerr(arr, g["%s_%s_%d" % (k, method, n_it)][m]) < STAGE_TOL
+
+
+@pytest.mark.parametrize("tag", ["pois", "mixed"])
+def test_update_w_v_golden(golden, tag):
+    g = golden("estep_" + tag)
+    for m in range(g["y0"].shape[0]):
+        zero = np.zeros_like(g["mu0"][m])
+        w = O.curvature_unit(g["y0"][m], g["x0"][m], g["mu0"][m], zero, g["a"], g["b"],
+                             g["noise"], g["gauss"])
+        assert relerr(w, g["w_stage"][m]) < STAGE_TOL
+        v, bad = O.variance_unit(w, zero, g["G"])
+        assert bad == 0 and relerr(v, g["v_stage"][m]) < STAGE_TOL
+
+
+def test_estep_long_golden(golden):
+    g = golden("estep_long")
+    out = O.estep_unit(g["y0"][0], g["x0"][0], g["mu0"][0], g["v0"][0], g["w0"][0], g["a"],
+                       g["b"], g["noise"], g["gauss"], g["G"], 5)
+    for k, arr in zip(("mu", "v", "w", "dmu"), out):
+        assert relerr(arr, g[k + "_VB_5"][0]) < STAGE_TOL
+
+
+@pytest.mark.parametrize("tag", ["p1", "p3", "mixed"])
+def test_mstep_golden(golden, tag):
+    g = golden("mstep_" + tag)
+    cat = lambda k: np.concatenate(list(g[k]), axis=0)
+    for key in ("H_1", "H_25", "G_1", "G_25"):
+        out = O.mstep_arrays(cat("y"), cat("x"), cat("mu"), cat("v"), g["a"], g["b"],
+                             g["gauss"], int(key[2:]), key[0] == "H", 1e-8,
+                             float(g["lr_" + key]))
+        for k, arr in zip(("a", "b", "da", "db", "noise"), out):
+            assert relerr(arr, g["%s_%s" % (k, key)]) < STAGE_TOL
+
+
+def test_hstep_objective_golden(golden):
+    g = golden("hstep")
+    t = np.arange(50.0)
+    for l in range(3):
+        for i, p in enumerate(g["logp"]):
+            ll, dll = O.gp_objective(p, t, g["mu"][:, :, l].T, g["w"][:, :, l].T)
+            assert abs(ll - g["ll"][l, i]) <= 1e-12 * abs(g["ll"][l, i])
+            assert relerr(dll, g["dll"][l, i]) < 1e-11
+
+
+def test_hstep_optimize_golden(golden):
+    g = golden("hstep")
+    sig, om = O.hstep_arrays(g["mu"], g["w"], g["sigma0"], g["omega0"], 1e-4,
+                             (5e-4, 5e-2), 50)
+    assert relerr(om, g["omega_opt"]) < 1e-9
+    assert relerr(sig, g["sigma_opt"]) < 1e-12
+
+
+def _c1_trials(g):
+    y = g["y"].astype(float)
+    n, T, N = y.shape
+    L = g["mu0"].shape[-1]
+    return [{"ID": i, "y": y[i].copy(), "mu": g["mu0"][i].copy(), "x": np.ones((T, 1, N)),
+             "w": np.zeros((T, L)), "v": np.zeros((T, L))} for i in range(n)]
+
+
+@pytest.mark.parametrize("tag,hs", [("H0", False), ("H1", True)])
+def test_vem_trajectory_golden(golden, tag, hs):
+    g = golden("vem_c1")
+    trials = _c1_trials(g)
+    cfg = O.make_config(Hstep=hs, max_iter=6, min_iter=6)
+    params = O.make_params(trials, 3, a=g["a0"].copy(), b=g["b0"].copy())
+    params["da"] = np.zeros_like(params["a"])
+    params["db"] = np.zeros_like(params["b"])
+    O.fill_trials(trials)
+    O.make_cholesky(trials, params)
+    O.update_w(trials, params)
+    O.update_v(trials, params, cfg)
+    segs = O.cut_trials(trials, 50)
+    O.make_cholesky(segs, params)
+    O.fill_trials(segs)
+    traj = []
+    cfg["callbacks"] = [lambda t_, p_, c_: traj.append(
+        (np.linalg.norm(np.concatenate([s["mu"] for s in t_])), np.linalg.norm(p_["a"]),
+         np.array(p_["omega"])))]
+    O.vem(segs, params, cfg)
+    tol = 1e-9 if hs else STAGE_TOL
+    assert cfg["runtime"]["it"] == int(g["it_" + tag])
+    assert relerr([t[0] for t in traj], g["norm_mu_" + tag]) < tol
+    assert relerr([t[1] for t in traj], g["norm_a_" + tag]) < tol
+    assert relerr(np.array([t[2] for t in traj]), g["omega_" + tag]) < tol
+    assert relerr(params["a"], g["a_" + tag]) < tol
+    assert relerr(params["b"], g["b_" + tag]) < tol
+    assert relerr(np.stack([s["mu"] for s in segs]), g["seg_mu_" + tag]) < tol
+    assert relerr(np.stack([s["v"] for s in segs]), g["seg_v_" + tag]) < tol
+
+
+def test_fit_golden(golden):
+    g = golden("fit_c1")
+    trials = _c1_trials(g)
+    cfg = O.make_config(Hstep=False, max_iter=5, min_iter=5)
+    params = O.make_params(trials, 3, a=g["a0"].copy(), b=g["b0"].copy())
+    O.fit_given_init(trials, params, cfg)
+    for k in ("mu", "v", "w", "dmu"):
+        assert relerr(np.stack([t[k] for t in trials]), g[k]) < STAGE_TOL
+    assert relerr(params["a"], g["a"]) < STAGE_TOL
+    assert np.array_equal(params["cholesky"][200], g["G200"])
