@@ -1,0 +1,173 @@
+/*
+ * vlgp_hip.h -- C ABI of libvlgp_hip.so, the MI355X (gfx950) engine behind the
+ * variational-EM hot path of catniplab/vlgp.
+ *
+ * The reference has no FFI: its seam is the Python contract
+ *     estep|mstep|hstep|update_w|update_v|make_cholesky|infer(trials, params, config) -> None
+ * (vlgp/core.py:22-471, vlgp/gp.py:65-162).  Each entry point below names the
+ * reference function it replaces.  The Python host (vlgp_amd/engine.py) binds
+ * these with ctypes; see INTEGRATION.md for the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is IEEE double
+ *   - every function returns an int status: 0 = ok, <0 = error (text via
+ *     vlgp_last_error); nothing throws across the boundary
+ *   - caller owns host buffers; the library owns device buffers behind the
+ *     opaque handle; one host thread per handle; one handle per GPU
+ *   - all work is enqueued on the handle's own HIP stream; calls that return
+ *     host data synchronise that stream, the others are asynchronous
+ *   - numerical failures never return an error: a non-positive pivot in a
+ *     Cholesky zeroes that latent's update for that unit (reference:
+ *     vlgp/core.py:92-94,112-113,194-196) and is counted in *n_failed
+ *
+ * Data model
+ *   unit      one trial or one fixed-length segment: T_m time bins
+ *   unit set  M units packed back to back in row-major arrays
+ *               y   (rows, N)      observations          rows = sum T_m
+ *               x   (rows, P, N)   regressors (NULL = all ones, P must be 1)
+ *               mu, v, w, dmu (rows, L)
+ *             addressed through a CSR-style offsets[M+1]; VLGP_MAX_SETS slots
+ *   params    a (L, N) loading, b (P, N) bias/regression, noise (N)
+ *   prior     per distinct unit length T: G (L, T, R), K_l ~= G_l G_l^T
+ */
+#ifndef VLGP_HIP_H
+#define VLGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLGP_ABI_VERSION 1
+#define VLGP_MAX_SETS 4
+#define VLGP_MAX_RANK 64          /* R <= 64 (the reference hard-codes 50, preprocess.py:75) */
+#define VLGP_UNIQUE_ID_BYTES 128
+
+#define VLGP_OK 0
+#define VLGP_ERR_ARG (-1)         /* bad argument / shape */
+#define VLGP_ERR_HIP (-2)         /* HIP runtime error (no GPU, OOM, launch failure) */
+#define VLGP_ERR_STATE (-3)       /* call sequence error (missing prior, empty set ...) */
+#define VLGP_ERR_COMM (-4)        /* RCCL error */
+
+typedef struct vlgp_ctx vlgp_ctx;
+
+/* ---- lifetime --------------------------------------------------------- */
+int vlgp_abi_version(void);
+int vlgp_device_count(int* count);
+/* gauss_mask[n] != 0 marks a Gaussian channel, 0 a Poisson one
+ * (params["likelihood"], vlgp/preprocess.py:59-64). */
+int vlgp_create(int device, int N, int L, int P, int R, const uint8_t* gauss_mask,
+                vlgp_ctx** out);
+int vlgp_destroy(vlgp_ctx* ctx);
+/* Last error text of this handle (or of the failed vlgp_create when ctx is NULL). */
+const char* vlgp_last_error(vlgp_ctx* ctx);
+int vlgp_synchronize(vlgp_ctx* ctx);
+
+/* ---- unit sets -------------------------------------------------------- */
+/* Replaces the list-of-dicts the reference passes around (trial dict keys
+ * y, x, mu, w, v; vlgp/preprocess.py:38-46).  x == NULL means x == 1, P == 1
+ * (what preprocess.initialize builds when the user gives no regressors);
+ * mu, v, w may be NULL (zero-filled). */
+int vlgp_upload_units(vlgp_ctx* ctx, int set, int M, const int64_t* offsets,
+                      const double* y, const double* x, const double* mu,
+                      const double* v, const double* w);
+/* util.cut_trials (vlgp/util.py:457-499): build set `dst` of M_dst units of
+ * `window` rows each, unit k starting at row src_row_start[k] of set `src`.
+ * When the segments tile `src` exactly (no overlap) `dst` aliases the same
+ * device arrays, as the reference's NumPy views do; otherwise rows are copied
+ * and segments are independent ("Hard parts"). */
+int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst,
+                   const int64_t* src_row_start, int window);
+/* Write mu and v of a cut set back into its source set (no-op when aliased;
+ * with overlapping segments later segments win, in order). */
+int vlgp_merge_units(vlgp_ctx* ctx, int cut_set);
+/* Any of the output pointers may be NULL. */
+int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v, double* w,
+                        double* dmu);
+int vlgp_free_units(vlgp_ctx* ctx, int set);
+
+/* ---- parameters ------------------------------------------------------- */
+int vlgp_set_params(vlgp_ctx* ctx, const double* a, const double* b, const double* noise);
+/* Any pointer may be NULL.  da, db are the last M-step increments
+ * (params["da"], params["db"], vlgp/core.py:201,219). */
+int vlgp_get_params(vlgp_ctx* ctx, double* a, double* b, double* noise, double* da,
+                    double* db);
+
+/* ---- prior factor ----------------------------------------------------- */
+/* gp.make_cholesky (vlgp/gp.py:150-162) + math.ichol_gauss (vlgp/math.py:76-126)
+ * on the device: REPLACES the whole prior table with one factor per listed
+ * length, G_l = ichol_gauss(T, omega_l, R) * sigma_l. */
+int vlgp_build_prior(vlgp_ctx* ctx, int n_lengths, const int* lengths,
+                     const double* omega, const double* sigma);
+/* Inject a host-made factor G (L, T, R) for length T (adds/replaces one entry). */
+int vlgp_set_prior(vlgp_ctx* ctx, int T, const double* G);
+int vlgp_clear_prior(vlgp_ctx* ctx);
+/* G (L, T, R) out; rank_out (L) = number of non-zero columns per latent (may be NULL). */
+int vlgp_get_prior(vlgp_ctx* ctx, int T, double* G, int* rank_out);
+
+/* ---- E-step ----------------------------------------------------------- */
+/* core.update_w (vlgp/core.py:419-442) */
+int vlgp_update_w(vlgp_ctx* ctx, int set);
+/* core.update_v (vlgp/core.py:445-471); vb == 0 is the reference's early
+ * return for method != "VB". */
+int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed);
+/* core.estep -> core.infer_single_trial (vlgp/core.py:22-126): n_iter inner
+ * iterations for every unit of the set.  n_failed may be NULL (no sync then). */
+int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb,
+               int* n_failed);
+
+/* ---- M-step ----------------------------------------------------------- */
+/* core.mstep (vlgp/core.py:129-249) over the concatenation of all units of
+ * the set.  With a communicator attached the sufficient statistics are
+ * all-reduced over ranks once per Newton iteration. */
+int vlgp_mstep(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps,
+               double learning_rate, double da_bound, double db_bound, int* n_failed);
+
+/* ---- H-step ----------------------------------------------------------- */
+/* The objective scipy's L-BFGS-B minimises in gp.optimze1d (vlgp/gp.py:100-123):
+ * construct_posterior_cov (gp.py:126-147) + elbo (gp.py:12-43), mask [0,1,0].
+ * n_eval independent evaluations in one call: evaluation e uses latent
+ * latent[e] and log-parameters logp[3e..3e+2] = log(sigma^2, omega, eps).
+ * Outputs the UN-negated ll[e] and dll[3e..3e+2] summed over all units of the
+ * set (and over ranks).  Every unit must have exactly `window` rows. */
+int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_eval,
+                         const int* latent, const double* logp, double* ll,
+                         double* dll);
+
+/* ---- constraints / norms --------------------------------------------- */
+/* mu <- (mu - shift) @ map for every unit (map (L, L) row-major, shift (L) or
+ * NULL).  Covers core.constrain_loading (vlgp/core.py:392-416: map = s I, or
+ * the SVD factor) and core.constrain_latent (vlgp/core.py:366-389). */
+int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const double* shift);
+/* out[0] = sum mu^2, out[1] = sum dmu^2 over the set (and over ranks):
+ * the convergence test of core.vem (vlgp/core.py:300-305,350-354). */
+int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]);
+/* Column sums over the set (and ranks): sum1[l] = sum mu[:,l], sum2[l] = sum mu[:,l]^2,
+ * *count = number of rows.  For core.constrain_latent. */
+int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double* sum2, double* count);
+
+/* ---- multi-GPU (RCCL over xGMI) --------------------------------------- */
+/* Rank 0 makes the id, every rank passes the same id to vlgp_comm_init. */
+int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]);
+int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES], int rank, int world);
+
+/* ---- measurement ------------------------------------------------------ */
+/* HIP-event timing of the kernels an entry point launches, on the handle's
+ * stream.  kind: 0 = E-step kernel, 1 = M-step statistics kernel,
+ * 2 = H-step objective kernel, 3 = prior (ichol) kernel. */
+#define VLGP_PROF_ESTEP 0
+#define VLGP_PROF_MSTEP 1
+#define VLGP_PROF_HSTEP 2
+#define VLGP_PROF_PRIOR 3
+#define VLGP_PROF_KINDS 4
+int vlgp_profile_enable(vlgp_ctx* ctx, int on);
+int vlgp_profile_reset(vlgp_ctx* ctx);
+/* launches and total milliseconds recorded for `kind` since the last reset. */
+int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLGP_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libvlgp_hip.so (C ABI: include/vlgp_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no GPU is
+visible when a handle is created, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlgp_hip.so")
+
+ABI_VERSION = 1
+MAX_SETS = 4
+UNIQUE_ID_BYTES = 128
+PROF_ESTEP, PROF_MSTEP, PROF_HSTEP, PROF_PRIOR = 0, 1, 2, 3
+
+_lib = None
+
+
+class VlgpError(RuntimeError):
+    """An entry point of libvlgp_hip.so returned a non-zero status."""
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_h = C.c_void_p
+
+_SIGNATURES = {
+    "vlgp_abi_version": (C.c_int, []),
+    "vlgp_device_count": (C.c_int, [_ip]),
+    "vlgp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.POINTER(_h)]),
+    "vlgp_destroy": (C.c_int, [_h]),
+    "vlgp_last_error": (C.c_char_p, [_h]),
+    "vlgp_synchronize": (C.c_int, [_h]),
+    "vlgp_upload_units": (C.c_int, [_h, C.c_int, C.c_int, _i64p, _dp, _dp, _dp, _dp, _dp]),
+    "vlgp_cut_units": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _i64p, C.c_int]),
+    "vlgp_merge_units": (C.c_int, [_h, C.c_int]),
+    "vlgp_download_units": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
+    "vlgp_free_units": (C.c_int, [_h, C.c_int]),
+    "vlgp_set_params": (C.c_int, [_h, _dp, _dp, _dp]),
+    "vlgp_get_params": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp]),
+    "vlgp_build_prior": (C.c_int, [_h, C.c_int, _ip, _dp, _dp]),
+    "vlgp_set_prior": (C.c_int, [_h, C.c_int, _dp]),
+    "vlgp_clear_prior": (C.c_int, [_h]),
+    "vlgp_get_prior": (C.c_int, [_h, C.c_int, _dp, _ip]),
+    "vlgp_update_w": (C.c_int, [_h, C.c_int]),
+    "vlgp_update_v": (C.c_int, [_h, C.c_int, C.c_int, _ip]),
+    "vlgp_estep": (C.c_int, [_h, C.c_int, C.c_int, C.c_double, C.c_int, _ip]),
+    "vlgp_mstep": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                             C.c_double, _ip]),
+    "vlgp_hstep_objective": (C.c_int, [_h, C.c_int, C.c_int, C.c_double, C.c_int, _ip, _dp, _dp, _dp]),
+    "vlgp_apply_latent_map": (C.c_int, [_h, C.c_int, _dp, _dp]),
+    "vlgp_norms": (C.c_int, [_h, C.c_int, _dp]),
+    "vlgp_latent_moments": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
+    "vlgp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "vlgp_comm_init": (C.c_int, [_h, C.c_char_p, C.c_int, C.c_int]),
+    "vlgp_profile_enable": (C.c_int, [_h, C.c_int]),
+    "vlgp_profile_reset": (C.c_int, [_h]),
+    "vlgp_profile_get": (C.c_int, [_h, C.c_int, _i64p, _dp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def load():
+    """Load the shared library once; raise ImportError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vlgp_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vlgp_abi_version() != ABI_VERSION:
+        raise ImportError("libvlgp_hip.so ABI %d != binding ABI %d" % (lib.vlgp_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def dptr(arr):
+    """double* of a C-contiguous float64 array (None -> NULL)."""
+    if arr is None:
+        return None
+    assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"], "need C-contiguous float64"
+    return arr.ctypes.data_as(_dp)
+
+
+def iptr(arr):
+    if arr is None:
+        return None
+    assert arr.dtype == np.int32 and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(_ip)
+
+
+def i64ptr(arr):
+    assert arr.dtype == np.int64 and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(_i64p)
+
+
+def u8ptr(arr):
+    assert arr.dtype == np.uint8 and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(_u8p)
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().vlgp_last_error(handle)
+        raise VlgpError("libvlgp_hip status %d: %s" % (rc, (msg or b"").decode(errors="replace")))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().vlgp_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

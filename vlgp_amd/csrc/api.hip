@@ -1,0 +1,740 @@
+// C ABI of libvlgp_hip.so (include/vlgp_hip.h): handle management, host<->device
+// marshalling, RCCL plumbing and the thin wrappers around the kernel launchers.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "ctx.h"
+
+static thread_local std::string g_create_err;
+
+int vlgp_fail(vlgp_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define NEED_CTX(ctx) \
+    if (!(ctx)) return vlgp_fail(nullptr, VLGP_ERR_ARG, "null handle")
+
+static int dev_alloc(vlgp_ctx* ctx, double** p, int64_t n, bool zero) {
+    *p = nullptr;
+    if (n <= 0) n = 1;
+    HIPCHK(ctx, hipMalloc(p, (size_t)n * sizeof(double)));
+    if (zero) HIPCHK(ctx, hipMemsetAsync(*p, 0, (size_t)n * sizeof(double), ctx->stream));
+    return VLGP_OK;
+}
+
+int vlgp_ensure_work(vlgp_ctx* ctx, int64_t n) {
+    if (n <= ctx->work_len) return VLGP_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_work) HIPCHK(ctx, hipFree(ctx->d_work));
+    ctx->d_work = nullptr;
+    ctx->work_len = 0;
+    const int64_t cap = n + n / 4 + 1024;
+    HIPCHK(ctx, hipMalloc(&ctx->d_work, (size_t)cap * sizeof(double)));
+    ctx->work_len = cap;
+    return VLGP_OK;
+}
+
+int vlgp_ensure_pinned(vlgp_ctx* ctx, int64_t n) {
+    if (n <= ctx->pinned_len) return VLGP_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned) HIPCHK(ctx, hipHostFree(ctx->h_pinned));
+    ctx->h_pinned = nullptr;
+    ctx->pinned_len = 0;
+    const int64_t cap = n + 1024;
+    HIPCHK(ctx, hipHostMalloc(&ctx->h_pinned, (size_t)cap * sizeof(double), hipHostMallocDefault));
+    ctx->pinned_len = cap;
+    return VLGP_OK;
+}
+
+UnitSet* vlgp_get_set(vlgp_ctx* ctx, int set, bool must_be_valid) {
+    if (set < 0 || set >= VLGP_MAX_SETS) {
+        vlgp_fail(ctx, VLGP_ERR_ARG, "unit set index %d out of range [0, %d)", set, VLGP_MAX_SETS);
+        return nullptr;
+    }
+    UnitSet* us = &ctx->sets[set];
+    if (must_be_valid && !us->valid) {
+        vlgp_fail(ctx, VLGP_ERR_STATE, "unit set %d is empty (upload or cut first)", set);
+        return nullptr;
+    }
+    return us;
+}
+
+// ---- profiling -----------------------------------------------------------
+void vlgp_prof_begin(vlgp_ctx* ctx, int kind) {
+    if (!ctx->prof_on) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, ctx->stream);
+    ctx->pending.push_back({kind, {a, b}});
+}
+void vlgp_prof_end(vlgp_ctx* ctx, int kind) {
+    if (!ctx->prof_on || ctx->pending.empty()) return;
+    auto& p = ctx->pending.back();
+    if (p.first != kind) return;
+    (void)hipEventRecord(p.second.second, ctx->stream);
+}
+static void prof_drain(vlgp_ctx* ctx) {
+    if (ctx->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            ctx->prof[p.first].launches += 1;
+            ctx->prof[p.first].ms += ms;
+        }
+        (void)hipEventDestroy(p.second.first);
+        (void)hipEventDestroy(p.second.second);
+    }
+    ctx->pending.clear();
+}
+
+// ---- RCCL (loaded lazily: single-GPU use never touches it) ---------------
+typedef struct { char internal[128]; } rccl_uid;
+typedef int (*fn_getuid)(rccl_uid*);
+typedef int (*fn_initrank)(void**, int, rccl_uid, int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+static struct {
+    void* lib = nullptr;
+    fn_getuid get_uid = nullptr;
+    fn_initrank init_rank = nullptr;
+    fn_allreduce all_reduce = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_errstr errstr = nullptr;
+} g_rccl;
+
+static int rccl_load(vlgp_ctx* ctx) {
+    if (g_rccl.lib) return VLGP_OK;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return vlgp_fail(ctx, VLGP_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    g_rccl.get_uid = (fn_getuid)dlsym(lib, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_initrank)dlsym(lib, "ncclCommInitRank");
+    g_rccl.all_reduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
+    g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
+    g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.all_reduce || !g_rccl.destroy)
+        return vlgp_fail(ctx, VLGP_ERR_COMM, "librccl.so lacks an expected symbol");
+    g_rccl.lib = lib;
+    return VLGP_OK;
+}
+
+int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n) {
+    if (ctx->world <= 1 || !ctx->comm) return VLGP_OK;
+    const int rc = g_rccl.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    if (rc != 0)
+        return vlgp_fail(ctx, VLGP_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]) {
+    CHK(rccl_load(nullptr));
+    rccl_uid u;
+    const int rc = g_rccl.get_uid(&u);
+    if (rc != 0) return vlgp_fail(nullptr, VLGP_ERR_COMM, "ncclGetUniqueId failed (%d)", rc);
+    memcpy(id, u.internal, VLGP_UNIQUE_ID_BYTES);
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES], int rank, int world) {
+    NEED_CTX(ctx);
+    if (world < 1 || rank < 0 || rank >= world) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad rank/world %d/%d", rank, world);
+    ctx->rank = rank;
+    ctx->world = world;
+    if (world == 1) return VLGP_OK;
+    CHK(rccl_load(ctx));
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    rccl_uid u;
+    memcpy(u.internal, id, VLGP_UNIQUE_ID_BYTES);
+    const int rc = g_rccl.init_rank(&ctx->comm, world, u, rank);
+    if (rc != 0)
+        return vlgp_fail(ctx, VLGP_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+    return VLGP_OK;
+}
+
+// ---- lifetime --------------------------------------------------------------
+extern "C" int vlgp_abi_version(void) { return VLGP_ABI_VERSION; }
+
+extern "C" int vlgp_device_count(int* count) {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return vlgp_fail(nullptr, VLGP_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return VLGP_OK;
+}
+
+extern "C" const char* vlgp_last_error(vlgp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+static void free_set(vlgp_ctx* ctx, UnitSet& us) {
+    if (!us.valid) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    if (!us.alias) { fr(us.y); fr(us.x); fr(us.mu); fr(us.v); fr(us.w); }
+    fr(us.dmu); fr(us.d_off); fr(us.d_src_start); fr(us.d_unit_prior); fr(us.d_xb); fr(us.d_scratch);
+    us = UnitSet();
+}
+
+extern "C" int vlgp_create(int device, int N, int L, int P, int R, const uint8_t* gauss_mask, vlgp_ctx** out) {
+    if (!out) return vlgp_fail(nullptr, VLGP_ERR_ARG, "null output handle");
+    *out = nullptr;
+    if (N < 1 || L < 1 || P < 1 || R < 1) return vlgp_fail(nullptr, VLGP_ERR_ARG, "N, L, P, R must be positive");
+    if (R > VLGP_MAX_RANK) return vlgp_fail(nullptr, VLGP_ERR_ARG, "rank %d exceeds VLGP_MAX_RANK=%d", R, VLGP_MAX_RANK);
+    if (L > 16) return vlgp_fail(nullptr, VLGP_ERR_ARG, "at most 16 latents supported, got %d", L);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return vlgp_fail(nullptr, VLGP_ERR_HIP, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return vlgp_fail(nullptr, VLGP_ERR_ARG, "device %d out of range (have %d)", device, ndev);
+    vlgp_ctx* ctx = new (std::nothrow) vlgp_ctx();
+    if (!ctx) return vlgp_fail(nullptr, VLGP_ERR_HIP, "out of host memory");
+    ctx->dev = device; ctx->N = N; ctx->L = L; ctx->P = P; ctx->R = R;
+#define CREATE_CHK(call)                                                                  \
+    do {                                                                                  \
+        hipError_t e2 = (call);                                                           \
+        if (e2 != hipSuccess) {                                                           \
+            vlgp_fail(nullptr, VLGP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2)); \
+            delete ctx;                                                                   \
+            return VLGP_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+    CREATE_CHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CREATE_CHK(hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->gauss.assign(N, 0);
+    std::vector<int> gi(N, 0);
+    for (int n = 0; n < N; ++n) {
+        const uint8_t g = gauss_mask ? gauss_mask[n] : 0;
+        ctx->gauss[n] = g ? 1 : 0;
+        gi[n] = g ? 1 : 0;
+        ctx->n_gauss += g ? 1 : 0;
+    }
+    CREATE_CHK(hipMalloc(&ctx->d_gauss, sizeof(int) * N));
+    CREATE_CHK(hipMemcpy(ctx->d_gauss, gi.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    CREATE_CHK(hipMalloc(&ctx->d_a, sizeof(double) * L * N));
+    CREATE_CHK(hipMalloc(&ctx->d_da, sizeof(double) * L * N));
+    CREATE_CHK(hipMalloc(&ctx->d_b, sizeof(double) * P * N));
+    CREATE_CHK(hipMalloc(&ctx->d_db, sizeof(double) * P * N));
+    CREATE_CHK(hipMalloc(&ctx->d_noise, sizeof(double) * N));
+    CREATE_CHK(hipMemset(ctx->d_da, 0, sizeof(double) * L * N));
+    CREATE_CHK(hipMemset(ctx->d_db, 0, sizeof(double) * P * N));
+    CREATE_CHK(hipMalloc(&ctx->d_fail, sizeof(int)));
+    CREATE_CHK(hipMemset(ctx->d_fail, 0, sizeof(int)));
+#undef CREATE_CHK
+    *out = ctx;
+    return VLGP_OK;
+}
+
+static void free_priors(vlgp_ctx* ctx) {
+    for (auto& kv : ctx->priors) {
+        if (kv.second.d_full) (void)hipFree(kv.second.d_full);
+        if (kv.second.d_compact) (void)hipFree(kv.second.d_compact);
+    }
+    ctx->priors.clear();
+}
+
+extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
+    if (!ctx) return VLGP_OK;
+    (void)hipSetDevice(ctx->dev);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
+    // aliased sets first, then owners
+    for (int pass = 0; pass < 2; ++pass)
+        for (auto& us : ctx->sets)
+            if (us.valid && (pass == 1 || us.alias)) free_set(ctx, us);
+    free_priors(ctx);
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    fr(ctx->d_gauss); fr(ctx->d_a); fr(ctx->d_b); fr(ctx->d_noise); fr(ctx->d_da); fr(ctx->d_db);
+    fr(ctx->d_fail); fr(ctx->d_work); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_synchronize(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+
+// ---- unit sets -------------------------------------------------------------
+static int set_offsets(vlgp_ctx* ctx, UnitSet& us, int M, const int64_t* off) {
+    us.M = M;
+    us.off.assign(off, off + M + 1);
+    us.rows = off[M] - off[0];
+    us.Tmax = 0;
+    us.Tmin = 0x7fffffff;
+    for (int m = 0; m < M; ++m) {
+        const int64_t T = off[m + 1] - off[m];
+        if (T < 1) return vlgp_fail(ctx, VLGP_ERR_ARG, "unit %d has %lld rows", m, (long long)T);
+        us.Tmax = std::max<int>(us.Tmax, (int)T);
+        us.Tmin = std::min<int>(us.Tmin, (int)T);
+    }
+    HIPCHK(ctx, hipMalloc(&us.d_off, sizeof(int64_t) * (M + 1)));
+    HIPCHK(ctx, hipMemcpyAsync(us.d_off, us.off.data(), sizeof(int64_t) * (M + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMalloc(&us.d_unit_prior, sizeof(int) * M));
+    us.prior_epoch = 0;
+    return VLGP_OK;
+}
+
+static int up(vlgp_ctx* ctx, double** dst, const double* src, int64_t n) {
+    CHK(dev_alloc(ctx, dst, n, src == nullptr));
+    if (src) HIPCHK(ctx, hipMemcpyAsync(*dst, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_upload_units(vlgp_ctx* ctx, int set, int M, const int64_t* offsets, const double* y,
+                                 const double* x, const double* mu, const double* v, const double* w) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, false);
+    if (!us) return VLGP_ERR_ARG;
+    if (M < 1 || !offsets || !y) return vlgp_fail(ctx, VLGP_ERR_ARG, "upload needs M >= 1, offsets and y");
+    if (offsets[0] != 0) return vlgp_fail(ctx, VLGP_ERR_ARG, "offsets[0] must be 0");
+    if (!x && ctx->P != 1) return vlgp_fail(ctx, VLGP_ERR_ARG, "x == NULL (all ones) requires xdim == 1");
+    for (auto& other : ctx->sets)
+        if (other.valid && other.alias && other.parent == set) free_set(ctx, other);
+    free_set(ctx, *us);
+    CHK(set_offsets(ctx, *us, M, offsets));
+    const int64_t rows = us->rows;
+    CHK(up(ctx, &us->y, y, rows * ctx->N));
+    us->x_ones = (x == nullptr);
+    if (x) CHK(up(ctx, &us->x, x, rows * ctx->P * ctx->N));
+    CHK(up(ctx, &us->mu, mu, rows * ctx->L));
+    CHK(up(ctx, &us->v, v, rows * ctx->L));
+    CHK(up(ctx, &us->w, w, rows * ctx->L));
+    CHK(dev_alloc(ctx, &us->dmu, rows * ctx->L, true));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are the caller's again
+    us->valid = true;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst, const int64_t* start, int window) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* s = vlgp_get_set(ctx, src, true);
+    UnitSet* d = vlgp_get_set(ctx, dst, false);
+    if (!s || !d) return VLGP_ERR_ARG;
+    if (src == dst || M_dst < 1 || window < 1 || !start) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad cut arguments");
+    if (s->alias) return vlgp_fail(ctx, VLGP_ERR_STATE, "cannot cut a set that is itself a cut");
+    bool exact = (int64_t)M_dst * window == s->rows;
+    for (int k = 0; k < M_dst; ++k) {
+        if (start[k] < 0 || start[k] + window > s->rows)
+            return vlgp_fail(ctx, VLGP_ERR_ARG, "segment %d [%lld, +%d) outside the source set", k, (long long)start[k], window);
+        if (start[k] != (int64_t)k * window) exact = false;
+    }
+    free_set(ctx, *d);
+    std::vector<int64_t> off(M_dst + 1);
+    for (int k = 0; k <= M_dst; ++k) off[k] = (int64_t)k * window;
+    CHK(set_offsets(ctx, *d, M_dst, off.data()));
+    d->parent = src;
+    d->x_ones = s->x_ones;
+    d->src_start.assign(start, start + M_dst);
+    HIPCHK(ctx, hipMalloc(&d->d_src_start, sizeof(int64_t) * M_dst));
+    HIPCHK(ctx, hipMemcpyAsync(d->d_src_start, start, sizeof(int64_t) * M_dst, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t rows = d->rows;
+    CHK(dev_alloc(ctx, &d->dmu, rows * ctx->L, true));
+    if (exact) {
+        d->alias = true;
+        d->y = s->y; d->x = s->x; d->mu = s->mu; d->v = s->v; d->w = s->w;
+    } else {
+        d->alias = false;
+        CHK(dev_alloc(ctx, &d->y, rows * ctx->N, false));
+        if (!s->x_ones) CHK(dev_alloc(ctx, &d->x, rows * ctx->P * ctx->N, false));
+        CHK(dev_alloc(ctx, &d->mu, rows * ctx->L, false));
+        CHK(dev_alloc(ctx, &d->v, rows * ctx->L, false));
+        CHK(dev_alloc(ctx, &d->w, rows * ctx->L, false));
+        CHK(launch_gather(ctx, *s, *d, window));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    d->valid = true;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_merge_units(vlgp_ctx* ctx, int cut_set) {
+    NEED_CTX(ctx);
+    UnitSet* c = vlgp_get_set(ctx, cut_set, true);
+    if (!c) return VLGP_ERR_ARG;
+    if (c->parent < 0) return vlgp_fail(ctx, VLGP_ERR_STATE, "set %d is not a cut", cut_set);
+    if (c->alias) return VLGP_OK;
+    UnitSet* p = vlgp_get_set(ctx, c->parent, true);
+    if (!p) return VLGP_ERR_STATE;
+    return launch_scatter(ctx, *c, *p, (int)(c->off[1] - c->off[0]));
+}
+
+extern "C" int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v, double* w, double* dmu) {
+    NEED_CTX(ctx);
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    const size_t nb = (size_t)us->rows * ctx->L * sizeof(double);
+    if (mu) HIPCHK(ctx, hipMemcpyAsync(mu, us->mu, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (v) HIPCHK(ctx, hipMemcpyAsync(v, us->v, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (w) HIPCHK(ctx, hipMemcpyAsync(w, us->w, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (dmu) HIPCHK(ctx, hipMemcpyAsync(dmu, us->dmu, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_free_units(vlgp_ctx* ctx, int set) {
+    NEED_CTX(ctx);
+    UnitSet* us = vlgp_get_set(ctx, set, false);
+    if (!us) return VLGP_ERR_ARG;
+    for (auto& other : ctx->sets)
+        if (other.valid && other.alias && other.parent == set) free_set(ctx, other);
+    free_set(ctx, *us);
+    return VLGP_OK;
+}
+
+// ---- parameters ------------------------------------------------------------
+extern "C" int vlgp_set_params(vlgp_ctx* ctx, const double* a, const double* b, const double* noise) {
+    NEED_CTX(ctx);
+    const int N = ctx->N, L = ctx->L, P = ctx->P;
+    if (a) HIPCHK(ctx, hipMemcpyAsync(ctx->d_a, a, sizeof(double) * L * N, hipMemcpyHostToDevice, ctx->stream));
+    if (b) HIPCHK(ctx, hipMemcpyAsync(ctx->d_b, b, sizeof(double) * P * N, hipMemcpyHostToDevice, ctx->stream));
+    if (noise) HIPCHK(ctx, hipMemcpyAsync(ctx->d_noise, noise, sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (a && b && noise) ctx->have_params = true;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_get_params(vlgp_ctx* ctx, double* a, double* b, double* noise, double* da, double* db) {
+    NEED_CTX(ctx);
+    const int N = ctx->N, L = ctx->L, P = ctx->P;
+    if (a) HIPCHK(ctx, hipMemcpyAsync(a, ctx->d_a, sizeof(double) * L * N, hipMemcpyDeviceToHost, ctx->stream));
+    if (b) HIPCHK(ctx, hipMemcpyAsync(b, ctx->d_b, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    if (noise) HIPCHK(ctx, hipMemcpyAsync(noise, ctx->d_noise, sizeof(double) * N, hipMemcpyDeviceToHost, ctx->stream));
+    if (da) HIPCHK(ctx, hipMemcpyAsync(da, ctx->d_da, sizeof(double) * L * N, hipMemcpyDeviceToHost, ctx->stream));
+    if (db) HIPCHK(ctx, hipMemcpyAsync(db, ctx->d_db, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+
+// ---- prior -----------------------------------------------------------------
+static int rebuild_prior_table(vlgp_ctx* ctx) {
+    const int L = ctx->L;
+    const int rows = (int)ctx->priors.size();
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_prior_base) (void)hipFree((void*)ctx->d_prior_base);
+    if (ctx->d_prior_rl) (void)hipFree(ctx->d_prior_rl);
+    if (ctx->d_prior_goff) (void)hipFree(ctx->d_prior_goff);
+    ctx->d_prior_base = nullptr; ctx->d_prior_rl = nullptr; ctx->d_prior_goff = nullptr;
+    ctx->prior_rows = rows;
+    ctx->prior_epoch++;
+    if (rows == 0) return VLGP_OK;
+    std::vector<const double*> base(rows);
+    std::vector<int> rl(rows * L);
+    std::vector<int64_t> goff(rows * L);
+    int i = 0;
+    for (auto& kv : ctx->priors) {
+        Prior& pr = kv.second;
+        pr.index = i;
+        base[i] = pr.d_compact;
+        for (int l = 0; l < L; ++l) {
+            rl[i * L + l] = pr.rl[l];
+            goff[i * L + l] = pr.goff[l];
+        }
+        ++i;
+    }
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_prior_base, sizeof(double*) * rows));
+    HIPCHK(ctx, hipMalloc(&ctx->d_prior_rl, sizeof(int) * rows * L));
+    HIPCHK(ctx, hipMalloc(&ctx->d_prior_goff, sizeof(int64_t) * rows * L));
+    HIPCHK(ctx, hipMemcpy((void*)ctx->d_prior_base, base.data(), sizeof(double*) * rows, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_prior_rl, rl.data(), sizeof(int) * rows * L, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_prior_goff, goff.data(), sizeof(int64_t) * rows * L, hipMemcpyHostToDevice));
+    return VLGP_OK;
+}
+
+static int new_prior(vlgp_ctx* ctx, int T, Prior** out) {
+    if (T < 1) return vlgp_fail(ctx, VLGP_ERR_ARG, "prior length must be positive");
+    auto it = ctx->priors.find(T);
+    if (it != ctx->priors.end()) {
+        *out = &it->second;
+        return VLGP_OK;
+    }
+    Prior pr;
+    pr.T = T;
+    const int64_t n = (int64_t)ctx->L * T * ctx->R;
+    HIPCHK(ctx, hipMalloc(&pr.d_full, (size_t)n * sizeof(double)));
+    HIPCHK(ctx, hipMalloc(&pr.d_compact, (size_t)n * sizeof(double)));
+    auto res = ctx->priors.emplace(T, pr);
+    *out = &res.first->second;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_clear_prior(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_priors(ctx);
+    return rebuild_prior_table(ctx);
+}
+
+extern "C" int vlgp_build_prior(vlgp_ctx* ctx, int n_lengths, const int* lengths, const double* omega,
+                                const double* sigma) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    if (n_lengths < 1 || !lengths || !omega || !sigma) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad build_prior arguments");
+    const int L = ctx->L;
+    // the reference replaces the whole dict on every call (gp.py:158); keep
+    // buffers of lengths that are rebuilt, drop the others
+    for (auto it = ctx->priors.begin(); it != ctx->priors.end();) {
+        if (std::find(lengths, lengths + n_lengths, it->first) == lengths + n_lengths) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (it->second.d_full) (void)hipFree(it->second.d_full);
+            if (it->second.d_compact) (void)hipFree(it->second.d_compact);
+            it = ctx->priors.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    int Tmax = 0;
+    for (int i = 0; i < n_lengths; ++i) Tmax = std::max(Tmax, lengths[i]);
+    CHK(vlgp_ensure_pinned(ctx, 2 * L + 8 * L + 64));
+    // hyper-parameters live at the tail of the workspace the ichol kernel sizes
+    const int64_t per = (int64_t)Tmax * ctx->R + Tmax;
+    const int64_t n_d = per * L + ((int64_t)L * Tmax + L + 1) / 2 + 1;
+    CHK(vlgp_ensure_work(ctx, n_d + 2 * L + 8));
+    double* d_hyp = ctx->d_work + n_d;
+    double* hp = ctx->h_pinned + 8 * L + 32;
+    for (int l = 0; l < L; ++l) { hp[l] = omega[l]; hp[L + l] = sigma[l]; }
+    HIPCHK(ctx, hipMemcpyAsync(d_hyp, hp, sizeof(double) * 2 * L, hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < n_lengths; ++i) {
+        Prior* pr = nullptr;
+        CHK(new_prior(ctx, lengths[i], &pr));
+        CHK(launch_ichol(ctx, *pr, d_hyp, d_hyp + L));
+    }
+    return rebuild_prior_table(ctx);
+}
+
+extern "C" int vlgp_set_prior(vlgp_ctx* ctx, int T, const double* G) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    if (!G) return vlgp_fail(ctx, VLGP_ERR_ARG, "null G");
+    Prior* pr = nullptr;
+    CHK(new_prior(ctx, T, &pr));
+    const int64_t n = (int64_t)ctx->L * T * ctx->R;
+    HIPCHK(ctx, hipMemcpyAsync(pr->d_full, G, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    CHK(launch_compact_prior(ctx, *pr));
+    return rebuild_prior_table(ctx);
+}
+
+extern "C" int vlgp_get_prior(vlgp_ctx* ctx, int T, double* G, int* rank_out) {
+    NEED_CTX(ctx);
+    auto it = ctx->priors.find(T);
+    if (it == ctx->priors.end()) return vlgp_fail(ctx, VLGP_ERR_STATE, "no prior factor for length %d", T);
+    const int64_t n = (int64_t)ctx->L * T * ctx->R;
+    if (G) {
+        HIPCHK(ctx, hipMemcpyAsync(G, it->second.d_full, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (rank_out)
+        for (int l = 0; l < ctx->L; ++l) rank_out[l] = it->second.rl[l];
+    return VLGP_OK;
+}
+
+int vlgp_bind_priors(vlgp_ctx* ctx, UnitSet& us) {
+    if (us.prior_epoch == ctx->prior_epoch) return VLGP_OK;
+    std::vector<int> idx(us.M);
+    for (int m = 0; m < us.M; ++m) {
+        const int T = (int)(us.off[m + 1] - us.off[m]);
+        auto it = ctx->priors.find(T);
+        if (it == ctx->priors.end())
+            return vlgp_fail(ctx, VLGP_ERR_STATE, "no prior factor for unit length %d (call build_prior/set_prior)", T);
+        idx[m] = it->second.index;
+    }
+    HIPCHK(ctx, hipMemcpy(us.d_unit_prior, idx.data(), sizeof(int) * us.M, hipMemcpyHostToDevice));
+    us.prior_epoch = ctx->prior_epoch;
+    return VLGP_OK;
+}
+
+int vlgp_refresh_xb(vlgp_ctx* ctx, UnitSet& us) {
+    if (us.x_ones) return VLGP_OK;
+    if (!us.d_xb) HIPCHK(ctx, hipMalloc(&us.d_xb, (size_t)us.rows * ctx->N * sizeof(double)));
+    return launch_xb(ctx, us);
+}
+
+// ---- E / M / H ---------------------------------------------------------------
+static int begin_count(vlgp_ctx* ctx) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_fail, 0, sizeof(int), ctx->stream));
+    return VLGP_OK;
+}
+static int end_count(vlgp_ctx* ctx, int* n_failed) {
+    if (!n_failed) return VLGP_OK;
+    HIPCHK(ctx, hipMemcpyAsync(n_failed, ctx->d_fail, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+#define NEED_PARAMS(ctx) \
+    if (!(ctx)->have_params) return vlgp_fail(ctx, VLGP_ERR_STATE, "parameters not set (vlgp_set_params)")
+
+extern "C" int vlgp_update_w(vlgp_ctx* ctx, int set) {
+    NEED_CTX(ctx);
+    NEED_PARAMS(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    return launch_estep(ctx, *us, EM_W, 0, 0.0, 0);
+}
+
+extern "C" int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed) {
+    NEED_CTX(ctx);
+    NEED_PARAMS(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (n_failed) *n_failed = 0;
+    if (!vb) return VLGP_OK;
+    CHK(begin_count(ctx));
+    CHK(launch_estep(ctx, *us, EM_FACTOR0 | EM_V, 0, 0.0, 1));
+    return end_count(ctx, n_failed);
+}
+
+extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb, int* n_failed) {
+    NEED_CTX(ctx);
+    NEED_PARAMS(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (n_failed) *n_failed = 0;
+    if (n_iter < 1) return VLGP_OK;  // core.py:24-25
+    if (!(dmu_bound > 0)) return vlgp_fail(ctx, VLGP_ERR_ARG, "dmu_bound must be positive");
+    CHK(begin_count(ctx));
+    CHK(launch_estep(ctx, *us, EM_FACTOR0 | EM_MEAN | EM_W | (vb ? EM_V : 0), n_iter, dmu_bound, vb ? 1 : 0));
+    return end_count(ctx, n_failed);
+}
+
+extern "C" int vlgp_mstep(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps, double lr,
+                          double da_bound, double db_bound, int* n_failed) {
+    NEED_CTX(ctx);
+    NEED_PARAMS(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (n_failed) *n_failed = 0;
+    if (n_iter < 1) return VLGP_OK;  // core.py:131-133
+    if (!(da_bound > 0) || !(db_bound > 0)) return vlgp_fail(ctx, VLGP_ERR_ARG, "da_bound/db_bound must be positive");
+    CHK(begin_count(ctx));
+    CHK(launch_mstep(ctx, *us, n_iter, use_hessian, eps, lr, da_bound, db_bound));
+    return end_count(ctx, n_failed);
+}
+
+extern "C" int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_eval, const int* latent,
+                                    const double* logp, double* ll, double* dll) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (n_eval < 1 || !latent || !logp || !ll || !dll) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad hstep arguments");
+    return launch_hstep(ctx, *us, window, dt, n_eval, latent, logp, ll, dll);
+}
+
+// ---- constraints / norms -----------------------------------------------------
+extern "C" int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const double* shift) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us || !map) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad latent map arguments");
+    const int L = ctx->L;
+    CHK(vlgp_ensure_work(ctx, L * L + L + 8));
+    CHK(vlgp_ensure_pinned(ctx, L * L + L + 8));
+    memcpy(ctx->h_pinned, map, sizeof(double) * L * L);
+    if (shift) memcpy(ctx->h_pinned + L * L, shift, sizeof(double) * L);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_pinned, sizeof(double) * (L * L + L), hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_latent_map(ctx, *us, ctx->d_work, shift ? ctx->d_work + L * L : nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // workspace and pinned buffer are reused
+    return VLGP_OK;
+}
+
+static int moments_host(vlgp_ctx* ctx, UnitSet& us, std::vector<double>& out) {
+    const int L = ctx->L;
+    const int K = L * (L + 1) / 2 + 3 * L + 1;
+    CHK(vlgp_ensure_pinned(ctx, K + 8));
+    CHK(launch_moments(ctx, us, ctx->d_work));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_work, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    out.assign(ctx->h_pinned, ctx->h_pinned + K);
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    std::vector<double> m;
+    CHK(moments_host(ctx, *us, m));
+    const int L = ctx->L, t = L * (L + 1) / 2;
+    double s = 0.0;
+    for (int l = 0; l < L; ++l) s += m[t + 2 * L + l];
+    out[0] = s;
+    out[1] = m[t + 3 * L];
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double* sum2, double* count) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    std::vector<double> m;
+    CHK(moments_host(ctx, *us, m));
+    const int L = ctx->L, t = L * (L + 1) / 2;
+    for (int l = 0; l < L; ++l) {
+        if (sum1) sum1[l] = m[t + l];
+        if (sum2) sum2[l] = m[t + 2 * L + l];
+    }
+    if (count) {
+        double c = (double)us->rows;
+        if (ctx->world > 1) {
+            CHK(vlgp_ensure_work(ctx, 8));
+            HIPCHK(ctx, hipMemcpy(ctx->d_work, &c, sizeof(double), hipMemcpyHostToDevice));
+            CHK(vlgp_allreduce(ctx, ctx->d_work, 1));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipMemcpy(&c, ctx->d_work, sizeof(double), hipMemcpyDeviceToHost));
+        }
+        *count = c;
+    }
+    return VLGP_OK;
+}
+
+// ---- measurement -------------------------------------------------------------
+extern "C" int vlgp_profile_enable(vlgp_ctx* ctx, int on) {
+    NEED_CTX(ctx);
+    if (!on) prof_drain(ctx);
+    ctx->prof_on = on != 0;
+    return VLGP_OK;
+}
+extern "C" int vlgp_profile_reset(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    prof_drain(ctx);
+    for (auto& p : ctx->prof) p = ProfSlot();
+    return VLGP_OK;
+}
+extern "C" int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
+    NEED_CTX(ctx);
+    if (kind < 0 || kind >= VLGP_PROF_KINDS) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad profile kind %d", kind);
+    prof_drain(ctx);
+    if (launches) *launches = ctx->prof[kind].launches;
+    if (total_ms) *total_ms = ctx->prof[kind].ms;
+    return VLGP_OK;
+}

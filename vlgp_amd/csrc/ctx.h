@@ -1,0 +1,132 @@
+// Internal state behind the opaque vlgp_ctx handle (host side, C++17).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vlgp_hip.h"
+
+#define VLGP_WAVE 64
+
+// One low-rank prior factor per distinct unit length (gp.make_cholesky).
+struct Prior {
+    int T = 0;
+    double* d_full = nullptr;     // (L, T, R) as the reference lays it out
+    double* d_compact = nullptr;  // per latent: (T, rl) row-major, zero columns dropped
+    std::vector<int> rl;          // effective rank per latent
+    std::vector<int64_t> goff;    // offset of latent l inside d_compact (doubles)
+    int64_t compact_len = 0;
+    int index = -1;               // row in the device prior table
+};
+
+struct UnitSet {
+    bool valid = false;
+    int M = 0;
+    int64_t rows = 0;
+    int Tmax = 0, Tmin = 0;
+    std::vector<int64_t> off;     // host copy of offsets (M+1)
+    int64_t* d_off = nullptr;
+    double *y = nullptr, *x = nullptr, *mu = nullptr, *v = nullptr, *w = nullptr, *dmu = nullptr;
+    bool x_ones = true;
+    bool alias = false;           // shares y/x/mu/v/w with `parent` (exact tiling cut)
+    int parent = -1;
+    std::vector<int64_t> src_start;  // for non-aliased cuts: source row of each unit
+    int64_t* d_src_start = nullptr;
+    int* d_unit_prior = nullptr;  // prior-table row per unit
+    uint64_t prior_epoch = 0;     // epoch of the table d_unit_prior was built against
+    double* d_xb = nullptr;       // (rows, N) x.b, only when !x_ones
+    double* d_scratch = nullptr;  // long-unit E-step scratch
+    int64_t scratch_len = 0;
+};
+
+struct ProfSlot {
+    int64_t launches = 0;
+    double ms = 0.0;
+};
+
+struct vlgp_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int N = 0, L = 0, P = 0, R = 0;
+    int n_cu = 256;
+    std::vector<uint8_t> gauss;   // host copy
+    int n_gauss = 0;
+    int* d_gauss = nullptr;       // (N) int flags
+    double *d_a = nullptr, *d_b = nullptr, *d_noise = nullptr, *d_da = nullptr, *d_db = nullptr;
+    bool have_params = false;
+
+    std::map<int, Prior> priors;
+    uint64_t prior_epoch = 1;
+    const double** d_prior_base = nullptr;  // table row -> compact base pointer
+    int* d_prior_rl = nullptr;              // (rows, L)
+    int64_t* d_prior_goff = nullptr;        // (rows, L)
+    int prior_rows = 0;
+
+    UnitSet sets[VLGP_MAX_SETS];
+
+    int* d_fail = nullptr;        // device failure counter
+    double* d_work = nullptr;     // general workspace (M-step partials, H-step, reductions)
+    int64_t work_len = 0;
+    double* h_pinned = nullptr;   // small pinned staging buffer
+    int64_t pinned_len = 0;
+
+    // profiling
+    bool prof_on = false;
+    ProfSlot prof[VLGP_PROF_KINDS];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+
+    // RCCL
+    void* comm = nullptr;         // ncclComm_t
+    int rank = 0, world = 1;
+
+    std::string err;
+};
+
+// ---- error plumbing ------------------------------------------------------
+int vlgp_fail(vlgp_ctx* ctx, int code, const char* fmt, ...);
+#define HIPCHK(ctx, call)                                                          \
+    do {                                                                           \
+        hipError_t e__ = (call);                                                   \
+        if (e__ != hipSuccess)                                                     \
+            return vlgp_fail(ctx, VLGP_ERR_HIP, "%s failed: %s (%s:%d)", #call,    \
+                             hipGetErrorString(e__), __FILE__, __LINE__);          \
+    } while (0)
+#define CHK(expr)                 \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != VLGP_OK) return rc__; \
+    } while (0)
+
+int vlgp_ensure_work(vlgp_ctx* ctx, int64_t n_doubles);
+int vlgp_ensure_pinned(vlgp_ctx* ctx, int64_t n_doubles);
+int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n);  // in place, sum, on ctx->stream
+int vlgp_bind_priors(vlgp_ctx* ctx, UnitSet& us);             // (re)build d_unit_prior
+int vlgp_refresh_xb(vlgp_ctx* ctx, UnitSet& us);              // xb = x.b when x is general
+UnitSet* vlgp_get_set(vlgp_ctx* ctx, int set, bool must_be_valid);
+
+// profiling brackets (HIP events on ctx->stream)
+void vlgp_prof_begin(vlgp_ctx* ctx, int kind);
+void vlgp_prof_end(vlgp_ctx* ctx, int kind);
+
+// ---- kernel launchers (one per translation unit) -------------------------
+// mode bits for the E-step kernel
+#define EM_FACTOR0 1   // factor I + G'WG from the incoming w before the first sweep
+#define EM_MEAN 2      // run mean-update sweeps (n_iter of them)
+#define EM_W 4         // recompute w
+#define EM_V 8         // update v from the factor
+int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bound, int vb);
+int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double eps, double lr,
+                 double da_bound, double db_bound);
+int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
+                 const double* logp, double* ll, double* dll);
+int launch_ichol(vlgp_ctx* ctx, Prior& pr, const double* d_omega, const double* d_sigma);
+int launch_compact_prior(vlgp_ctx* ctx, Prior& pr);  // d_full -> rl, d_compact
+int launch_xb(vlgp_ctx* ctx, UnitSet& us);
+int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
+int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out /* 2L+2: sum1, sum2, |mu|^2, |dmu|^2 */);
+int launch_gather(vlgp_ctx* ctx, UnitSet& src, UnitSet& dst, int window);
+int launch_scatter(vlgp_ctx* ctx, UnitSet& cut, UnitSet& dst, int window);

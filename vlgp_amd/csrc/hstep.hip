@@ -1,0 +1,311 @@
+// H-step objective of vLGP on gfx950: the function scipy's L-BFGS-B minimises
+// in gp.optimze1d (vlgp/gp.py:100-123) = construct_posterior_cov
+// (gp.py:126-147) + elbo (gp.py:12-43) with gradient mask [0, 1, 0].
+//
+// For one latent and log-parameters (sigma^2, omega, eps), with K the T x T
+// squared-exponential kernel over one window, per segment i
+//     S_i = (K^-1 + diag w_i)^-1
+//     ll_i  = -1/2 mu_i' K^-1 mu_i - 1/2 tr(K^-1 S_i) - sum log diag chol(K)
+//     dll_i = 1/2 tr[(alpha alpha' - K^-1 + K^-1 S_i K^-1) dK/dln(omega)]
+// Shared per evaluation (prep kernel, one workgroup): K^-1, Q = K^-1 dK K^-1,
+// tr(K^-1 dK), log det.  Per segment (one wavefront each, factor in LDS):
+// Cholesky of K^-1 + W, its triangular inverse X, and the two Frobenius
+// products <X'X, K^-1>, <X'X, Q> accumulated without materialising S.
+#include "ctx.h"
+
+#define HS_MAXT 64
+
+struct HPrepArgs {
+    int T;
+    double dt;
+    const double* logp;  // (n_eval, 3)
+    double* kinv;        // (n_eval, T, T)
+    double* q;           // (n_eval, T, T)
+    double* dk;          // (n_eval, T, T)
+    double* scal;        // (n_eval, 4): logdet, tr(Kinv dK), omega_used, ok
+};
+
+__device__ __forceinline__ void hs_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// wave-level in-place Cholesky (lower) + triangular inverse of an n x n matrix in
+// LDS with row stride ls; returns false on a non-positive pivot.  On success the
+// lower triangle holds X = chol^-1 and *logdet = sum log diag(chol).
+__device__ bool wave_chol_inv(double* Amat, int n, int ls, int lane, double* logdet) {
+    double ld = 0.0;
+    for (int k = 0; k < n; ++k) {
+        double s = 0.0;
+        const bool act = lane >= k && lane < n;
+        if (act) {
+            s = Amat[lane * ls + k];
+            for (int i = 0; i < k; ++i) s = fma(-Amat[lane * ls + i], Amat[k * ls + i], s);
+        }
+        const double d = __shfl(s, k, 64);
+        if (!(d > 0.0) || !(d < 1e300)) return false;
+        const double sd = sqrt(d);
+        ld += log(sd);
+        if (act) Amat[lane * ls + k] = (lane == k) ? sd : s / sd;
+        hs_wave_sync();
+    }
+    for (int i = 0; i < n; ++i) {
+        const double lii = Amat[i * ls + i];
+        double acc = 0.0;
+        if (lane < i)
+            for (int j = lane; j < i; ++j) acc = fma(Amat[i * ls + j], Amat[j * ls + lane], acc);
+        hs_wave_sync();
+        if (lane < i) Amat[i * ls + lane] = -acc / lii;
+        else if (lane == i) Amat[i * ls + i] = 1.0 / lii;
+        hs_wave_sync();
+    }
+    *logdet = ld;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) hstep_prep_kernel(HPrepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[256];
+    __shared__ int s_ok;
+    __shared__ double s_logdet;
+    const int T = A.T, ls = T | 1;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double* Km = smem;            // T x ls : K, then chol, then X
+    double* Ki = Km + T * ls;     // T x T  : K^-1
+    double* Dk = Ki + T * T;      // T x T  : dK/dln omega
+    double* Tm = Dk + T * T;      // T x T  : K^-1 dK
+    const double sigmasq = exp(A.logp[3 * e + 0]);
+    double omega = exp(A.logp[3 * e + 1]);
+    const double eps = exp(A.logp[3 * e + 2]);
+
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        for (int i = tid; i < T * T; i += 256) {
+            const int r = i / T, c = i - r * T;
+            const double d = (r - c) * A.dt;
+            const double d2 = d * d;
+            const double kv = sigmasq * exp(-omega * d2);
+            Km[r * ls + c] = kv + (r == c ? eps : 0.0);
+            Dk[i] = -kv * d2 * omega;
+        }
+        __syncthreads();
+        if (wid == 0) {
+            double ld;
+            const bool ok = wave_chol_inv(Km, T, ls, lane, &ld);
+            if (lane == 0) { s_ok = ok; s_logdet = ld; }
+        }
+        __syncthreads();
+        if (s_ok) break;
+        omega += 2.302585092994046;  // gp.py:135 adds log(10) to omega itself
+        __syncthreads();
+    }
+    // K^-1 = X'X
+    for (int i = tid; i < T * T; i += 256) {
+        const int r = i / T, c = i - r * T;
+        const int k0 = r > c ? r : c;
+        double s = 0.0;
+        for (int k = k0; k < T; ++k) s = fma(Km[k * ls + r], Km[k * ls + c], s);
+        Ki[i] = s;
+    }
+    __syncthreads();
+    double tr = 0.0;
+    for (int i = tid; i < T * T; i += 256) {
+        const int r = i / T, c = i - r * T;
+        double s = 0.0;
+        for (int k = 0; k < T; ++k) s = fma(Ki[r * T + k], Dk[k * T + c], s);
+        Tm[i] = s;
+        tr += Ki[i] * Dk[i];
+    }
+    red[tid] = tr;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const int64_t base = (int64_t)e * T * T;
+    for (int i = tid; i < T * T; i += 256) {
+        const int r = i / T, c = i - r * T;
+        double s = 0.0;
+        for (int k = 0; k < T; ++k) s = fma(Tm[r * T + k], Ki[k * T + c], s);
+        A.q[base + i] = s;
+        A.kinv[base + i] = Ki[i];
+        A.dk[base + i] = Dk[i];
+    }
+    if (tid == 0) {
+        A.scal[4 * e + 0] = s_logdet;
+        A.scal[4 * e + 1] = red[0];
+        A.scal[4 * e + 2] = omega;
+        A.scal[4 * e + 3] = s_ok ? 1.0 : 0.0;
+    }
+}
+
+struct HSegArgs {
+    int T, L, M;
+    const int64_t* off;
+    const double* mu;
+    const double* w;
+    const int* latent;   // (n_eval)
+    const double* kinv;
+    const double* q;
+    const double* dk;
+    const double* scal;
+    double* out;         // (n_eval, M, 2)
+};
+
+// one wavefront per (segment, evaluation)
+__global__ void __launch_bounds__(256) hstep_seg_kernel(HSegArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int T = A.T, ls = T | 1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int seg = blockIdx.x * nw + wid;
+    const int e = blockIdx.y;
+    if (seg >= A.M) return;
+    double* B = smem + (int64_t)wid * (T * ls + 2 * HS_MAXT);
+    double* muv = B + T * ls;
+    double* alv = muv + HS_MAXT;
+    const int l = A.latent[e];
+    const int64_t r0 = A.off[seg];
+    const double* Ki = A.kinv + (int64_t)e * T * T;
+    const double* Q = A.q + (int64_t)e * T * T;
+    const double* Dk = A.dk + (int64_t)e * T * T;
+
+    double mu_t = 0.0, w_t = 0.0;
+    if (lane < T) {
+        mu_t = A.mu[(r0 + lane) * A.L + l];
+        w_t = A.w[(r0 + lane) * A.L + l];
+    }
+    muv[lane] = mu_t;
+    for (int i = lane; i < T * T; i += 64) {
+        const int r = i / T, c = i - r * T;
+        B[r * ls + c] = Ki[i];
+    }
+    hs_wave_sync();
+    if (lane < T) B[lane * ls + lane] += w_t;
+    // alpha = K^-1 mu (K^-1 symmetric: read columns for coalescing)
+    double al = 0.0;
+    if (lane < T)
+        for (int j = 0; j < T; ++j) al = fma(Ki[j * T + lane], muv[j], al);
+    alv[lane] = al;
+    hs_wave_sync();
+    double quad = mu_t * al;
+    double gq = 0.0;
+    if (lane < T) {
+        double s = 0.0;
+        for (int j = 0; j < T; ++j) s = fma(Dk[j * T + lane], alv[j], s);
+        gq = s * al;
+    }
+    double ld;
+    const bool ok = wave_chol_inv(B, T, ls, lane, &ld);
+    double sk = 0.0, sq = 0.0;
+    if (ok) {
+        const int ne = T * (T + 1) / 2;
+        for (int idx = lane; idx < ne; idx += 64) {
+            int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            while (i * (i + 1) / 2 > idx) --i;
+            while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+            const int j = idx - i * (i + 1) / 2;
+            double s = 0.0;
+            for (int k = i; k < T; ++k) s = fma(B[k * ls + i], B[k * ls + j], s);
+            const double f = (i == j) ? 1.0 : 2.0;
+            sk = fma(f * s, Ki[i * T + j], sk);
+            sq = fma(f * s, Q[i * T + j], sq);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        quad += __shfl_xor(quad, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+        sk += __shfl_xor(sk, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+    }
+    if (lane == 0) {
+        const double logdet = A.scal[4 * e + 0], trkd = A.scal[4 * e + 1];
+        double ll = -0.5 * quad - 0.5 * sk - logdet;
+        double dll = 0.5 * (gq - trkd + sq);
+        if (!ok) { ll = nan(""); dll = nan(""); }
+        A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
+        A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
+    }
+}
+
+// out[e][c] = sum_i in[e][i][c]  (fixed order: strided partial sums, then a tree)
+__global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* in, double* out) {
+    __shared__ double r0[256], r1[256];
+    const int e = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        a += in[((int64_t)e * M + i) * 2 + 0];
+        b += in[((int64_t)e * M + i) * 2 + 1];
+    }
+    r0[threadIdx.x] = a;
+    r1[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            r0[threadIdx.x] += r0[threadIdx.x + o];
+            r1[threadIdx.x] += r1[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * e + 0] = r0[0];
+        out[2 * e + 1] = r1[0];
+    }
+}
+
+int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
+                 const double* logp, double* ll, double* dll) {
+    const int T = window, L = ctx->L, M = us.M;
+    if (T > HS_MAXT) return vlgp_fail(ctx, VLGP_ERR_ARG, "H-step kernel supports window <= %d, got %d", HS_MAXT, T);
+    if (us.Tmin != T || us.Tmax != T)
+        return vlgp_fail(ctx, VLGP_ERR_STATE, "H-step needs every unit to have exactly window=%d rows", T);
+    const int64_t TT = (int64_t)T * T;
+    // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
+    const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
+    const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 2 * n_eval;
+    const int64_t o_lat = o_logp + 3 * n_eval, total = o_lat + n_eval + 8;
+    CHK(vlgp_ensure_work(ctx, total));
+    CHK(vlgp_ensure_pinned(ctx, 8 * n_eval + 16));
+    double* W = ctx->d_work;
+    double* hp = ctx->h_pinned;
+    for (int i = 0; i < 3 * n_eval; ++i) hp[i] = logp[i];
+    int* hlat = reinterpret_cast<int*>(hp + 3 * n_eval);
+    for (int i = 0; i < n_eval; ++i) {
+        if (latent[i] < 0 || latent[i] >= L) return vlgp_fail(ctx, VLGP_ERR_ARG, "latent index out of range");
+        hlat[i] = latent[i];
+    }
+    HIPCHK(ctx, hipMemcpyAsync(W + o_logp, hp, sizeof(double) * 3 * n_eval, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(W + o_lat, hlat, sizeof(int) * n_eval, hipMemcpyHostToDevice, ctx->stream));
+
+    HPrepArgs P;
+    P.T = T; P.dt = dt; P.logp = W + o_logp; P.kinv = W + o_kinv; P.q = W + o_q; P.dk = W + o_dk;
+    P.scal = W + o_scal;
+    const size_t lds_prep = (size_t)(T * (T | 1) + 3 * TT) * 8;
+    if (lds_prep > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+    hipLaunchKernelGGL(hstep_prep_kernel, dim3(n_eval), dim3(256), lds_prep, ctx->stream, P);
+    HIPCHK(ctx, hipGetLastError());
+
+    HSegArgs S;
+    S.T = T; S.L = L; S.M = M; S.off = us.d_off; S.mu = us.mu; S.w = us.w;
+    S.latent = reinterpret_cast<const int*>(W + o_lat);
+    S.kinv = W + o_kinv; S.q = W + o_q; S.dk = W + o_dk; S.scal = W + o_scal; S.out = W + o_out;
+    const int nw = 2;
+    const size_t lds_seg = (size_t)nw * (T * (T | 1) + 2 * HS_MAXT) * 8;
+    vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
+    hipLaunchKernelGGL(hstep_seg_kernel, dim3((M + nw - 1) / nw, n_eval), dim3(64 * nw), lds_seg, ctx->stream, S);
+    vlgp_prof_end(ctx, VLGP_PROF_HSTEP);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
+    double* hres = hp + 4 * n_eval + 8;
+    HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 2 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int e = 0; e < n_eval; ++e) {
+        ll[e] = hres[2 * e + 0];
+        dll[3 * e + 0] = 0.0;
+        dll[3 * e + 1] = hres[2 * e + 1];
+        dll[3 * e + 2] = 0.0;
+    }
+    return VLGP_OK;
+}

@@ -1,0 +1,617 @@
+// M-step of vLGP on gfx950 (core.mstep, vlgp/core.py:129-249).
+//
+// All units are treated as one (rows x N) matrix.  Per Newton iteration the
+// reference recomputes the rate and then, per channel n, forms
+//     grad_a = mu' y_n - (mu + v a_n)' r_n
+//     nhess_a = (mu + v a_n)' diag(r_n) (mu + v a_n) + diag(r_n' v)
+//     grad_b = x_n' (y_n - r_n),  nhess_b = x_n' diag(r_n) x_n
+// (core.py:181-220).  The y-dependent halves (mu'y, x'y) do not change inside
+// the M-step, so they are accumulated once (PREP pass, the only full read of y
+// besides the noise pass); each Newton iteration then streams mu, v (and x if
+// it is not identically 1) and accumulates the rate-dependent sums.  Gaussian
+// channels use the closed-form alternating least squares of core.py:224-235,
+// which only needs moments gathered in the PREP pass.
+//
+// Mapping: lane <-> channel (coalesced rows of y/x), several row slices per
+// workgroup, accumulators in registers, mu/v row tiles broadcast from LDS.
+// Reduction is deterministic: per-workgroup partials, then a fixed-order sum,
+// then (multi-GPU) one RCCL all-reduce of the fused statistics buffer.
+#include <type_traits>
+
+#include "ctx.h"
+
+#define M_TILE 64
+
+enum { K_PREP = 0, K_NEWTON = 1, K_NOISE1 = 2, K_NOISE2 = 3 };
+
+struct MArgs {
+    int N, L, P;
+    int64_t rows;
+    int rows_per_wg;
+    int CT;          // channels per tile (grid.y tiles)
+    int S;           // row slices per workgroup
+    const double* y;
+    const double* x;  // null = ones
+    const double* mu;
+    const double* v;
+    const double* a;
+    const double* b;
+    const int* gauss;
+    const double* mean;  // NOISE2: per-channel mean of (y - eta)
+    double* partial;     // (G, K, N)
+};
+
+__host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
+template <int LT, int PT, int KIND>
+__host__ __device__ constexpr int nacc() {
+    return KIND == K_PREP ? LT + PT + PT * LT + tri(PT)
+         : KIND == K_NEWTON ? 2 * LT + tri(LT) + PT + tri(PT)
+         : 1;
+}
+// runtime (exact L, P) number of statistics per channel
+static inline int nstat_rt(int L, int P, int kind) {
+    return kind == K_PREP ? L + P + P * L + tri(P) : kind == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+}
+
+template <int LT, int PT, int KIND>
+__global__ void __launch_bounds__(512) mstep_accum(MArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NA = nacc<LT, PT, KIND>();
+    const int N = A.N, L = A.L, P = A.P, CT = A.CT, S = A.S;
+    const int tid = threadIdx.x;
+    const int nl = tid % CT, s = tid / CT;
+    const int n = blockIdx.y * CT + nl;
+    const bool active = s < S && n < N;
+    double* mu_t = smem;               // M_TILE x L
+    double* v_t = mu_t + M_TILE * L;   // M_TILE x L
+    double* red = v_t + M_TILE * L;    // S x CT
+
+    double al[LT], bl[PT], acc[NA];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) al[l] = (active && l < L) ? A.a[l * N + n] : 0.0;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) bl[j] = (active && j < P) ? A.b[j * N + n] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+    const bool gch = active ? A.gauss[n] != 0 : false;
+    const double shift = (KIND == K_NOISE2 && active) ? A.mean[n] : 0.0;
+
+    const int64_t c0 = (int64_t)blockIdx.x * A.rows_per_wg;
+    int64_t c1 = c0 + A.rows_per_wg;
+    if (c1 > A.rows) c1 = A.rows;
+    for (int64_t t0 = c0; t0 < c1; t0 += M_TILE) {
+        const int nr = (int)((c1 - t0) < M_TILE ? (c1 - t0) : M_TILE);
+        __syncthreads();
+        for (int i = tid; i < nr * L; i += blockDim.x) {
+            mu_t[i] = A.mu[t0 * L + i];
+            v_t[i] = A.v[t0 * L + i];
+        }
+        __syncthreads();
+        if (!active) continue;
+        if (KIND == K_NEWTON && gch) continue;  // Gaussian channels need no rate statistics
+        for (int rr = s; rr < nr; rr += S) {
+            const int64_t row = t0 + rr;
+            double xv[PT];
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                xv[j] = (j < P) ? (A.x ? A.x[(row * P + j) * N + n] : 1.0) : 0.0;
+            double mr[LT], vr[LT];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                mr[l] = l < L ? mu_t[rr * L + l] : 0.0;
+                vr[l] = l < L ? v_t[rr * L + l] : 0.0;
+            }
+            if constexpr (KIND == K_PREP) {
+                const double yv = A.y[row * N + n];
+                int k = 0;
+#pragma unroll
+                for (int l = 0; l < LT; ++l) { acc[k] = fma(mr[l], yv, acc[k]); ++k; }
+#pragma unroll
+                for (int j = 0; j < PT; ++j) { acc[k] = fma(xv[j], yv, acc[k]); ++k; }
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) { acc[k] = fma(xv[j], mr[l], acc[k]); ++k; }
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) { acc[k] = fma(xv[i], xv[j], acc[k]); ++k; }
+            } else {
+                double eta = 0.0, lin = 0.0;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) eta = fma(xv[j], bl[j], eta);
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    eta = fma(mr[l], al[l], eta);
+                    lin = fma(vr[l] * al[l], al[l], lin);
+                }
+                if constexpr (KIND == K_NEWTON) {
+                    const double rate = exp(fmin(fma(0.5, lin, eta), 10.0));
+                    double mt[LT], q[LT];
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        mt[l] = fma(vr[l], al[l], mr[l]);
+                        q[l] = mt[l] * rate;
+                    }
+                    int k = 0;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) { acc[k] += q[l]; ++k; }
+#pragma unroll
+                    for (int i = 0; i < LT; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) { acc[k] = fma(q[i], mt[j], acc[k]); ++k; }
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) { acc[k] = fma(rate, vr[l], acc[k]); ++k; }
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) { acc[k] = fma(xv[j], rate, acc[k]); ++k; }
+#pragma unroll
+                    for (int i = 0; i < PT; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) { acc[k] = fma(xv[i] * xv[j], rate, acc[k]); ++k; }
+                } else {
+                    const double dres = A.y[row * N + n] - eta - shift;
+                    if constexpr (KIND == K_NOISE1) acc[0] += dres;
+                    else acc[0] = fma(dres, dres, acc[0]);
+                }
+            }
+        }
+    }
+    // slices -> one partial per workgroup, statistic by statistic.  The
+    // template index k (padded LT/PT) is mapped to the exact (L, P) layout.
+    auto emit = [&](int k_exact, double val) {
+        __syncthreads();
+        if (s < S) red[s * CT + nl] = active ? val : 0.0;
+        __syncthreads();
+        if (s == 0 && n < N) {
+            double t = 0.0;
+            for (int q = 0; q < S; ++q) t += red[q * CT + nl];
+            const int K = KIND == K_PREP ? L + P + P * L + tri(P)
+                        : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+            A.partial[((int64_t)blockIdx.x * K + k_exact) * N + n] = t;
+        }
+    };
+    if constexpr (KIND == K_PREP) {
+        int k = 0, ke = 0;
+#pragma unroll
+        for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+#pragma unroll
+        for (int j = 0; j < PT; ++j, ++k) if (j < P) emit(ke++, acc[k]);
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+#pragma unroll
+            for (int l = 0; l < LT; ++l, ++k) if (j < P && l < L) emit(ke++, acc[k]);
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j, ++k) if (i < P) emit(ke++, acc[k]);
+    } else if constexpr (KIND == K_NEWTON) {
+        int k = 0, ke = 0;
+#pragma unroll
+        for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j, ++k) if (i < L) emit(ke++, acc[k]);
+#pragma unroll
+        for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+#pragma unroll
+        for (int j = 0; j < PT; ++j, ++k) if (j < P) emit(ke++, acc[k]);
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j, ++k) if (i < P) emit(ke++, acc[k]);
+    } else {
+        emit(0, acc[0]);
+    }
+}
+
+// out[i] = sum_g partial[g][i], fixed order
+__global__ void __launch_bounds__(256) sum_partials_kernel(const double* partial, int G, int64_t K, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += partial[(int64_t)g * K + i];
+    out[i] = s;
+}
+
+// latent-only moments: Gram of mu (lower), column sums of mu and v, sums of squares
+// out layout: [tri(L) gram | L sum_mu | L sum_v | L sum_mu^2 | 1 |dmu|^2 ]
+template <int LT>
+__global__ void __launch_bounds__(256)
+latent_moments_kernel(int L, int64_t rows, const double* mu, const double* v, const double* dmu,
+                      double* partial) {
+    __shared__ double red[256];
+    constexpr int NA = tri(LT) + 3 * LT + 1;
+    double acc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+        double mr[LT], vr[LT], dr[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            mr[l] = l < L ? mu[t * L + l] : 0.0;
+            vr[l] = (v && l < L) ? v[t * L + l] : 0.0;
+            dr[l] = (dmu && l < L) ? dmu[t * L + l] : 0.0;
+        }
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) { acc[k] = fma(mr[i], mr[j], acc[k]); ++k; }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) { acc[k] += mr[l]; ++k; }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) { acc[k] += vr[l]; ++k; }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) { acc[k] = fma(mr[l], mr[l], acc[k]); ++k; }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) acc[k] = fma(dr[l], dr[l], acc[k]);
+    }
+    const int K = tri(L) + 3 * L + 1;
+    auto emit = [&](int ke, double val) {
+        __syncthreads();
+        red[threadIdx.x] = val;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * K + ke] = red[0];
+    };
+    int k = 0, ke = 0;
+#pragma unroll
+    for (int i = 0; i < LT; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j, ++k) if (i < L) emit(ke++, acc[k]);
+#pragma unroll
+    for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+#pragma unroll
+    for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+#pragma unroll
+    for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+    emit(ke, acc[k]);
+}
+
+// ---- per-channel Newton / least-squares update -----------------------------
+#define SOLVE_MAXD 16
+// in-place Cholesky solve of the packed-lower SPD system H x = g (dimension d);
+// returns false on a non-positive pivot.
+__device__ bool chol_solve_small(int d, double* H /* d*d full, lower used */, double* g) {
+    for (int k = 0; k < d; ++k) {
+        double s = H[k * d + k];
+        for (int i = 0; i < k; ++i) s -= H[k * d + i] * H[k * d + i];
+        if (!(s > 0.0) || !(s < 1e300)) return false;
+        const double sd = sqrt(s);
+        H[k * d + k] = sd;
+        for (int j = k + 1; j < d; ++j) {
+            double t = H[j * d + k];
+            for (int i = 0; i < k; ++i) t -= H[j * d + i] * H[k * d + i];
+            H[j * d + k] = t / sd;
+        }
+    }
+    for (int i = 0; i < d; ++i) {
+        double t = g[i];
+        for (int j = 0; j < i; ++j) t -= H[i * d + j] * g[j];
+        g[i] = t / H[i * d + i];
+    }
+    for (int i = d - 1; i >= 0; --i) {
+        double t = g[i];
+        for (int j = i + 1; j < d; ++j) t -= H[j * d + i] * g[j];
+        g[i] = t / H[i * d + i];
+    }
+    return true;
+}
+
+struct SolveArgs {
+    int N, L, P;
+    int use_hessian;
+    double eps, lr, da_bound, db_bound;
+    const double* prep;   // (Kprep, N): MtY, XtY, XtM, XtX
+    const double* stats;  // (Knewton, N)
+    const double* lat;    // tri(L) gram | L sum_mu | L sum_v | ...
+    const int* gauss;
+    double *a, *b, *da, *db;
+    int* fail;
+};
+
+__global__ void __launch_bounds__(64) mstep_solve_kernel(SolveArgs A) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= A.N) return;
+    const int N = A.N, L = A.L, P = A.P;
+    double H[SOLVE_MAXD * SOLVE_MAXD], g[SOLVE_MAXD];
+    const double* MtY = A.prep;                       // L rows
+    const double* XtY = A.prep + (int64_t)L * N;      // P rows
+    const double* XtM = XtY + (int64_t)P * N;         // P*L rows: [j*L + l]
+    const double* XtX = XtM + (int64_t)P * L * N;     // tri(P) rows
+    if (!A.gauss[n]) {
+        const double* g1 = A.stats;
+        const double* Hs = g1 + (int64_t)L * N;
+        const double* rv = Hs + (int64_t)tri(L) * N;
+        const double* gb = rv + (int64_t)L * N;
+        const double* Hb = gb + (int64_t)P * N;
+        // loading
+        for (int l = 0; l < L; ++l) g[l] = MtY[(int64_t)l * N + n] - g1[(int64_t)l * N + n];
+        bool newton = A.use_hessian != 0;
+        if (newton) {
+            int k = 0;
+            for (int i = 0; i < L; ++i)
+                for (int j = 0; j <= i; ++j, ++k) H[i * L + j] = Hs[(int64_t)k * N + n];
+            for (int l = 0; l < L; ++l) H[l * L + l] += rv[(int64_t)l * N + n] + A.eps;
+            double gs[SOLVE_MAXD];
+            for (int l = 0; l < L; ++l) gs[l] = g[l];
+            if (chol_solve_small(L, H, gs)) {
+                for (int l = 0; l < L; ++l) g[l] = gs[l];
+            } else {
+                newton = false;
+                atomicAdd(A.fail, 1);
+            }
+        }
+        for (int l = 0; l < L; ++l) {
+            double st = newton ? g[l] : A.lr * g[l];
+            st = fmin(fmax(st, -A.da_bound), A.da_bound);
+            A.da[(int64_t)l * N + n] = st;
+            A.a[(int64_t)l * N + n] += st;
+        }
+        // bias / regression (uses the same, un-refreshed rate: core.py:205)
+        for (int j = 0; j < P; ++j) g[j] = XtY[(int64_t)j * N + n] - gb[(int64_t)j * N + n];
+        newton = A.use_hessian != 0;
+        if (newton) {
+            int k = 0;
+            for (int i = 0; i < P; ++i)
+                for (int j = 0; j <= i; ++j, ++k) H[i * P + j] = Hb[(int64_t)k * N + n];
+            for (int j = 0; j < P; ++j) H[j * P + j] += A.eps;
+            double gs[SOLVE_MAXD];
+            for (int j = 0; j < P; ++j) gs[j] = g[j];
+            if (chol_solve_small(P, H, gs)) {
+                for (int j = 0; j < P; ++j) g[j] = gs[j];
+            } else {
+                newton = false;
+                atomicAdd(A.fail, 1);
+            }
+        }
+        for (int j = 0; j < P; ++j) {
+            double st = newton ? g[j] : A.lr * g[j];
+            st = fmin(fmax(st, -A.db_bound), A.db_bound);
+            A.db[(int64_t)j * N + n] = st;
+            A.b[(int64_t)j * N + n] += st;
+        }
+    } else {
+        // Gaussian channel: a_n = (M'M + diag(sum v))^-1 M'(y_n - X_n b_n), then
+        // b_n = (X_n'X_n)^-1 X_n'(y_n - M a_n), b_n[1:] = 0   (core.py:224-235)
+        const double* gram = A.lat;
+        const double* sumv = A.lat + tri(L) + L;
+        int k = 0;
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j <= i; ++j, ++k) H[i * L + j] = gram[k];
+        for (int l = 0; l < L; ++l) H[l * L + l] += sumv[l];
+        for (int l = 0; l < L; ++l) {
+            double t = MtY[(int64_t)l * N + n];
+            for (int j = 0; j < P; ++j) t -= XtM[((int64_t)j * L + l) * N + n] * A.b[(int64_t)j * N + n];
+            g[l] = t;
+        }
+        if (!chol_solve_small(L, H, g)) {
+            atomicAdd(A.fail, 1);
+            return;
+        }
+        for (int l = 0; l < L; ++l) A.a[(int64_t)l * N + n] = g[l];
+        double an[SOLVE_MAXD];
+        for (int l = 0; l < L; ++l) an[l] = g[l];
+        k = 0;
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j <= i; ++j, ++k) H[i * P + j] = XtX[(int64_t)k * N + n];
+        for (int j = 0; j < P; ++j) {
+            double t = XtY[(int64_t)j * N + n];
+            for (int l = 0; l < L; ++l) t -= XtM[((int64_t)j * L + l) * N + n] * an[l];
+            g[j] = t;
+        }
+        if (!chol_solve_small(P, H, g)) {
+            atomicAdd(A.fail, 1);
+            return;
+        }
+        A.b[(int64_t)0 * N + n] = g[0];
+        for (int j = 1; j < P; ++j) A.b[(int64_t)j * N + n] = 0.0;
+    }
+}
+
+__global__ void noise_mean_kernel(int N, double count, const double* s1, double* mean) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) mean[n] = s1[n] / count;
+}
+__global__ void noise_final_kernel(int N, double count, const double* s2, double* noise) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) noise[n] = s2[n] / count;
+}
+__global__ void zero_kernel(int64_t n, double* p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+struct Geometry {
+    int G, rows_per_wg, CT, S, nthr, tiles;
+    size_t lds;
+};
+
+static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
+    Geometry g;
+    const int N = ctx->N, L = ctx->L;
+    if (N <= 512) {
+        g.CT = N;
+        double best = -1.0;
+        g.nthr = 512;
+        for (int k = 2; k <= 8; ++k) {
+            const int nt = 64 * k;
+            if (nt < N) continue;
+            const double u = (double)((nt / N) * N) / nt;
+            if (u > best + 1e-9) { best = u; g.nthr = nt; }
+        }
+        g.S = g.nthr / N;
+        g.tiles = 1;
+    } else {
+        g.CT = 512;
+        g.nthr = 512;
+        g.S = 1;
+        g.tiles = (N + 511) / 512;
+    }
+    int64_t G = (rows + 63) / 64;
+    const int64_t cap = 2LL * ctx->n_cu;
+    if (G > cap) G = cap;
+    if (G < 1) G = 1;
+    g.rows_per_wg = (int)((rows + G - 1) / G);
+    g.rows_per_wg = ((g.rows_per_wg + M_TILE - 1) / M_TILE) * M_TILE;
+    g.G = (int)((rows + g.rows_per_wg - 1) / g.rows_per_wg);
+    g.lds = (size_t)(2 * M_TILE * L + g.S * g.CT) * 8;
+    return g;
+}
+
+template <int LT, int PT>
+static void launch_accum_k(hipStream_t st, int kind, const Geometry& g, const MArgs& A) {
+    dim3 grid(g.G, g.tiles), blk(g.nthr);
+    switch (kind) {
+        case K_PREP: hipLaunchKernelGGL((mstep_accum<LT, PT, K_PREP>), grid, blk, g.lds, st, A); break;
+        case K_NEWTON: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NEWTON>), grid, blk, g.lds, st, A); break;
+        case K_NOISE1: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NOISE1>), grid, blk, g.lds, st, A); break;
+        default: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NOISE2>), grid, blk, g.lds, st, A); break;
+    }
+}
+template <int LT>
+static int launch_accum_p(vlgp_ctx* ctx, int kind, const Geometry& g, const MArgs& A) {
+    const int P = A.P;
+    if (P <= 1) launch_accum_k<LT, 1>(ctx->stream, kind, g, A);
+    else if (P <= 2) launch_accum_k<LT, 2>(ctx->stream, kind, g, A);
+    else if (P <= 4) launch_accum_k<LT, 4>(ctx->stream, kind, g, A);
+    else if (P <= 8) launch_accum_k<LT, 8>(ctx->stream, kind, g, A);
+    else return vlgp_fail(ctx, VLGP_ERR_ARG, "M-step kernel supports xdim <= 8, got %d", P);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+static int launch_accum(vlgp_ctx* ctx, int kind, const Geometry& g, const MArgs& A) {
+    const int L = A.L;
+    if (L <= 2) return launch_accum_p<2>(ctx, kind, g, A);
+    if (L <= 3) return launch_accum_p<3>(ctx, kind, g, A);
+    if (L <= 5) return launch_accum_p<5>(ctx, kind, g, A);
+    if (L <= 8) return launch_accum_p<8>(ctx, kind, g, A);
+    if (L <= 10) return launch_accum_p<10>(ctx, kind, g, A);
+    if (L <= 16) return launch_accum_p<16>(ctx, kind, g, A);
+    return vlgp_fail(ctx, VLGP_ERR_ARG, "M-step kernel supports at most 16 latents, got %d", L);
+}
+
+template <int LT>
+static void launch_lat_t(hipStream_t st, int G, int L, int64_t rows, const double* mu, const double* v,
+                         const double* dmu, double* partial) {
+    hipLaunchKernelGGL((latent_moments_kernel<LT>), dim3(G), dim3(256), 0, st, L, rows, mu, v, dmu, partial);
+}
+
+// d_out: tri(L) gram | L sum_mu | L sum_v | L sum_mu^2 | 1 |dmu|^2 ; all-reduced over ranks
+static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double* d_out) {
+    const int L = ctx->L;
+    int G = (int)((us.rows + 255) / 256);
+    if (G > 256) G = 256;
+    if (G < 1) G = 1;
+    const int K = tri(L) + 3 * L + 1;
+    if (L <= 2) launch_lat_t<2>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 3) launch_lat_t<3>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 5) launch_lat_t<5>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 8) launch_lat_t<8>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 10) launch_lat_t<10>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 16) launch_lat_t<16>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 latents supported, got %d", L);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, d_partial, G,
+                       (int64_t)K, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return vlgp_allreduce(ctx, d_out, K);
+}
+
+int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out) {
+    const int L = ctx->L;
+    const int K = tri(L) + 3 * L + 1;
+    CHK(vlgp_ensure_work(ctx, 256LL * K + K + 64));
+    // caller's d_out may live inside d_work: use the tail of the workspace for partials
+    double* d_partial = ctx->d_work + K + 64;
+    CHK(latent_moments(ctx, us, d_partial, ctx->d_work));
+    if (d_out != ctx->d_work)
+        HIPCHK(ctx, hipMemcpyAsync(d_out, ctx->d_work, sizeof(double) * K, hipMemcpyDeviceToDevice, ctx->stream));
+    return VLGP_OK;
+}
+
+int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double eps, double lr,
+                 double da_bound, double db_bound) {
+    const int N = ctx->N, L = ctx->L, P = ctx->P;
+    if (L > SOLVE_MAXD || P > 8)
+        return vlgp_fail(ctx, VLGP_ERR_ARG, "M-step supports L <= 16 and xdim <= 8");
+    const Geometry g = plan(ctx, us.rows);
+    const int Kp = nstat_rt(L, P, K_PREP), Kn = nstat_rt(L, P, K_NEWTON);
+    const int Kl = tri(L) + 3 * L + 1;
+    const int Kmax = Kp > Kn ? Kp : Kn;
+    // workspace: prep | stats | lat | noise1 | mean | partial
+    const int64_t o_prep = 0, o_stats = o_prep + (int64_t)Kp * N, o_lat = o_stats + (int64_t)Kn * N;
+    const int64_t o_s1 = o_lat + Kl + 8, o_mean = o_s1 + N, o_part = o_mean + N;
+    int64_t part_len = (int64_t)g.G * Kmax * N;
+    if (part_len < 256LL * Kl) part_len = 256LL * Kl;
+    CHK(vlgp_ensure_work(ctx, o_part + part_len));
+    double* W = ctx->d_work;
+    double *d_prep = W + o_prep, *d_stats = W + o_stats, *d_lat = W + o_lat, *d_s1 = W + o_s1,
+           *d_mean = W + o_mean, *d_part = W + o_part;
+
+    MArgs A;
+    A.N = N; A.L = L; A.P = P; A.rows = us.rows; A.rows_per_wg = g.rows_per_wg; A.CT = g.CT; A.S = g.S;
+    A.y = us.y; A.x = us.x_ones ? nullptr : us.x; A.mu = us.mu; A.v = us.v;
+    A.a = ctx->d_a; A.b = ctx->d_b; A.gauss = ctx->d_gauss; A.mean = d_mean; A.partial = d_part;
+
+    auto reduce_to = [&](int K, double* dst) -> int {
+        const int64_t n = (int64_t)K * N;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_part, g.G, n, dst);
+        HIPCHK(ctx, hipGetLastError());
+        return vlgp_allreduce(ctx, dst, n);
+    };
+
+    // sweep-invariant moments
+    CHK(launch_accum(ctx, K_PREP, g, A));
+    CHK(reduce_to(Kp, d_prep));
+    CHK(latent_moments(ctx, us, d_part, d_lat));
+    double total_rows = (double)us.rows;
+    if (ctx->world > 1) {
+        // total row count over ranks rides along in the workspace
+        double h = total_rows;
+        HIPCHK(ctx, hipMemcpyAsync(d_lat + Kl, &h, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        CHK(vlgp_allreduce(ctx, d_lat + Kl, 1));
+        HIPCHK(ctx, hipMemcpyAsync(&h, d_lat + Kl, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        total_rows = h;
+    }
+
+    SolveArgs S;
+    S.N = N; S.L = L; S.P = P; S.use_hessian = use_hessian; S.eps = eps; S.lr = lr;
+    S.da_bound = da_bound; S.db_bound = db_bound;
+    S.prep = d_prep; S.stats = d_stats; S.lat = d_lat; S.gauss = ctx->d_gauss;
+    S.a = ctx->d_a; S.b = ctx->d_b; S.da = ctx->d_da; S.db = ctx->d_db; S.fail = ctx->d_fail;
+
+    const bool any_poisson = ctx->n_gauss < N;
+    for (int it = 0; it < n_iter; ++it) {
+        if (it == n_iter - 1) {
+            // noise = var(y - eta) with the parameters entering the last iteration (core.py:177)
+            CHK(launch_accum(ctx, K_NOISE1, g, A));
+            CHK(reduce_to(1, d_s1));
+            hipLaunchKernelGGL(noise_mean_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N,
+                               total_rows, d_s1, d_mean);
+            CHK(launch_accum(ctx, K_NOISE2, g, A));
+            CHK(reduce_to(1, d_s1));
+            hipLaunchKernelGGL(noise_final_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N,
+                               total_rows, d_s1, ctx->d_noise);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        if (any_poisson) {
+            vlgp_prof_begin(ctx, VLGP_PROF_MSTEP);
+            int rc = launch_accum(ctx, K_NEWTON, g, A);
+            vlgp_prof_end(ctx, VLGP_PROF_MSTEP);
+            CHK(rc);
+            CHK(reduce_to(Kn, d_stats));
+        }
+        hipLaunchKernelGGL(mstep_solve_kernel, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, S);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return VLGP_OK;
+}

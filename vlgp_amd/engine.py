@@ -1,0 +1,575 @@
+"""Host side of the MI355X vEM engine.
+
+Two layers:
+
+* :class:`Engine` -- one opaque handle of ``libvlgp_hip.so`` per GPU; NumPy in,
+  NumPy out, every heavy operation is a HIP kernel behind the C ABI.
+* the reference's inner seam, with the reference's names, argument meaning
+  and in-place mutation semantics (vlgp/core.py, vlgp/gp.py)::
+
+      estep | mstep | hstep | update_w | update_v | make_cholesky | infer
+      | constrain_loading | constrain_latent | vem   (trials, params, config) -> None
+
+  Called on plain lists of trial dicts they upload, run and download (that is
+  what the stage-wise parity tests do); called on a :class:`DeviceTrials` --
+  what :func:`vlgp_amd.fit` builds -- the data stays resident on the GPU and
+  nothing crosses PCIe between stages.
+"""
+import ctypes as C
+import logging
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import VlgpError, check, dptr, i64ptr, iptr, u8ptr
+
+logger = logging.getLogger(__name__)
+
+__all__ = ["Engine", "DeviceTrials", "estep", "mstep", "hstep", "update_w", "update_v",
+           "make_cholesky", "infer", "vem", "constrain_loading", "constrain_latent", "VlgpError"]
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine:
+    """One GPU, one handle (include/vlgp_hip.h)."""
+
+    def __init__(self, n_channels, n_latents, xdim, rank, gauss_mask=None, device=0):
+        self.lib = _lib.load()
+        self.N, self.L, self.P, self.R = int(n_channels), int(n_latents), int(xdim), int(rank)
+        mask = np.zeros(self.N, dtype=np.uint8) if gauss_mask is None else \
+            np.ascontiguousarray(np.asarray(gauss_mask, dtype=bool).astype(np.uint8))
+        if mask.shape != (self.N,):
+            raise ValueError("gauss_mask must have one entry per channel")
+        self.gauss = mask.astype(bool)
+        h = C.c_void_p()
+        rc = self.lib.vlgp_create(int(device), self.N, self.L, self.P, self.R, u8ptr(mask), C.byref(h))
+        if rc != 0:
+            check(rc, None)
+        self.h = h
+        self.sets = {}  # set id -> (M, rows, offsets)
+        self.rank, self.world = 0, 1
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vlgp_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        check(rc, self.h)
+
+    def synchronize(self):
+        self._ck(self.lib.vlgp_synchronize(self.h))
+
+    # -- unit sets --------------------------------------------------------
+    def upload(self, set_id, trials):
+        """Pack a list of trial dicts (keys y, x, mu, v, w) into set ``set_id``."""
+        lengths = np.array([tr["y"].shape[0] for tr in trials], dtype=np.int64)
+        off = np.zeros(len(trials) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=off[1:])
+        y = _f64(np.concatenate([tr["y"] for tr in trials], axis=0))
+        if y.shape[1] != self.N:
+            raise ValueError("trial y has %d channels, engine was built for %d" % (y.shape[1], self.N))
+        x = None
+        if any(tr.get("x") is not None for tr in trials):
+            xs = [tr["x"] if tr.get("x") is not None else np.ones((tr["y"].shape[0], self.P, self.N))
+                  for tr in trials]
+            x = _f64(np.concatenate(xs, axis=0))
+            if x.shape[1:] != (self.P, self.N):
+                raise ValueError("trial x must be (T, %d, %d)" % (self.P, self.N))
+            if self.P == 1 and np.all(x == 1.0):
+                x = None  # the default regressors of preprocess.initialize: x == 1
+        elif self.P != 1:
+            raise ValueError("trials without x need xdim == 1")
+
+        def cat(key):
+            if any(tr.get(key) is None for tr in trials):
+                return None
+            arr = _f64(np.concatenate([tr[key] for tr in trials], axis=0))
+            if arr.shape != (y.shape[0], self.L):
+                raise ValueError("trial %s must be (T, %d)" % (key, self.L))
+            return arr
+
+        mu, v, w = cat("mu"), cat("v"), cat("w")
+        self._ck(self.lib.vlgp_upload_units(self.h, set_id, len(trials), i64ptr(off), dptr(y), dptr(x),
+                                            dptr(mu), dptr(v), dptr(w)))
+        self.sets[set_id] = (len(trials), int(off[-1]), off)
+
+    def cut(self, src, dst, starts, window):
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        self._ck(self.lib.vlgp_cut_units(self.h, src, dst, len(starts), i64ptr(starts), int(window)))
+        off = np.arange(len(starts) + 1, dtype=np.int64) * int(window)
+        self.sets[dst] = (len(starts), int(off[-1]), off)
+
+    def merge(self, cut_set):
+        self._ck(self.lib.vlgp_merge_units(self.h, cut_set))
+
+    def download(self, set_id, keys=("mu", "v", "w", "dmu")):
+        """dict key -> (rows, L) array for the requested keys."""
+        _, rows, _ = self.sets[set_id]
+        out = {k: np.empty((rows, self.L)) for k in keys}
+        self._ck(self.lib.vlgp_download_units(self.h, set_id, dptr(out.get("mu")), dptr(out.get("v")),
+                                              dptr(out.get("w")), dptr(out.get("dmu"))))
+        return out
+
+    def free_units(self, set_id):
+        self._ck(self.lib.vlgp_free_units(self.h, set_id))
+        self.sets.pop(set_id, None)
+
+    # -- parameters -------------------------------------------------------
+    def set_params(self, a, b, noise):
+        a, b, noise = _f64(a), _f64(b), _f64(noise)
+        if a.shape != (self.L, self.N) or b.shape != (self.P, self.N) or noise.shape != (self.N,):
+            raise ValueError("parameter shapes must be a (L,N), b (P,N), noise (N)")
+        self._ck(self.lib.vlgp_set_params(self.h, dptr(a), dptr(b), dptr(noise)))
+
+    def get_params(self):
+        a, da = np.empty((self.L, self.N)), np.empty((self.L, self.N))
+        b, db = np.empty((self.P, self.N)), np.empty((self.P, self.N))
+        noise = np.empty(self.N)
+        self._ck(self.lib.vlgp_get_params(self.h, dptr(a), dptr(b), dptr(noise), dptr(da), dptr(db)))
+        return a, b, noise, da, db
+
+    # -- prior ------------------------------------------------------------
+    def build_prior(self, lengths, omega, sigma):
+        lengths = np.ascontiguousarray(np.unique(np.asarray(lengths)), dtype=np.int32)
+        omega, sigma = _f64(omega), _f64(sigma)
+        self._ck(self.lib.vlgp_build_prior(self.h, len(lengths), iptr(lengths), dptr(omega), dptr(sigma)))
+
+    def set_prior(self, T, G):
+        G = _f64(G)
+        if G.shape != (self.L, int(T), self.R):
+            raise ValueError("prior factor for length %d must be (%d, %d, %d), got %r"
+                             % (T, self.L, T, self.R, G.shape))
+        self._ck(self.lib.vlgp_set_prior(self.h, int(T), dptr(G)))
+
+    def clear_prior(self):
+        self._ck(self.lib.vlgp_clear_prior(self.h))
+
+    def get_prior(self, T, with_rank=False):
+        G = np.empty((self.L, int(T), self.R))
+        rk = np.zeros(self.L, dtype=np.int32)
+        self._ck(self.lib.vlgp_get_prior(self.h, int(T), dptr(G), iptr(rk)))
+        return (G, rk) if with_rank else G
+
+    # -- E / M / H --------------------------------------------------------
+    def update_w(self, set_id):
+        self._ck(self.lib.vlgp_update_w(self.h, set_id))
+
+    def update_v(self, set_id, vb=True, count=True):
+        n = C.c_int(0)
+        self._ck(self.lib.vlgp_update_v(self.h, set_id, int(bool(vb)), C.byref(n) if count else None))
+        return n.value
+
+    def estep(self, set_id, n_iter, dmu_bound=5.0, vb=True, count=True):
+        n = C.c_int(0)
+        self._ck(self.lib.vlgp_estep(self.h, set_id, int(n_iter), float(dmu_bound), int(bool(vb)),
+                                     C.byref(n) if count else None))
+        return n.value
+
+    def mstep(self, set_id, n_iter, use_hessian=True, eps=1e-8, learning_rate=1.0, da_bound=5.0,
+              db_bound=5.0, count=True):
+        n = C.c_int(0)
+        self._ck(self.lib.vlgp_mstep(self.h, set_id, int(n_iter), int(bool(use_hessian)), float(eps),
+                                     float(learning_rate), float(da_bound), float(db_bound),
+                                     C.byref(n) if count else None))
+        return n.value
+
+    def hstep_objective(self, set_id, window, dt, latents, logp):
+        """Batched (ll, dll) for evaluations (latents[e], logp[e, :3])."""
+        latents = np.ascontiguousarray(latents, dtype=np.int32)
+        logp = _f64(logp).reshape(len(latents), 3)
+        ll = np.empty(len(latents))
+        dll = np.empty((len(latents), 3))
+        self._ck(self.lib.vlgp_hstep_objective(self.h, set_id, int(window), float(dt), len(latents),
+                                               iptr(latents), dptr(logp), dptr(ll), dptr(dll)))
+        return ll, dll
+
+    # -- constraints / norms ----------------------------------------------
+    def apply_latent_map(self, set_id, mat, shift=None):
+        mat = _f64(mat)
+        if mat.shape != (self.L, self.L):
+            raise ValueError("latent map must be (L, L)")
+        self._ck(self.lib.vlgp_apply_latent_map(self.h, set_id, dptr(mat),
+                                                dptr(_f64(shift)) if shift is not None else None))
+
+    def norms(self, set_id):
+        out = np.empty(2)
+        self._ck(self.lib.vlgp_norms(self.h, set_id, dptr(out)))
+        return float(np.sqrt(out[0])), float(np.sqrt(out[1]))
+
+    def latent_moments(self, set_id):
+        s1, s2 = np.empty(self.L), np.empty(self.L)
+        cnt = C.c_double(0)
+        self._ck(self.lib.vlgp_latent_moments(self.h, set_id, dptr(s1), dptr(s2), C.byref(cnt)))
+        return s1, s2, cnt.value
+
+    # -- multi-GPU --------------------------------------------------------
+    def comm_init(self, uid, rank, world):
+        self._ck(self.lib.vlgp_comm_init(self.h, uid, int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    # -- measurement ------------------------------------------------------
+    def profile(self, on=True):
+        self._ck(self.lib.vlgp_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        self._ck(self.lib.vlgp_profile_reset(self.h))
+
+    def profile_get(self, kind):
+        n, ms = C.c_int64(0), C.c_double(0)
+        self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+def unique_id():
+    """RCCL unique id (rank 0 creates it, every rank passes it to Engine.comm_init)."""
+    buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    check(_lib.load().vlgp_comm_unique_id(buf), None)
+    return buf.raw
+
+
+# ===========================================================================
+# the reference's (trials, params, config) seam
+# ===========================================================================
+class DeviceTrials(list):
+    """A list of trial dicts whose arrays are resident on an :class:`Engine`.
+
+    Behaves as the plain list the reference passes around; the host copies of
+    mu/v/w/dmu are refreshed only by :meth:`pull` (callbacks, end of fit).
+    """
+
+    def __init__(self, trials, engine, set_id):
+        super().__init__(trials)
+        self.engine = engine
+        self.set_id = set_id
+
+    def pull(self, keys=("mu", "v", "w", "dmu")):
+        """Copy device state into the dicts: mu, v, dmu in place, w rebound
+        (exactly the ownership the reference leaves behind, core.py:117-120)."""
+        got = self.engine.download(self.set_id, keys)
+        _, _, off = self.engine.sets[self.set_id]
+        for i, tr in enumerate(self):
+            sl = slice(int(off[i]), int(off[i + 1]))
+            for k in keys:
+                if k == "w" or tr.get(k) is None or tr[k].shape != got[k][sl].shape:
+                    tr[k] = got[k][sl].copy()
+                else:
+                    tr[k][...] = got[k][sl]
+
+
+def _gauss_mask(params):
+    return np.asarray(params["likelihood"]) == "gaussian"
+
+
+def _push_params(eng, params):
+    eng.set_params(params["a"], params["b"], params["noise"])
+
+
+def _pull_params(eng, params):
+    a, b, noise, da, db = eng.get_params()
+    params["a"][...] = a          # in place, like core.py:202,220
+    params["b"][...] = b
+    params["noise"] = noise       # rebound, like core.py:244
+    if params.get("da") is None or params["da"].shape != da.shape:
+        params["da"], params["db"] = da, db
+    else:
+        params["da"][...] = da
+        params["db"][...] = db
+
+
+class _Bound:
+    """Context that yields (engine, set_id) for a trials argument.
+
+    DeviceTrials: the resident engine, parameters pushed.  Plain list: a
+    temporary engine -- upload on enter, download into the dicts on exit.
+    """
+
+    def __init__(self, trials, params, need_prior=True, pull=("mu", "v", "w", "dmu")):
+        self.trials, self.params, self.need_prior, self.keys = trials, params, need_prior, pull
+        self.temp = None
+
+    def __enter__(self):
+        tr, p = self.trials, self.params
+        if isinstance(tr, DeviceTrials):
+            return tr.engine, tr.set_id
+        tr = list(tr)
+        eng = Engine(p["ydim"], p["zdim"], p["xdim"], p["rank"], _gauss_mask(p))
+        self.temp = eng
+        try:
+            _push_params(eng, p)
+            eng.upload(0, tr)
+            if self.need_prior:
+                chol = p.get("cholesky") or {}
+                for T in sorted({t["y"].shape[0] for t in tr}):
+                    if T not in chol:
+                        raise KeyError("params['cholesky'] has no factor for length %d "
+                                       "(call make_cholesky first)" % T)
+                    eng.set_prior(T, chol[T])
+        except Exception:
+            eng.close()
+            raise
+        self.view = DeviceTrials(tr, eng, 0)
+        return eng, 0
+
+    def __exit__(self, et, ev, tb):
+        if self.temp is not None:
+            try:
+                if et is None and self.keys:
+                    self.view.pull(self.keys)
+            finally:
+                self.temp.close()
+        return False
+
+
+def make_cholesky(trials, params, config=None):
+    """gp.make_cholesky (vlgp/gp.py:150-162) with math.ichol_gauss on the GPU.
+
+    ``config["ichol"] == "host"`` selects the host NumPy factorisation instead
+    (bit-identical pivots to the reference for bit-identical omega; see
+    DESIGN.md, "pivot chaos")."""
+    from . import gp as _gp
+
+    lengths = sorted({int(tr["y"].shape[0]) for tr in trials})
+    mode = (config or {}).get("ichol", "device")
+    if mode == "host":
+        chol = {T: np.stack([_gp.ichol_gauss_host(T, params["omega"][l], params["rank"]) * params["sigma"][l]
+                             for l in range(params["zdim"])]) for T in lengths}
+        params["cholesky"] = chol
+        if isinstance(trials, DeviceTrials):
+            trials.engine.clear_prior()
+            for T, G in chol.items():
+                trials.engine.set_prior(T, G)
+        return
+    if isinstance(trials, DeviceTrials):
+        trials.engine.build_prior(lengths, params["omega"], params["sigma"])
+        params["cholesky"] = _LazyPrior(trials.engine, lengths)
+        return
+    with Engine(params["ydim"], params["zdim"], params["xdim"], params["rank"], _gauss_mask(params)) as eng:
+        eng.build_prior(lengths, params["omega"], params["sigma"])
+        params["cholesky"] = {T: eng.get_prior(T) for T in lengths}
+
+
+class _LazyPrior(dict):
+    """params["cholesky"] while the factors live on the device: downloads G on
+    first access of a length (keeps the EM loop free of PCIe traffic)."""
+
+    def __init__(self, engine, lengths):
+        super().__init__()
+        self._engine, self._lengths = engine, set(int(t) for t in lengths)
+
+    def __missing__(self, T):
+        if int(T) not in self._lengths:
+            raise KeyError(T)
+        G = self._engine.get_prior(int(T))
+        self[int(T)] = G
+        return G
+
+    def __contains__(self, T):
+        return int(T) in self._lengths
+
+    def materialize(self):
+        return {T: np.array(self[T]) for T in sorted(self._lengths)}
+
+
+def update_w(trials, params, config=None):
+    """core.update_w (vlgp/core.py:419-442)."""
+    for tr in trials:  # the reference creates missing w/v (core.py:433-434)
+        if not isinstance(trials, DeviceTrials):
+            tr.setdefault("w", np.zeros_like(tr["mu"]))
+            tr.setdefault("v", np.zeros_like(tr["mu"]))
+    with _Bound(trials, params, need_prior=False, pull=("w",)) as (eng, sid):
+        eng.update_w(sid)
+
+
+def update_v(trials, params, config):
+    """core.update_v (vlgp/core.py:445-471)."""
+    if config["method"] != "VB":
+        return
+    with _Bound(trials, params, pull=("v",)) as (eng, sid):
+        bad = eng.update_v(sid, True, count=not isinstance(trials, DeviceTrials))
+        if bad:
+            logger.error("Singular I + G'WG in %d unit-latent pairs", bad)
+
+
+def estep(trials, params, config):
+    """core.estep (vlgp/core.py:123-126): config["Eniter"] inner iterations per unit."""
+    if config["Eniter"] < 1:
+        return
+    with _Bound(trials, params) as (eng, sid):
+        bad = eng.estep(sid, config["Eniter"], config["dmu_bound"], config["method"] == "VB",
+                        count=not isinstance(trials, DeviceTrials))
+        if bad:
+            logger.error("%d posterior updates hit a singular system and were zeroed", bad)
+
+
+def mstep(trials, params, config):
+    """core.mstep (vlgp/core.py:129-249)."""
+    if config["Mniter"] < 1:
+        return
+    if params.get("da") is None:
+        params["da"] = np.zeros_like(params["a"])
+        params["db"] = np.zeros_like(params["b"])
+    with _Bound(trials, params, need_prior=False, pull=()) as (eng, sid):
+        bad = eng.mstep(sid, config["Mniter"], config["use_hessian"], config["eps"],
+                        config["learning_rate"], config["da_bound"], config["db_bound"],
+                        count=not isinstance(trials, DeviceTrials))
+        if bad:
+            logger.error("%d Newton systems were singular (gradient step taken)", bad)
+        _pull_params(eng, params)
+
+
+def hstep(trials, params, config):
+    """core.hstep (vlgp/core.py:252-257)."""
+    if not config["Hstep"]:
+        return
+    from . import gp as _gp
+
+    _gp.optimize(trials, params, config)
+
+
+def infer(trials, params, config, echo=None):
+    """core.infer (vlgp/core.py:260-266): E-step with Eniter := max_iter."""
+    keep = config["Eniter"]
+    config["Eniter"] = config["max_iter"]
+    t0 = time.perf_counter()
+    try:
+        estep(trials, params, config)
+        if isinstance(trials, DeviceTrials):
+            trials.engine.synchronize()
+    finally:
+        config["Eniter"] = keep
+    if echo:
+        echo("{:.2f}s".format(time.perf_counter() - t0))
+
+
+def constrain_loading(trials, params, config):
+    """core.constrain_loading (vlgp/core.py:392-416)."""
+    kind = config["constrain_loading"]
+    if not kind or kind == "none":
+        return
+    a = params["a"]
+    L = a.shape[0]
+    if kind == "svd":
+        _, _, vt = np.linalg.svd(a, full_matrices=False)
+        mat = a @ vt.T
+        params["a"] = vt
+    else:
+        if kind == "fro":
+            s = np.full(L, np.linalg.norm(a, ord="fro") + config["eps"])
+        else:
+            s = np.linalg.norm(a, ord=kind, axis=1) + config["eps"]
+        params["a"] /= s[:, None]
+        mat = np.diag(s)
+    if isinstance(trials, DeviceTrials):
+        trials.engine.apply_latent_map(trials.set_id, mat)
+        _push_params(trials.engine, params)
+    else:
+        for tr in trials:
+            tr["mu"] = tr["mu"] @ mat if kind == "svd" else _imul_cols(tr["mu"], np.diag(mat))
+
+
+def _imul_cols(mu, s):
+    mu *= s
+    return mu
+
+
+def constrain_latent(trials, params, config):
+    """core.constrain_latent (vlgp/core.py:366-389); off by default."""
+    kind = config["constrain_latent"]
+    if not kind or kind == "none":
+        return
+    L = params["zdim"]
+    if isinstance(trials, DeviceTrials):
+        s1, s2, cnt = trials.engine.latent_moments(trials.set_id)
+        mean = s1 / cnt
+        std = np.sqrt(np.maximum(s2 / cnt - mean ** 2, 0.0))
+    else:
+        mu = np.concatenate([tr["mu"] for tr in trials], axis=0)
+        mean, std = mu.mean(axis=0), mu.std(axis=0)
+    shift = np.zeros(L)
+    scale = np.ones(L)
+    if kind in ("location", "both"):
+        shift = mean
+        params["b"][0, :] += mean @ params["a"]
+    if kind in ("scale", "both"):
+        scale = 1.0 / std
+        params["a"] *= std[:, None]
+    if isinstance(trials, DeviceTrials):
+        trials.engine.apply_latent_map(trials.set_id, np.diag(scale), shift)
+        _push_params(trials.engine, params)
+    else:
+        for tr in trials:
+            tr["mu"] -= shift
+            tr["mu"] *= scale
+
+
+def vem(trials, params, config, echo=None):
+    """core.vem (vlgp/core.py:269-359): the EM loop, timers and stopping rule.
+
+    Timers are wall-clock around device-synchronised phases, so
+    ``config["runtime"]`` means what it means in the reference.
+    """
+    if not isinstance(trials, DeviceTrials):
+        raise TypeError("vem runs on DeviceTrials (use vlgp_amd.fit, or Engine + DeviceTrials)")
+    eng, sid = trials.engine, trials.set_id
+    runtime = {"it": 0, "e_elapsed": [], "m_elapsed": [], "h_elapsed": [], "em_elapsed": []}
+    tol = config["tol"]
+    _push_params(eng, params)
+    for it in range(config["max_iter"]):
+        runtime["it"] += 1
+        norm_mu, _ = eng.norms(sid)
+        norm_a = np.linalg.norm(params["a"])
+        norm_b = np.linalg.norm(params["b"])
+
+        t0 = time.perf_counter()
+        constrain_loading(trials, params, config)
+        estep(trials, params, config)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        constrain_latent(trials, params, config)
+        mstep(trials, params, config)
+        t2 = time.perf_counter()
+        hstep(trials, params, config)
+        eng.synchronize()
+        t3 = time.perf_counter()
+
+        runtime["e_elapsed"].append(t1 - t0)
+        runtime["m_elapsed"].append(t2 - t1)
+        runtime["h_elapsed"].append(t3 - t2)
+        runtime["em_elapsed"].append(t3 - t0)
+        config["runtime"] = runtime
+        if echo:
+            echo("Iteration {:4d}, E-step {:.2f}s, M-step {:.2f}s".format(
+                runtime["it"], runtime["e_elapsed"][-1], runtime["m_elapsed"][-1]))
+
+        if config["callbacks"]:
+            trials.pull()
+            for cb in config["callbacks"]:
+                try:
+                    cb(trials, params, config)
+                except RuntimeError:
+                    logger.error("Callback {} failed".format(cb))
+
+        _, norm_dmu = eng.norms(sid)
+        converged = (norm_dmu < tol * norm_mu
+                     and np.linalg.norm(params["da"]) < tol * norm_a
+                     and np.linalg.norm(params["db"]) < tol * norm_b)
+        if converged and it + 1 >= config["min_iter"]:
+            break

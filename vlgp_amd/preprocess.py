@@ -1,0 +1,85 @@
+"""Configuration, parameter skeleton and initialisation (vlgp/preprocess.py).
+
+Host-side and tiny; runs once per fit.  Semantics follow the reference:
+unknown keyword arguments are dropped silently, rank is fixed at 50, and the
+initial loading / latent come from a FactorAnalysis fit on a random 10 %
+subsample drawn from the global NumPy RNG.
+"""
+import numpy as np
+
+_DEFAULTS = (
+    ("constrain_loading", "fro"), ("constrain_latent", False), ("use_hessian", True),
+    ("eps", 1e-8), ("tol", 1e-8), ("min_iter", 5), ("method", "VB"), ("learning_rate", 1.0),
+    ("max_iter", 20), ("Eniter", 25), ("Mniter", 25), ("Hstep", True), ("da_bound", 5.0),
+    ("db_bound", 5.0), ("dmu_bound", 5.0), ("omega_bound", (5e-4, 5e-2)), ("window", 50),
+    ("saving_interval", 60 * 30), ("callbacks", None), ("parallel", False),
+    # build-specific: "device" (HIP ichol kernel) or "host" (NumPy, reference pivots)
+    ("ichol", "device"),
+)
+
+
+def get_config(**kwargs):
+    """vlgp/preprocess.py:84-112."""
+    config = {k: ([] if k == "callbacks" else v) for k, v in _DEFAULTS}
+    config.update({k: v for k, v in kwargs.items() if k in config})
+    return config
+
+
+def get_params(trials, zdim, **kwargs):
+    """vlgp/preprocess.py:49-81."""
+    ydim = trials[0]["y"].shape[-1]
+    lik = kwargs.get("lik", "poisson")
+    if not isinstance(lik, list):
+        lik = [lik] * ydim
+    return {
+        "ydim": ydim, "zdim": zdim, "xdim": max(kwargs.get("history", 0), 1),
+        "a": kwargs.get("a", None), "b": kwargs.get("b", None),
+        "noise": kwargs.get("noise", np.full(ydim, fill_value=1.0)),
+        "sigma": kwargs.get("sigma", np.full(zdim, fill_value=1.0)),
+        "omega": kwargs.get("omega", np.full(zdim, fill_value=kwargs["omega_bound"][1])),
+        "rank": 50, "gp_noise": 1e-4, "dt": 1, "likelihood": np.asarray(lik),
+    }
+
+
+def initialize(trials, params, config):
+    """vlgp/preprocess.py:4-46."""
+    zdim, xdim = params["zdim"], params["xdim"]
+    y = np.concatenate([tr["y"] for tr in trials], axis=0)
+    pick = np.random.choice(y.shape[0], max(y.shape[0] // 10, 50))
+    ydim = y.shape[-1]
+    if params.get("transform") is None:
+        from sklearn.decomposition import FactorAnalysis
+
+        fa = FactorAnalysis(n_components=zdim, random_state=0)
+        z = fa.fit_transform(y[pick, :])
+        a = fa.components_
+        params["transform"] = fa.transform
+        if params.get("a") is None:
+            params["a"] = a
+        if params.get("b") is None:
+            params["b"] = np.log(np.maximum(np.mean(y, axis=0, keepdims=True), config["eps"]))
+        if params.get("noise") is None:
+            params["noise"] = np.var(y[pick, :] - z @ a, ddof=0, axis=0)
+    to_latent = params["transform"]
+    for tr in trials:
+        T = tr["y"].shape[0]
+        if tr.get("mu") is None:
+            tr["mu"] = to_latent(tr["y"])
+        if tr.get("x") is None:
+            tr["x"] = np.ones((T, xdim, ydim))
+        tr["w"] = np.zeros((T, zdim))
+        tr["v"] = np.zeros((T, zdim))
+
+
+def fill_trials(trials):
+    """vlgp/preprocess.py:115-120."""
+    for i, tr in enumerate(trials):
+        tr["cut"] = i
+        for key in ("w", "v", "dmu"):
+            tr.setdefault(key, np.zeros_like(tr["mu"]))
+
+
+def fill_params(params):
+    """vlgp/preprocess.py:123-125."""
+    params.setdefault("da", np.zeros_like(params["a"]))
+    params.setdefault("db", np.zeros_like(params["b"]))
