@@ -152,6 +152,10 @@ int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double* sum2, doub
 /* Rank 0 makes the id, every rank passes the same id to vlgp_comm_init. */
 int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]);
 int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES], int rank, int world);
+/* In-place sum over ranks of n host doubles (staged through the device, on the
+ * handle's stream, synchronous).  With no communicator attached it is a no-op.
+ * n == 0 is a pure barrier. */
+int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n);
 
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event timing of the kernels an entry point launches, on the handle's

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "vlgp_latent_moments": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "vlgp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "vlgp_comm_init": (C.c_int, [_h, C.c_char_p, C.c_int, C.c_int]),
+    "vlgp_comm_allreduce_host": (C.c_int, [_h, _dp, C.c_int]),
     "vlgp_profile_enable": (C.c_int, [_h, C.c_int]),
     "vlgp_profile_reset": (C.c_int, [_h]),
     "vlgp_profile_get": (C.c_int, [_h, C.c_int, _i64p, _dp]),

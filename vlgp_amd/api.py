@@ -14,7 +14,7 @@ from . import engine as E
 from .preprocess import fill_params, fill_trials, get_config, get_params, initialize
 from .util import segment_starts
 
-__all__ = ["fit", "transform"]
+__all__ = ["fit", "transform", "FitSession"]
 
 logger = logging.getLogger(__name__)
 
@@ -40,76 +40,124 @@ def _segments(trials, window, eng):
     return E.DeviceTrials(segs, eng, SET_SEGMENTS)
 
 
+class FitSession:
+    """The three phases of api.fit as separate calls.
+
+    ``FitSession(...)``  api.py:27-60 -- config, params, initialisation, upload,
+                         prior factor, w, v, segmentation
+    ``run()``            api.py:64 -- core.vem on the segments
+    ``finish()``         api.py:66-76 -- full-length prior, w, v, inference, download
+
+    ``bench.py`` drives ``em_iteration`` directly to time single EM iterations;
+    ``fit`` is ``FitSession(...).run().finish()``.
+    """
+
+    def __init__(self, trials, n_factors, device=0, comm=None, verbose=True, **kwargs):
+        self.echo = _echo if verbose else None
+        echo = self.echo
+        self.trials = trials
+        self.config = config = get_config(**kwargs)
+        logger.info("\n".join("{} : {}".format(k, v) for k, v in config.items()))
+        kwargs["omega_bound"] = config["omega_bound"]
+        self.params = params = get_params(trials, n_factors, **kwargs)
+        self.comm = comm
+        self.eng = None
+        self.runtime = E.new_runtime()
+
+        if echo:
+            echo("Initializing")
+        initialize(trials, params, config)
+        if echo:
+            echo("Initialized")
+        fill_params(params)
+        fill_trials(trials)
+        for key in ("a", "b", "noise", "omega", "sigma"):
+            params[key] = np.array(params[key], dtype=float)
+
+        eng = E.Engine(params["ydim"], params["zdim"], params["xdim"], params["rank"],
+                       np.asarray(params["likelihood"]) == "gaussian", device=device)
+        self.eng = eng
+        try:
+            if comm is not None and comm.world > 1:
+                comm.attach(eng)
+                self._replicate_params()
+            eng.set_params(params["a"], params["b"], params["noise"])
+            eng.upload(SET_TRIALS, trials)
+            self.dev_trials = E.DeviceTrials(trials, eng, SET_TRIALS)
+            E.make_cholesky(self.dev_trials, params, config)
+            E.update_w(self.dev_trials, params, config)
+            E.update_v(self.dev_trials, params, config)
+            window = config["window"]
+            if window:
+                self.segs = _segments(trials, window, eng)
+                E.make_cholesky(self.segs, params, config)
+                fill_trials(self.segs)
+            else:
+                self.segs = self.dev_trials
+            snapshot = {k: v for k, v in params.items() if k not in ("cholesky", "transform")}
+            params["initial"] = copy.deepcopy(snapshot)
+            E._push_params(eng, params)
+        except Exception:
+            self.close()
+            raise
+
+    def _replicate_params(self):
+        """Every rank must start from the same a, b, noise: keep rank 0's."""
+        p, eng = self.params, self.eng
+        for key in ("a", "b", "noise"):
+            buf = np.ascontiguousarray(p[key], dtype=float)
+            if eng.rank != 0:
+                buf = np.zeros_like(buf)
+            eng.allreduce_host(buf)
+            p[key] = buf
+
+    def em_iteration(self):
+        """One EM iteration on the segments; True when the stopping rule fires."""
+        return E.em_iteration(self.segs, self.params, self.config, self.runtime, self.echo)
+
+    def run(self):
+        if self.echo:
+            self.echo("Fitting")
+        for _ in range(self.config["max_iter"]):
+            if self.em_iteration():
+                break
+        return self
+
+    def finish(self):
+        eng, params, config, echo = self.eng, self.params, self.config, self.echo
+        try:
+            if self.segs is not self.dev_trials:
+                eng.merge(SET_SEGMENTS)
+            E.make_cholesky(self.dev_trials, params, config)
+            E.update_w(self.dev_trials, params, config)
+            E.update_v(self.dev_trials, params, config)
+            if echo:
+                echo("Inferring")
+            E.infer(self.dev_trials, params, config, echo=echo)
+            self.dev_trials.pull()
+            if isinstance(params["cholesky"], E._LazyPrior):
+                params["cholesky"] = params["cholesky"].materialize()
+            if echo:
+                echo("Done")
+        finally:
+            self.close()
+        return {"trials": self.trials, "params": params, "config": config}
+
+    def close(self):
+        if self.eng is not None:
+            self.eng.close()
+            self.eng = None
+
+
 def fit(trials, n_factors, device=0, comm=None, verbose=True, **kwargs):
     """Variational-EM fit of vLGP on one MI355X (or one rank of several).
 
     Same arguments as the reference: ``lik``, ``history``, ``a``, ``b``,
     ``noise``, ``sigma``, ``omega`` and every ``get_config`` key.  Extra:
     ``device`` (GPU index), ``comm`` (a :class:`vlgp_amd.dist.Comm` when the
-    trials are sharded over ranks), ``verbose``.
+    trials are sharded over ranks), ``verbose``, ``ichol`` ("device"/"host").
     """
-    echo = _echo if verbose else None
-    config = get_config(**kwargs)
-    logger.info("\n".join("{} : {}".format(k, v) for k, v in config.items()))
-    kwargs["omega_bound"] = config["omega_bound"]
-    params = get_params(trials, n_factors, **kwargs)
-
-    if echo:
-        echo("Initializing")
-    initialize(trials, params, config)
-    if echo:
-        echo("Initialized")
-    fill_params(params)
-    fill_trials(trials)
-    params["a"] = np.array(params["a"], dtype=float)
-    params["b"] = np.array(params["b"], dtype=float)
-    params["noise"] = np.array(params["noise"], dtype=float)
-    params["omega"] = np.array(params["omega"], dtype=float)
-    params["sigma"] = np.array(params["sigma"], dtype=float)
-
-    eng = E.Engine(params["ydim"], params["zdim"], params["xdim"], params["rank"],
-                   np.asarray(params["likelihood"]) == "gaussian", device=device)
-    try:
-        if comm is not None:
-            comm.attach(eng)
-        eng.set_params(params["a"], params["b"], params["noise"])
-        eng.upload(SET_TRIALS, trials)
-        dev_trials = E.DeviceTrials(trials, eng, SET_TRIALS)
-        E.make_cholesky(dev_trials, params, config)
-        E.update_w(dev_trials, params, config)
-        E.update_v(dev_trials, params, config)
-
-        window = config["window"]
-        if window:
-            segs = _segments(trials, window, eng)
-            E.make_cholesky(segs, params, config)
-            fill_trials(segs)
-        else:
-            segs = dev_trials
-
-        snapshot = {k: v for k, v in params.items() if k not in ("cholesky", "transform")}
-        params["initial"] = copy.deepcopy(snapshot)
-
-        if echo:
-            echo("Fitting")
-        E.vem(segs, params, config, echo=echo)
-
-        if segs is not dev_trials:
-            eng.merge(SET_SEGMENTS)
-        E.make_cholesky(dev_trials, params, config)
-        E.update_w(dev_trials, params, config)
-        E.update_v(dev_trials, params, config)
-        if echo:
-            echo("Inferring")
-        E.infer(dev_trials, params, config, echo=echo)
-        dev_trials.pull()
-        if isinstance(params["cholesky"], E._LazyPrior):
-            params["cholesky"] = params["cholesky"].materialize()
-        if echo:
-            echo("Done")
-    finally:
-        eng.close()
-    return {"trials": trials, "params": params, "config": config}
+    return FitSession(trials, n_factors, device=device, comm=comm, verbose=verbose, **kwargs).run().finish()
 
 
 def transform(trials, params, config, device=0):
@@ -124,17 +172,17 @@ def transform(trials, params, config, device=0):
         eng.set_params(params["a"], params["b"], params["noise"])
         eng.upload(SET_TRIALS, trials)
         dev = E.DeviceTrials(trials, eng, SET_TRIALS)
-        chol = params.get("cholesky") or {}
+        chol = dict(params.get("cholesky") or {})
         lengths = sorted({int(tr["y"].shape[0]) for tr in trials})
         missing = [T for T in lengths if T not in chol]
+        have = [T for T in lengths if T in chol]
         if missing:
             eng.build_prior(missing, params["omega"], params["sigma"])
             for T in missing:
                 chol[T] = eng.get_prior(T)
-        for T in lengths:
-            if T not in missing:
-                eng.set_prior(T, chol[T])
-        params["cholesky"] = dict(chol)
+        for T in have:
+            eng.set_prior(T, chol[T])
+        params["cholesky"] = chol
         E.infer(dev, params, config)
         dev.pull()
     return trials

@@ -166,6 +166,27 @@ extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]
     return VLGP_OK;
 }
 
+extern "C" int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n) {
+    NEED_CTX(ctx);
+    if (n < 0 || (n > 0 && !buf)) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad allreduce arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    if (ctx->world <= 1 || !ctx->comm) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return VLGP_OK;
+    }
+    const int m = n > 0 ? n : 1;
+    CHK(vlgp_ensure_work(ctx, m + 8));
+    CHK(vlgp_ensure_pinned(ctx, m + 8));
+    if (n > 0) memcpy(ctx->h_pinned, buf, sizeof(double) * n);
+    else ctx->h_pinned[0] = 0.0;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_pinned, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+    CHK(vlgp_allreduce(ctx, ctx->d_work, m));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_work, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > 0) memcpy(buf, ctx->h_pinned, sizeof(double) * n);
+    return VLGP_OK;
+}
+
 // ---- lifetime --------------------------------------------------------------
 extern "C" int vlgp_abi_version(void) { return VLGP_ABI_VERSION; }
 

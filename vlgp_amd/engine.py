@@ -225,6 +225,16 @@ class Engine:
         self._ck(self.lib.vlgp_comm_init(self.h, uid, int(rank), int(world)))
         self.rank, self.world = int(rank), int(world)
 
+    def allreduce_host(self, arr):
+        """In-place sum over ranks of a float64 host array (no-op on one GPU)."""
+        assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
+        self._ck(self.lib.vlgp_comm_allreduce_host(self.h, dptr(arr), arr.size))
+        return arr
+
+    def barrier(self):
+        """Drain this handle's stream and rendezvous with the other ranks."""
+        self._ck(self.lib.vlgp_comm_allreduce_host(self.h, None, 0))
+
     # -- measurement ------------------------------------------------------
     def profile(self, on=True):
         self._ck(self.lib.vlgp_profile_enable(self.h, int(bool(on))))
@@ -520,6 +530,56 @@ def constrain_latent(trials, params, config):
             tr["mu"] *= scale
 
 
+def new_runtime():
+    return {"it": 0, "e_elapsed": [], "m_elapsed": [], "h_elapsed": [], "em_elapsed": []}
+
+
+def em_iteration(trials, params, config, runtime, echo=None):
+    """One pass of the body of core.vem (vlgp/core.py:298-357): E, M, H, timers,
+    callbacks, convergence test.  Returns True when the stopping rule fires."""
+    eng, sid = trials.engine, trials.set_id
+    tol = config["tol"]
+    runtime["it"] += 1
+    norm_mu, _ = eng.norms(sid)       # pre-iteration norms (core.py:300-305)
+    norm_a = np.linalg.norm(params["a"])
+    norm_b = np.linalg.norm(params["b"])
+
+    t0 = time.perf_counter()
+    constrain_loading(trials, params, config)
+    estep(trials, params, config)
+    eng.synchronize()
+    t1 = time.perf_counter()
+    constrain_latent(trials, params, config)
+    mstep(trials, params, config)
+    t2 = time.perf_counter()
+    hstep(trials, params, config)
+    eng.synchronize()
+    t3 = time.perf_counter()
+
+    runtime["e_elapsed"].append(t1 - t0)
+    runtime["m_elapsed"].append(t2 - t1)
+    runtime["h_elapsed"].append(t3 - t2)
+    runtime["em_elapsed"].append(t3 - t0)
+    config["runtime"] = runtime
+    if echo:
+        echo("Iteration {:4d}, E-step {:.2f}s, M-step {:.2f}s".format(
+            runtime["it"], runtime["e_elapsed"][-1], runtime["m_elapsed"][-1]))
+
+    if config["callbacks"]:
+        trials.pull()
+        for cb in config["callbacks"]:
+            try:
+                cb(trials, params, config)
+            except RuntimeError:
+                logger.error("Callback {} failed".format(cb))
+
+    _, norm_dmu = eng.norms(sid)
+    converged = (norm_dmu < tol * norm_mu
+                 and np.linalg.norm(params["da"]) < tol * norm_a
+                 and np.linalg.norm(params["db"]) < tol * norm_b)
+    return bool(converged and runtime["it"] >= config["min_iter"])
+
+
 def vem(trials, params, config, echo=None):
     """core.vem (vlgp/core.py:269-359): the EM loop, timers and stopping rule.
 
@@ -528,48 +588,8 @@ def vem(trials, params, config, echo=None):
     """
     if not isinstance(trials, DeviceTrials):
         raise TypeError("vem runs on DeviceTrials (use vlgp_amd.fit, or Engine + DeviceTrials)")
-    eng, sid = trials.engine, trials.set_id
-    runtime = {"it": 0, "e_elapsed": [], "m_elapsed": [], "h_elapsed": [], "em_elapsed": []}
-    tol = config["tol"]
-    _push_params(eng, params)
-    for it in range(config["max_iter"]):
-        runtime["it"] += 1
-        norm_mu, _ = eng.norms(sid)
-        norm_a = np.linalg.norm(params["a"])
-        norm_b = np.linalg.norm(params["b"])
-
-        t0 = time.perf_counter()
-        constrain_loading(trials, params, config)
-        estep(trials, params, config)
-        eng.synchronize()
-        t1 = time.perf_counter()
-        constrain_latent(trials, params, config)
-        mstep(trials, params, config)
-        t2 = time.perf_counter()
-        hstep(trials, params, config)
-        eng.synchronize()
-        t3 = time.perf_counter()
-
-        runtime["e_elapsed"].append(t1 - t0)
-        runtime["m_elapsed"].append(t2 - t1)
-        runtime["h_elapsed"].append(t3 - t2)
-        runtime["em_elapsed"].append(t3 - t0)
-        config["runtime"] = runtime
-        if echo:
-            echo("Iteration {:4d}, E-step {:.2f}s, M-step {:.2f}s".format(
-                runtime["it"], runtime["e_elapsed"][-1], runtime["m_elapsed"][-1]))
-
-        if config["callbacks"]:
-            trials.pull()
-            for cb in config["callbacks"]:
-                try:
-                    cb(trials, params, config)
-                except RuntimeError:
-                    logger.error("Callback {} failed".format(cb))
-
-        _, norm_dmu = eng.norms(sid)
-        converged = (norm_dmu < tol * norm_mu
-                     and np.linalg.norm(params["da"]) < tol * norm_a
-                     and np.linalg.norm(params["db"]) < tol * norm_b)
-        if converged and it + 1 >= config["min_iter"]:
+    runtime = new_runtime()
+    _push_params(trials.engine, params)
+    for _ in range(config["max_iter"]):
+        if em_iteration(trials, params, config, runtime, echo):
             break
