@@ -170,6 +170,11 @@ int vlgp_profile_enable(vlgp_ctx* ctx, int on);
 int vlgp_profile_reset(vlgp_ctx* ctx);
 /* launches and total milliseconds recorded for `kind` since the last reset. */
 int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms);
+/* E-step phase anatomy: when enabled, thread 0 of every workgroup adds its
+ * shader-clock cycles per phase into 8 counters (0 staging, 1 y.a pass + first
+ * factor, 2 residual pass, 3 mean update, 4 curvature pass, 5 factor + variance).
+ * `out` may be NULL; on != 0 also zeroes the counters. */
+int vlgp_debug_phase_clock(vlgp_ctx* ctx, int on, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -285,7 +285,7 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     free_priors(ctx);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(ctx->d_gauss); fr(ctx->d_a); fr(ctx->d_b); fr(ctx->d_noise); fr(ctx->d_da); fr(ctx->d_db);
-    fr(ctx->d_fail); fr(ctx->d_work); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
+    fr(ctx->d_fail); fr(ctx->d_clk); fr(ctx->d_work); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -739,6 +739,23 @@ extern "C" int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double*
 }
 
 // ---- measurement -------------------------------------------------------------
+extern "C" int vlgp_debug_phase_clock(vlgp_ctx* ctx, int on, uint64_t out[8]) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (out) {
+        for (int i = 0; i < 8; ++i) out[i] = 0;
+        if (ctx->d_clk) HIPCHK(ctx, hipMemcpy(out, ctx->d_clk, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    if (on) {
+        if (!ctx->d_clk) HIPCHK(ctx, hipMalloc(&ctx->d_clk, 8 * sizeof(uint64_t)));
+        HIPCHK(ctx, hipMemset(ctx->d_clk, 0, 8 * sizeof(uint64_t)));
+    } else if (ctx->d_clk) {
+        (void)hipFree(ctx->d_clk);
+        ctx->d_clk = nullptr;
+    }
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_profile_enable(vlgp_ctx* ctx, int on) {
     NEED_CTX(ctx);
     if (!on) prof_drain(ctx);

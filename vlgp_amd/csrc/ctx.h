@@ -68,6 +68,7 @@ struct vlgp_ctx {
     UnitSet sets[VLGP_MAX_SETS];
 
     int* d_fail = nullptr;        // device failure counter
+    unsigned long long* d_clk = nullptr;  // E-step per-phase cycle counters (debug), 8 slots
     double* d_work = nullptr;     // general workspace (M-step partials, H-step, reductions)
     int64_t work_len = 0;
     double* h_pinned = nullptr;   // small pinned staging buffer

@@ -47,6 +47,7 @@ struct EstepArgs {
     int rg;                // lanes per row in the (T x N) passes (power of two <= 64)
     int lds_T;             // SMALL: row capacity of the LDS tiles
     int lds_gsz, lds_lcsz; // doubles reserved for G tiles / factors in LDS
+    unsigned long long* clk; // optional per-phase cycle counters (thread 0 of every block), or null
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -354,20 +355,34 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) estep_kernel(EstepArgs A) 
 
     // ---- schedule ----------------------------------------------------------
     const int mode = A.mode;
+    unsigned long long tick = A.clk ? __builtin_readcyclecounter() : 0;
+    auto lap = [&](int slot) {
+        if (A.clk && tid == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            atomicAdd(A.clk + slot, now - tick);
+            tick = now;
+        }
+    };
+    lap(0);  // staging
     if (mode & EM_MEAN) tn_pass(std::integral_constant<int, PASS_YA>{});
     if (mode & EM_FACTOR0) factor_phase((mode & EM_V) && !(mode & EM_MEAN));
     __syncthreads();
+    lap(1);  // y.a pass + first factor
     if (mode & EM_MEAN) {
         for (int it = 0; it < A.n_iter; ++it) {
             const bool last = it == A.n_iter - 1;
             tn_pass(std::integral_constant<int, PASS_RES>{});
             __syncthreads();
+            lap(2);
             mean_phase(last);
             __syncthreads();
+            lap(3);
             tn_pass(std::integral_constant<int, PASS_W>{});
             __syncthreads();
+            lap(4);
             if (A.vb || !last) factor_phase(A.vb != 0);
             __syncthreads();
+            lap(5);
         }
     } else if (mode & EM_W) {
         tn_pass(std::integral_constant<int, PASS_W>{});
@@ -461,6 +476,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.a = ctx->d_a; A.b = ctx->d_b; A.noise = ctx->d_noise; A.gauss = ctx->d_gauss;
     A.scratch = nullptr; A.lc_global = nullptr; A.lc_stride = 0;
     A.fail = ctx->d_fail;
+    A.clk = ctx->d_clk;
     A.lds_T = us.Tmax; A.lds_gsz = (int)gsz; A.lds_lcsz = (int)lcsz;
 
     // SMALL: whole unit state lives in LDS

@@ -242,6 +242,12 @@ class Engine:
     def profile_reset(self):
         self._ck(self.lib.vlgp_profile_reset(self.h))
 
+    def phase_clock(self, on=True):
+        """Read (and re-arm or disable) the E-step per-phase cycle counters."""
+        out = (C.c_uint64 * 8)()
+        self._ck(self.lib.vlgp_debug_phase_clock(self.h, int(bool(on)), out))
+        return [int(v) for v in out]
+
     def profile_get(self, kind):
         n, ms = C.c_int64(0), C.c_double(0)
         self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms)))
