@@ -11,7 +11,10 @@
 // tr(K^-1 dK), log det.  Per segment (one wavefront each, factor in LDS):
 // Cholesky of K^-1 + W, its triangular inverse X, and the two Frobenius
 // products <X'X, K^-1>, <X'X, Q> accumulated without materialising S.
+#include <stdlib.h>
+
 #include "ctx.h"
+#include "wave_tri.h"
 
 #define HS_MAXT 64
 
@@ -251,6 +254,203 @@ __global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* 
     }
 }
 
+
+// ===========================================================================
+// Fast path (window known at compile time): register-resident rows, see
+// wave_tri.h.  Uses the algebraically equivalent, better conditioned form
+//     A_i = I + W_i^1/2 K W_i^1/2          (eigenvalues >= 1)
+//     tr(K^-1 S_i)            = tr(A_i^-1)
+//     tr(K^-1 S_i K^-1 dK)    = tr(K^-1 dK) - sum_jk sqrt(w_j w_k) dK_jk (A_i^-1)_jk
+// (W^1/2 S W^1/2 = I - A^-1, diag(dK) = 0), so that K^-1 is needed only for
+// alpha = K^-1 mu, and K, dK enter through their first columns (Toeplitz).
+// ===========================================================================
+struct HFastArgs {
+    int L, M;
+    double dt;
+    const int64_t* off;
+    const double* mu;
+    const double* w;
+    const int* latent;
+    const double* logp;
+    double* kinv;   // (n_eval, T, T)
+    double* kcol;   // (n_eval, 2, 64): first column of K, first column of dK
+    double* scal;   // (n_eval, 4): logdet, -, omega_used, ok
+    double* out;    // (n_eval, M, 2)
+};
+
+template <int T>
+__global__ void __launch_bounds__(64, 3) hstep_prep_fast(HFastArgs A) {
+    constexpr int PK = tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
+    __shared__ __attribute__((aligned(16))) double Lp[PK];
+    __shared__ double kv[64], dkv[64];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const double sigmasq = exp(A.logp[3 * e + 0]);
+    double omega = exp(A.logp[3 * e + 1]);
+    const double eps = exp(A.logp[3 * e + 2]);
+    double r[T];
+    double logdet = 0.0;
+    // No retry loop here: if K fails to factor (the reference then bumps omega,
+    // gp.py:128-135) the host re-runs the batch through the generic kernels.
+    {
+        const double d = lane * A.dt, d2 = d * d;
+        const double kk = sigmasq * exp(-omega * d2);
+        kv[lane] = kk + (lane == 0 ? eps : 0.0);
+        dkv[lane] = -kk * d2 * omega;
+    }
+    tri_wave_sync();
+    if (lane < T) {
+        const int my_off = tri_row_off(lane);
+#pragma nounroll
+        for (int i = 0; i <= lane; ++i) Lp[my_off + i] = kv[lane - i];
+    }
+    tri_wave_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    const bool ok = wave_chol_rows<T>(r, Lp, lane);
+    logdet = wave_tri_logdet<T>(Lp, lane);
+    double x[T];
+    wave_tri_inverse_cols<T>(Lp, x, lane);
+    tri_wave_sync();
+    wave_store_cols<T>(x, Lp, lane);
+    // K^-1 = X'X: lane i produces row i
+    constexpr TriuOff<T> off{};
+    double* Ki = A.kinv + (int64_t)e * T * T;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const double* Xj = Lp + off.v[j];
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = j; k < T; k += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
+            a0 = fma(x[k], v.x, a0);
+            if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
+        }
+        if (lane < T) Ki[(int64_t)lane * T + j] = a0 + a1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    A.kcol[(int64_t)e * 128 + lane] = kv[lane];
+    A.kcol[(int64_t)e * 128 + 64 + lane] = dkv[lane];
+    if (lane == 0) {
+        A.scal[4 * e + 0] = logdet;
+        A.scal[4 * e + 1] = 0.0;
+        A.scal[4 * e + 2] = omega;
+        A.scal[4 * e + 3] = ok ? 1.0 : 0.0;
+    }
+}
+
+template <int T>
+__global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
+    constexpr int PK = tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
+    constexpr int NW = 4;
+    __shared__ __attribute__((aligned(16))) double Lp_all[NW][PK];
+    __shared__ double vec_all[NW][3][64];
+    __shared__ double kv[64], dkv[64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int e = blockIdx.y;
+    const int seg = blockIdx.x * NW + wid;
+    if (threadIdx.x < 64) kv[threadIdx.x] = A.kcol[(int64_t)e * 128 + threadIdx.x];
+    else if (threadIdx.x < 128) dkv[threadIdx.x - 64] = A.kcol[(int64_t)e * 128 + threadIdx.x];
+    __syncthreads();
+    if (seg >= A.M) return;
+    double* Lp = Lp_all[wid];
+    double* sw = vec_all[wid][0];
+    double* muv = vec_all[wid][1];
+    double* alv = vec_all[wid][2];
+    const int l = A.latent[e];
+    const int64_t r0 = A.off[seg];
+    const double* Ki = A.kinv + (int64_t)e * T * T;
+    const bool in = lane < T;
+    double mu_t = 0.0, w_t = 0.0;
+    if (in) {
+        mu_t = A.mu[(r0 + lane) * A.L + l];
+        w_t = A.w[(r0 + lane) * A.L + l];
+    }
+    const double sw_t = sqrt(w_t);
+    sw[lane] = sw_t;
+    muv[lane] = mu_t;
+    tri_wave_sync();
+    // alpha = K^-1 mu (K^-1 symmetric: read a column, coalesced)
+    double al = 0.0;
+    if (in) {
+#pragma unroll 5
+        for (int j = 0; j < T; ++j) al = fma(Ki[j * T + lane], muv[j], al);
+    }
+    alv[lane] = al;
+    tri_wave_sync();
+    double quad = mu_t * al, gq = 0.0;
+    {
+        double sacc = 0.0;
+#pragma unroll 5
+        for (int j = 0; j < T; ++j) {
+            const int dd = lane > j ? lane - j : j - lane;
+            sacc = fma(dkv[dd & 63], alv[j], sacc);
+        }
+        gq = in ? sacc * al : 0.0;
+    }
+    // row `lane` of A = I + W^1/2 K W^1/2, lower part, into packed LDS
+    if (in) {
+        const int my_off = tri_row_off(lane);
+#pragma nounroll
+        for (int i = 0; i <= lane; ++i)
+            Lp[my_off + i] = sw_t * sw[i] * kv[lane - i] + (i == lane ? 1.0 : 0.0);
+    }
+    tri_wave_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    double r[T];
+    const bool ok = wave_chol_rows<T>(r, Lp, lane);
+    double tr = 0.0, cacc = 0.0;
+    if (ok) {
+        double x[T];
+        wave_tri_inverse_cols<T>(Lp, x, lane);
+#pragma unroll
+        for (int k = 0; k < T; ++k) tr = fma(x[k], x[k], tr);
+        tri_wave_sync();
+        wave_store_cols<T>(x, Lp, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr TriuOff<T> off{};
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const double* Xj = Lp + off.v[j];
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = j; k < T; k += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
+                a0 = fma(x[k], v.x, a0);
+                if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
+            }
+            const int dd = lane > j ? lane - j : j - lane;
+            cacc = fma((a0 + a1) * sw[j], dkv[dd & 63], cacc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cacc = in ? cacc * sw_t : 0.0;
+        if (!in) tr = 0.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        quad += __shfl_xor(quad, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+        tr += __shfl_xor(tr, o, 64);
+        cacc += __shfl_xor(cacc, o, 64);
+    }
+    if (lane == 0) {
+        const double logdet = A.scal[4 * e + 0];
+        double ll = -0.5 * quad - 0.5 * tr - logdet;
+        double dll = 0.5 * (gq - cacc);
+        if (!ok) { ll = nan(""); dll = nan(""); }
+        A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
+        A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
+    }
+}
+
+template <int T>
+static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
+    hipLaunchKernelGGL((hstep_prep_fast<T>), dim3(n_eval), dim3(64), 0, ctx->stream, F);
+    HIPCHK(ctx, hipGetLastError());
+    vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
+    hipLaunchKernelGGL((hstep_seg_fast<T>), dim3((M + 3) / 4, n_eval), dim3(256), 0, ctx->stream, F);
+    vlgp_prof_end(ctx, VLGP_PROF_HSTEP);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
 int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
                  const double* logp, double* ll, double* dll) {
     const int T = window, L = ctx->L, M = us.M;
@@ -263,7 +463,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 2 * n_eval;
     const int64_t o_lat = o_logp + 3 * n_eval, total = o_lat + n_eval + 8;
     CHK(vlgp_ensure_work(ctx, total));
-    CHK(vlgp_ensure_pinned(ctx, 8 * n_eval + 16));
+    CHK(vlgp_ensure_pinned(ctx, 12 * n_eval + 32));
     double* W = ctx->d_work;
     double* hp = ctx->h_pinned;
     for (int i = 0; i < 3 * n_eval; ++i) hp[i] = logp[i];
@@ -275,6 +475,34 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     HIPCHK(ctx, hipMemcpyAsync(W + o_logp, hp, sizeof(double) * 3 * n_eval, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(W + o_lat, hlat, sizeof(int) * n_eval, hipMemcpyHostToDevice, ctx->stream));
 
+    if (T == 50 && !getenv("VLGP_HSTEP_GENERIC")) {
+        HFastArgs F;
+        F.L = L; F.M = M; F.dt = dt; F.off = us.d_off; F.mu = us.mu; F.w = us.w;
+        F.latent = reinterpret_cast<const int*>(W + o_lat); F.logp = W + o_logp;
+        F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
+        CHK(launch_fast<50>(ctx, F, n_eval, M));
+        hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red);
+        HIPCHK(ctx, hipGetLastError());
+        CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
+        double* hres = hp + 4 * n_eval + 8;
+        double* hscal = hres + 2 * n_eval;
+        HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 2 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hscal, W + o_scal, sizeof(double) * 4 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        bool all_ok = true;
+        for (int e = 0; e < n_eval; ++e) all_ok = all_ok && hscal[4 * e + 3] != 0.0;
+        if (all_ok) {
+            for (int e = 0; e < n_eval; ++e) {
+                ll[e] = hres[2 * e + 0];
+                dll[3 * e + 0] = 0.0;
+                dll[3 * e + 1] = hres[2 * e + 1];
+                dll[3 * e + 2] = 0.0;
+            }
+            return VLGP_OK;
+        }
+        // K did not factor for some evaluation: fall through to the generic path,
+        // which implements the reference's omega bump
+    }
     HPrepArgs P;
     P.T = T; P.dt = dt; P.logp = W + o_logp; P.kinv = W + o_kinv; P.q = W + o_q; P.dk = W + o_dk;
     P.scal = W + o_scal;

@@ -205,13 +205,29 @@ __global__ void __launch_bounds__(512) mstep_accum(MArgs A) {
     }
 }
 
-// out[i] = sum_g partial[g][i], fixed order
-__global__ void __launch_bounds__(256) sum_partials_kernel(const double* partial, int G, int64_t K, double* out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= K) return;
-    double s = 0.0;
-    for (int g = 0; g < G; ++g) s += partial[(int64_t)g * K + i];
-    out[i] = s;
+// out[i] = sum_g partial[g][i] in a fixed order: 8 strided slices of g per output
+// (coalesced over i), then a fixed 8-way combine through LDS.
+__global__ void __launch_bounds__(512) sum_partials_kernel(const double* partial, int G, int64_t K, double* out) {
+    __shared__ double red[8][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < K) {
+        int g = sl;
+        for (; g + 8 < G; g += 16) {
+            s0 += partial[(int64_t)g * K + i];
+            s1 += partial[(int64_t)(g + 8) * K + i];
+        }
+        if (g < G) s0 += partial[(int64_t)g * K + i];
+    }
+    red[sl][o] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && i < K) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][o];
+        out[i] = t;
+    }
 }
 
 // latent-only moments: Gram of mu (lower), column sums of mu and v, sums of squares
@@ -517,7 +533,7 @@ static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double*
     else if (L <= 16) launch_lat_t<16>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     else return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 latents supported, got %d", L);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, d_partial, G,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 63) / 64), dim3(512), 0, ctx->stream, d_partial, G,
                        (int64_t)K, d_out);
     HIPCHK(ctx, hipGetLastError());
     return vlgp_allreduce(ctx, d_out, K);
@@ -561,7 +577,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
 
     auto reduce_to = [&](int K, double* dst) -> int {
         const int64_t n = (int64_t)K * N;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, ctx->stream,
                            d_part, g.G, n, dst);
         HIPCHK(ctx, hipGetLastError());
         return vlgp_allreduce(ctx, dst, n);

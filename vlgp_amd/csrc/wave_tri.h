@@ -1,0 +1,132 @@
+// Wave-synchronous dense factorisation of one small SPD matrix per wavefront,
+// with each lane's row (or column) held in REGISTERS and the finished factor
+// rows broadcast from LDS.
+//
+// Why this shape on CDNA4: a T x T (T <= 64) fp64 Cholesky done by one wave out
+// of LDS alone needs two LDS reads per FMA (own row + pivot row); the own-row
+// reads are 512 B/instruction and saturate the CU's LDS port long before the
+// fp64 pipe (measured: 1.15 ms per 20 000 50x50 factorisations).  With the loop
+// fully unrolled (T is a template parameter) every register index is static,
+// the own row lives in 2T VGPRs, and the only LDS traffic left is the pivot
+// row, read with one wave-uniform (broadcast) ds_read_b128 per two FMAs.
+//
+// Packed storage: row i of a lower-triangular factor holds i+1 entries padded
+// to an even count so that every row starts 16-byte aligned.
+#pragma once
+#include <hip/hip_runtime.h>
+
+__host__ __device__ constexpr int tri_row_off(int i) {
+    // sum_{q<i} ((q + 2) & ~1)
+    return (i & 1) ? 2 * (i / 2) * (i / 2) + 4 * (i / 2) + 2 : 2 * (i / 2) * (i / 2) + 2 * (i / 2);
+}
+__host__ __device__ constexpr int tri_packed_size(int T) { return tri_row_off(T); }
+
+__device__ __forceinline__ void tri_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double tri_readlane(double x, int src_lane) {
+    union { double d; int i[2]; } u, o;
+    u.d = x;
+    o.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+    o.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+    return o.d;
+}
+
+// In: Lp (LDS, packed lower) holds A: row `lane` at tri_row_off(lane).  Out: Lp
+// holds chol(A) in place; r[i] = L[lane][i]; returns false on a non-positive
+// pivot.  Lanes >= T compute garbage, write nothing.
+template <int T>
+__device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int lane) {
+    const int my_off = tri_row_off(lane < T ? lane : 0);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {  // no early exit: a `break` would defeat the full unroll
+        const double* Lk = Lp + tri_row_off(k);
+        double s0 = Lp[my_off + k], s1 = 0.0;  // A[lane][k]; garbage (in bounds) for lane < k
+#pragma unroll
+        for (int i = 0; i + 1 < k; i += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Lk + i);
+            s0 = fma(-r[i], v.x, s0);
+            s1 = fma(-r[i + 1], v.y, s1);
+        }
+        if (k & 1) s0 = fma(-r[k - 1], Lk[k - 1], s0);
+        const double s = s0 + s1;
+        const double d = tri_readlane(s, k);
+        if (!(d > 0.0) || !(d < 1e300)) ok = false;  // later columns are garbage; caller discards
+        const double sd = sqrt(d);
+        r[k] = (lane == k) ? sd : s / sd;
+        if (lane >= k && lane < T) Lp[my_off + k] = r[k];
+        tri_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);  // one scheduling region per column: bounded live ranges
+    }
+    return ok;
+}
+
+// sum_k log L[k][k] of a packed factor: one log per lane, then a wave reduction
+template <int T>
+__device__ __forceinline__ double wave_tri_logdet(const double* Lp, int lane) {
+    double v = lane < T ? log(Lp[tri_row_off(lane < T ? lane : 0) + (lane < T ? lane : 0)]) : 0.0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// In: Lp = packed lower-triangular L.  Out: x[i] = (L^-1)[i][lane], i.e. lane c
+// holds COLUMN c of X = L^-1 (zeros above the diagonal).
+template <int T>
+__device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (&x)[T], int lane) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const double* Li = Lp + tri_row_off(i);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j + 1 < i; j += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Li + j);
+            a0 = fma(v.x, x[j], a0);
+            a1 = fma(v.y, x[j + 1], a1);
+        }
+        if (i & 1) a0 = fma(Li[i - 1], x[i - 1], a0);
+        const double rhs = (lane == i) ? 1.0 : 0.0;
+        x[i] = (rhs - (a0 + a1)) / Li[i];
+        // keep the scheduler from hoisting later rows' LDS loads (register pressure)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Upper-packed storage of X' (row c = column c of X, entries k = c..T-1, padded
+// to an even count): offset of row c.
+__host__ __device__ constexpr int triu_row_off(int c, int T) {
+    // sum_{q<c} ((T - q + 1) & ~1)
+    int s = 0;
+    for (int q = 0; q < c; ++q) s += (T - q + 1) & ~1;
+    return s;
+}
+template <int T>
+struct TriuOff {
+    int v[T + 1];
+    constexpr TriuOff() : v() {
+        int s = 0;
+        for (int q = 0; q <= T; ++q) {
+            v[q] = s;
+            s += (T - q + 1) & ~1;
+        }
+    }
+};
+
+// Store column `lane` of X (registers) as packed row `lane` of X' in LDS.
+template <int T>
+__device__ __forceinline__ void wave_store_cols(const double (&x)[T], double* Xp, int lane) {
+    constexpr TriuOff<T> off{};
+    int my = 0;
+#pragma unroll
+    for (int q = 0; q < T; ++q)
+        if (q == lane) my = off.v[q];
+    if (lane < T) {
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+            if (k >= lane) Xp[my + k - lane] = x[k];
+        if ((T - lane) & 1) Xp[my + T - lane] = 0.0;  // zero the pad so pair reads are exact
+    }
+    tri_wave_sync();
+}
