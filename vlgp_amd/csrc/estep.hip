@@ -21,34 +21,7 @@
 // factor/solve phases (wave-synchronous, no workgroup barriers inside).
 #include "ctx.h"
 
-struct EstepArgs {
-    int N, L;
-    int mode, n_iter, vb;
-    double dmu_bound;
-    const int64_t* off;
-    const int* unit_prior;
-    const double* const* prior_base;
-    const int* prior_rl;
-    const int64_t* prior_goff;
-    const double* y;
-    const double* xb;  // (rows, N) or null when x == 1
-    double* mu;
-    double* v;
-    double* w;
-    double* dmu;
-    const double* a;
-    const double* b;
-    const double* noise;
-    const int* gauss;
-    double* scratch;       // long units: 3 * rows * L doubles (ra, ya, u)
-    double* lc_global;     // long units whose factors do not fit LDS (else null)
-    int64_t lc_stride;     // doubles per unit in lc_global
-    int* fail;
-    int rg;                // lanes per row in the (T x N) passes (power of two <= 64)
-    int lds_T;             // SMALL: row capacity of the LDS tiles
-    int lds_gsz, lds_lcsz; // doubles reserved for G tiles / factors in LDS
-    unsigned long long* clk; // optional per-phase cycle counters (thread 0 of every block), or null
-};
+#include "estep_args.h"
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -478,6 +451,13 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.fail = ctx->d_fail;
     A.clk = ctx->d_clk;
     A.lds_T = us.Tmax; A.lds_gsz = (int)gsz; A.lds_lcsz = (int)lcsz;
+
+    // FAST: register-resident factorisations (estep_fast.hip); declines when it does not apply
+    {
+        int handled = 0;
+        CHK(launch_estep_fast(ctx, us, A, &handled));
+        if (handled) return VLGP_OK;
+    }
 
     // SMALL: whole unit state lives in LDS
     int nw_s = L < 4 ? 4 : (L > 8 ? 8 : L);

@@ -1,0 +1,38 @@
+// Kernel argument block shared by the generic (estep.hip) and the fast
+// (estep_fast.hip) E-step kernels.
+#pragma once
+#include "ctx.h"
+
+struct EstepArgs {
+    int N, L;
+    int mode, n_iter, vb;
+    double dmu_bound;
+    const int64_t* off;
+    const int* unit_prior;
+    const double* const* prior_base;
+    const int* prior_rl;
+    const int64_t* prior_goff;
+    const double* y;
+    const double* xb;  // (rows, N) or null when x == 1
+    double* mu;
+    double* v;
+    double* w;
+    double* dmu;
+    const double* a;
+    const double* b;
+    const double* noise;
+    const int* gauss;
+    double* scratch;       // long units: 3 * rows * L doubles (ra, ya, u)
+    double* lc_global;     // long units whose factors do not fit LDS (else null)
+    int64_t lc_stride;     // doubles per unit in lc_global
+    int* fail;
+    int rg;                // lanes per row in the (T x N) passes (power of two <= 64)
+    int lds_T;             // SMALL: row capacity of the LDS tiles
+    int lds_gsz, lds_lcsz; // doubles reserved for G tiles / factors in LDS
+    unsigned long long* clk; // optional per-phase cycle counters (thread 0 of every block), or null
+};
+
+
+// estep_fast.hip: sets *handled = 1 and launches when the fast kernel applies
+// (T <= 64, every effective rank <= 32, L <= 8, LDS fits), else leaves 0.
+int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);

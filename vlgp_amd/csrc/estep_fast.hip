@@ -1,0 +1,498 @@
+// Fast E-step kernel for window-sized units (T <= 64 bins, effective rank <= 32).
+//
+// Same mathematics and phase order as estep.hip (see its header; reference
+// vlgp/core.py:22-120); what changes is the mapping onto the CU:
+//
+//   (T x N) passes   lane <-> time bin, each wave owns a contiguous block of
+//                    channels.  The per-channel record (a_l, a_l^2, b, 1/noise)
+//                    is wave-uniform -> one broadcast ds_read_b128 per two
+//                    values, no cross-lane reduction at all; the per-(t, l)
+//                    sums of the waves meet once in LDS.  Gaussian channels are
+//                    a wave-uniform branch (no exp, no divergence).
+//   factor phases    one wave per latent, the matrix I + G'WG (padded with the
+//                    identity to RP = 16 or 32) is built with lanes =
+//                    (row, time-chunk), factored and inverted with each lane's
+//                    row / column in registers (wave_tri.h): the only LDS
+//                    traffic is the broadcast pivot row.
+//   solves           (I+H)^-1 rhs = X'(X rhs) and v_t = |X g_t|^2 as dense
+//                    products with X rows broadcast from LDS and the G row of
+//                    lane t in registers.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "estep_args.h"
+#include "wave_tri.h"
+
+enum { FP_YA = 0, FP_RES = 1, FP_W = 2 };
+
+// exp(x) for x <= 10 (callers clamp): Cody-Waite reduction by ln 2, degree-13
+// Taylor polynomial on |r| <= ln2/2 (truncation 4e-18), one ldexp.  < 2 ulp.
+__device__ __forceinline__ double fast_exp(double x) {
+    x = x < -745.0 ? -745.0 : x;  // keeps NaN (comparison false), avoids int overflow below
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.0876756987868100e-09);
+    p = fma(p, r, 2.5052108385441720e-08);
+    p = fma(p, r, 2.7557319223985888e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.4801587301587302e-05);
+    p = fma(p, r, 1.9841269841269841e-04);
+    p = fma(p, r, 1.3888888888888889e-03);
+    p = fma(p, r, 8.3333333333333332e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+template <int LT, int RP>
+__global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(EstepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int REC = 2 * LT + 2;          // a[LT], a^2[LT], b, c  (even -> 16-byte records)
+    constexpr int PK = tri_packed_size(RP);  // packed lower-triangular RP x RP
+    constexpr int NCH = 64 / RP;             // time chunks per wave in the (row, chunk) mapping
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+    const int N = A.N, L = A.L;
+    const int m = blockIdx.x;
+    const int64_t r0 = A.off[m];
+    const int T = (int)(A.off[m + 1] - r0);
+    const int Tc = A.lds_T;
+    const int pidx = A.unit_prior ? A.unit_prior[m] : -1;
+    const double* Gbase = pidx >= 0 ? A.prior_base[pidx] : nullptr;
+
+    double* p = smem;
+    double* cols = p;    p += (int64_t)N * REC;
+    double* wconst = p;  p += (L + 1) & ~1;
+    double* mu_s = p;    p += Tc * L;
+    double* v_s = p;     p += Tc * L;
+    double* w_s = p;     p += Tc * L;
+    double* ra_s = p;    p += Tc * L;
+    double* ya_s = p;    p += Tc * L;
+    double* u_s = p;     p += Tc * L;
+    double* part = p;    p += (int64_t)nw * Tc * L;
+    p += ((p - smem) & 1);  // keep 16-byte alignment for the vector-read regions below
+    double* vec_s = p;   p += nw * 128;
+    double* Xp = p;      p += (int64_t)L * PK;
+    double* G_s = p;     p += A.lds_gsz;
+    int* ip = reinterpret_cast<int*>(p);
+    int* gflag = ip;     ip += N;
+    int* rl_s = ip;      ip += L;
+    int* goff_s = ip;    ip += L;
+    int* fail_s = ip;    ip += L;
+
+    // ---- stage ---------------------------------------------------------------
+    for (int n = tid; n < N; n += nthr) {
+        const int g = A.gauss[n];
+        gflag[n] = g;
+        double* rec = cols + (int64_t)n * REC;
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const double av = l < L ? A.a[l * N + n] : 0.0;
+            rec[l] = av;
+            rec[LT + l] = av * av;
+        }
+        rec[2 * LT] = A.b[n];
+        rec[2 * LT + 1] = g ? 1.0 / A.noise[n] : 1.0;
+    }
+    if (tid == 0) {
+        int go = 0;
+        for (int l = 0; l < L; ++l) {
+            const int r = pidx >= 0 ? A.prior_rl[pidx * L + l] : 0;
+            rl_s[l] = r;
+            goff_s[l] = go;
+            go += T * ((r + 1) & ~1);
+            fail_s[l] = 0;
+        }
+    }
+    for (int i = tid; i < T * L; i += nthr) {
+        mu_s[i] = A.mu[r0 * L + i];
+        v_s[i] = A.v[r0 * L + i];
+        w_s[i] = A.w[r0 * L + i];
+    }
+    __syncthreads();
+    if (tid < L) {
+        double s = 0.0;
+        for (int n = 0; n < N; ++n)
+            if (gflag[n]) s = fma(cols[(int64_t)n * REC + LT + tid], cols[(int64_t)n * REC + 2 * LT + 1], s);
+        wconst[tid] = s;
+    }
+    for (int l = 0; l < L; ++l) {
+        const int r = rl_s[l], rs = (r + 1) & ~1;
+        if (r == 0) continue;
+        const double* src = Gbase + A.prior_goff[pidx * L + l];
+        double* dst = G_s + goff_s[l];
+        for (int i = tid; i < T * rs; i += nthr) {
+            const int t = i / rs, c = i - t * rs;
+            dst[i] = c < r ? src[t * r + c] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- (T x N) passes ----------------------------------------------------------
+    auto tn_pass = [&](auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int t = lane;
+        const bool in = t < T;
+        double mr[LT], vr[LT], acc[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const bool use = in && l < L && KIND != FP_YA;
+            mr[l] = use ? mu_s[t * L + l] : 0.0;
+            vr[l] = use ? v_s[t * L + l] : 0.0;
+            acc[l] = 0.0;
+        }
+        const int n0 = (N * wid) / nw, n1 = (N * (wid + 1)) / nw;
+        const double* yrow = A.y + (r0 + (in ? t : 0)) * N;
+        const double* xbrow = A.xb ? A.xb + (r0 + (in ? t : 0)) * N : nullptr;
+#pragma unroll 2
+        for (int n = n0; n < n1; ++n) {  // two channels in flight: their dependent fp64 chains interleave
+            double rv[REC];
+            const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)n * REC);
+#pragma unroll
+            for (int q = 0; q < REC / 2; ++q) {
+                const double2 t2 = rp[q];
+                rv[2 * q] = t2.x;
+                rv[2 * q + 1] = t2.y;
+            }
+            if constexpr (KIND == FP_YA) {
+                const double yc = yrow[n] * rv[2 * LT + 1];
+#pragma unroll
+                for (int l = 0; l < LT; ++l) acc[l] = fma(yc, rv[l], acc[l]);
+            } else {
+                double eta = xbrow ? xbrow[n] : rv[2 * LT];
+                double lin = 0.0;
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    eta = fma(mr[l], rv[l], eta);
+                    lin = fma(vr[l], rv[LT + l], lin);
+                }
+                const int g = gflag[n];  // wave-uniform
+                if constexpr (KIND == FP_RES) {
+                    double mval;
+                    if (g) mval = eta * rv[2 * LT + 1];
+                    else mval = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) acc[l] = fma(mval, rv[l], acc[l]);
+                } else if (!g) {
+                    const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) acc[l] = fma(rate, rv[LT + l], acc[l]);
+                }
+            }
+        }
+        if (in) {
+#pragma unroll
+            for (int l = 0; l < LT; ++l)
+                if (l < L) part[((int64_t)wid * Tc + t) * L + l] = acc[l];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < T * L; idx += nthr) {
+            double s = 0.0;
+            for (int w = 0; w < nw; ++w) s += part[(int64_t)w * Tc * L + idx];
+            if constexpr (KIND == FP_YA) ya_s[idx] = s;
+            else if constexpr (KIND == FP_RES) ra_s[idx] = ya_s[idx] - s;
+            else w_s[idx] = s + wconst[idx % L];
+        }
+        __syncthreads();
+    };
+
+    // ---- factor I + G'WG, invert, optionally refresh v -------------------------------
+    auto factor_phase = [&](bool do_v) {
+        for (int l = wid; l < L; l += nw) {
+            const int r = __builtin_amdgcn_readfirstlane(rl_s[l]);
+            const int rs = (r + 1) & ~1;
+            const double* Gl = G_s + __builtin_amdgcn_readfirstlane(goff_s[l]);
+            double* Xl = Xp + (int64_t)l * PK;
+            const int j = lane & (RP - 1), ch = lane / RP;
+            {
+                double a[RP];
+#pragma unroll
+                for (int i = 0; i < RP; ++i) a[i] = 0.0;
+                if (j < rs) {
+                    for (int t = ch; t < T; t += NCH) {
+                        const double* Gt = Gl + t * rs;
+                        const double gj = w_s[t * L + l] * Gt[j];
+#pragma unroll
+                        for (int i = 0; i < RP; i += 2)
+                            if (i < rs) {
+                                const double2 g2 = *reinterpret_cast<const double2*>(Gt + i);
+                                a[i] = fma(gj, g2.x, a[i]);
+                                a[i + 1] = fma(gj, g2.y, a[i + 1]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int o = RP; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int i = 0; i < RP; ++i) a[i] += __shfl_xor(a[i], o, 64);
+                }
+                if (lane < RP) {
+                    const int off = tri_row_off(lane);
+#pragma unroll
+                    for (int i = 0; i < RP; ++i)
+                        if (i <= lane) Xl[off + i] = a[i] + (i == lane ? 1.0 : 0.0);
+                }
+            }
+            tri_wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            bool ok;
+            {
+                double rr[RP];
+                ok = wave_chol_rows<RP>(rr, Xl, lane);
+            }
+            {
+                double x[RP];
+                wave_tri_inverse_cols<RP>(Xl, x, lane);
+                tri_wave_sync();
+                if (lane < RP) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+#pragma unroll
+                    for (int i = 0; i < RP; ++i)
+                        if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
+                }
+            }
+            tri_wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_v && ok && lane < T) {
+                const double* Gt = Gl + lane * rs;
+                double gt[RP];
+#pragma unroll
+                for (int i = 0; i < RP; i += 2) {
+                    double2 g2 = {0.0, 0.0};
+                    if (i < rs) g2 = *reinterpret_cast<const double2*>(Gt + i);
+                    gt[i] = g2.x;
+                    gt[i + 1] = g2.y;
+                }
+                double vv = 0.0;
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    if (i < r) {
+                        const double* Xi = Xl + tri_row_off(i);
+                        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                        for (int q = 0; q + 1 <= i; q += 2) {
+                            const double2 x2 = *reinterpret_cast<const double2*>(Xi + q);
+                            z0 = fma(x2.x, gt[q], z0);
+                            z1 = fma(x2.y, gt[q + 1], z1);
+                        }
+                        if (!(i & 1)) z0 = fma(Xi[i], gt[i], z0);
+                        const double z = z0 + z1;
+                        vv = fma(z, z, vv);
+                    }
+                }
+                v_s[lane * L + l] = vv;
+            }
+            if (lane == 0) {
+                fail_s[l] = ok ? 0 : 1;
+                if (!ok) atomicAdd(A.fail, 1);
+            }
+        }
+    };
+
+    // ---- Newton step on the posterior mean -------------------------------------------
+    auto mean_phase = [&](bool last) {
+        double* vec = vec_s + wid * 128;
+        double* vec2 = vec + 64;
+        for (int l = wid; l < L; l += nw) {
+            const int r = __builtin_amdgcn_readfirstlane(rl_s[l]);
+            const int rs = (r + 1) & ~1;
+            const double* Gl = G_s + __builtin_amdgcn_readfirstlane(goff_s[l]);
+            const double* Xl = Xp + (int64_t)l * PK;
+            double* u = u_s + (int64_t)l * Tc;
+            if (__builtin_amdgcn_readfirstlane(fail_s[l])) {  // singular system: zero update (core.py:92-94)
+                if (lane == 0) atomicAdd(A.fail, 1);
+                if (last && lane < T) A.dmu[(r0 + lane) * L + l] = 0.0;
+                continue;
+            }
+            const int j = lane & (RP - 1), ch = lane / RP;
+            // g1 = G' (res a_l)
+            double acc = 0.0;
+            if (j < rs)
+                for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * rs + j], ra_s[t * L + l], acc);
+#pragma unroll
+            for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane < RP) vec[lane] = acc;
+            tri_wave_sync();
+            // u = G g1 - mu_l   (row t of G stays in registers for the last step)
+            double gt[RP];
+            double ut = 0.0;
+            {
+                const double* Gt = Gl + (lane < T ? lane : 0) * rs;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < RP; i += 2) {
+                    double2 g2 = {0.0, 0.0};
+                    if (i < rs) {
+                        g2 = *reinterpret_cast<const double2*>(Gt + i);
+                        const double2 c2 = *reinterpret_cast<const double2*>(vec + i);
+                        s0 = fma(g2.x, c2.x, s0);
+                        s1 = fma(g2.y, c2.y, s1);
+                    }
+                    gt[i] = g2.x;
+                    gt[i + 1] = g2.y;
+                }
+                if (lane < T) {
+                    ut = (s0 + s1) - mu_s[lane * L + l];
+                    u[lane] = ut;
+                }
+            }
+            tri_wave_sync();
+            // rhs = (W G)' u
+            acc = 0.0;
+            if (j < rs)
+                for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * rs + j], u[t], acc);
+#pragma unroll
+            for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane < RP) vec2[lane] = acc;
+            tri_wave_sync();
+            // z = X rhs, sol = X' z   (lane = row, then lane = column)
+            double z = 0.0;
+            if (lane < RP) {
+                const double* Xi = Xl + tri_row_off(lane);
+#pragma unroll
+                for (int q = 0; q < RP; ++q)
+                    if (q <= lane) z = fma(Xi[q], vec2[q], z);
+            }
+            tri_wave_sync();
+            if (lane < RP) vec[lane] = z;
+            tri_wave_sync();
+            double sol = 0.0;
+            if (lane < RP) {
+#pragma unroll
+                for (int q = 0; q < RP; ++q)
+                    if (q >= lane) sol = fma(Xl[tri_row_off(q) + lane], vec[q], sol);
+            }
+            tri_wave_sync();
+            if (lane < RP) vec2[lane] = sol;
+            tri_wave_sync();
+            if (lane < T) {
+                double s0 = ut, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < RP; i += 2)
+                    if (i < rs) {
+                        const double2 c2 = *reinterpret_cast<const double2*>(vec2 + i);
+                        s0 = fma(-gt[i], c2.x, s0);
+                        s1 = fma(-gt[i + 1], c2.y, s1);
+                    }
+                double s = s0 + s1;
+                s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
+                if (last) A.dmu[(r0 + lane) * L + l] = s;
+                mu_s[lane * L + l] += s;
+            }
+            tri_wave_sync();
+        }
+    };
+
+    // ---- schedule (identical to estep.hip) ---------------------------------------------
+    const int mode = A.mode;
+    unsigned long long tick = A.clk ? __builtin_readcyclecounter() : 0;
+    auto lap = [&](int slot) {
+        if (A.clk && tid == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            atomicAdd(A.clk + slot, now - tick);
+            tick = now;
+        }
+    };
+    lap(0);
+    // One call site per phase (the unrolled factor code is large): iteration -1
+    // is the initial factorisation from the incoming w; update_w is a single
+    // curvature pass; update_v is iteration -1 alone.
+    const bool with_mean = (mode & EM_MEAN) != 0;
+    const int n_it = with_mean ? A.n_iter : ((mode & EM_W) ? 1 : 0);
+    if (with_mean) tn_pass(std::integral_constant<int, FP_YA>{});
+    for (int it = (mode & EM_FACTOR0) ? -1 : 0; it < n_it; ++it) {
+        const bool last = it == n_it - 1;
+        bool do_factor, do_v;
+        if (it >= 0) {
+            if (with_mean) {
+                tn_pass(std::integral_constant<int, FP_RES>{});
+                lap(2);
+                mean_phase(last);
+                __syncthreads();
+                lap(3);
+            }
+            tn_pass(std::integral_constant<int, FP_W>{});
+            lap(4);
+            do_factor = with_mean && (A.vb || !last);
+            do_v = A.vb != 0;
+        } else {
+            do_factor = true;
+            do_v = (mode & EM_V) && !with_mean;
+        }
+        if (do_factor) factor_phase(do_v);
+        __syncthreads();
+        lap(it >= 0 ? 5 : 1);
+    }
+
+    const bool wr_mu = mode & EM_MEAN;
+    const bool wr_w = mode & (EM_MEAN | EM_W);
+    const bool wr_v = (mode & EM_V) != 0;
+    for (int i = tid; i < T * L; i += nthr) {
+        if (wr_mu) A.mu[r0 * L + i] = mu_s[i];
+        if (wr_w) A.w[r0 * L + i] = w_s[i];
+        if (wr_v) A.v[r0 * L + i] = v_s[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <int LT, int RP>
+static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t lds) {
+    auto fn = estep_fast_kernel<LT, RP>;
+    if (lds > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
+    hipLaunchKernelGGL(fn, dim3(M), dim3(nthr), lds, ctx->stream, A);
+    vlgp_prof_end(ctx, VLGP_PROF_ESTEP);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
+template <int RP>
+static int launch_fast_l(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t lds) {
+    if (A.L <= 3) return launch_fast_t<3, RP>(ctx, A, M, nthr, lds);
+    if (A.L <= 5) return launch_fast_t<5, RP>(ctx, A, M, nthr, lds);
+    return launch_fast_t<8, RP>(ctx, A, M, nthr, lds);
+}
+
+int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
+    *handled = 0;
+    const int N = ctx->N, L = ctx->L;
+    if (getenv("VLGP_ESTEP_GENERIC")) return VLGP_OK;
+    if (us.Tmax > 64 || L > 8) return VLGP_OK;
+    const bool need_prior = (A.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
+    int rmax = 0;
+    int64_t gsz = 0;
+    if (need_prior) {
+        for (auto& kv : ctx->priors) {
+            const Prior& pr = kv.second;
+            if (pr.T < us.Tmin || pr.T > us.Tmax) continue;
+            int64_t g = 0;
+            for (int l = 0; l < L; ++l) {
+                rmax = pr.rl[l] > rmax ? pr.rl[l] : rmax;
+                g += (int64_t)pr.T * ((pr.rl[l] + 1) & ~1);
+            }
+            gsz = g > gsz ? g : gsz;
+        }
+    }
+    if (rmax > 32) return VLGP_OK;
+    const int RP = rmax <= 16 ? 16 : 32;
+    const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : 8);
+    const int nw = L < 4 ? 4 : L;  // L <= 8
+    const int Tc = us.Tmax;
+    const int64_t PK = RP == 16 ? tri_packed_size(16) : tri_packed_size(32);
+    int64_t d = (int64_t)N * (2 * LT + 2) + ((L + 1) & ~1) + 6LL * Tc * L + (int64_t)nw * Tc * L + 1 + nw * 128 +
+                L * PK + gsz + (N + 3 * L + 1) / 2 + 2;
+    if (d * 8 > 160 * 1024) return VLGP_OK;
+    A.lds_gsz = (int)gsz;
+    A.lds_T = Tc;
+    *handled = 1;
+    const int nthr = nw * 64;
+    if (RP == 16) return launch_fast_l<16>(ctx, A, us.M, nthr, (size_t)d * 8);
+    return launch_fast_l<32>(ctx, A, us.M, nthr, (size_t)d * 8);
+}

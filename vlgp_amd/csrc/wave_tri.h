@@ -35,8 +35,9 @@ __device__ __forceinline__ double tri_readlane(double x, int src_lane) {
 }
 
 // In: Lp (LDS, packed lower) holds A: row `lane` at tri_row_off(lane).  Out: Lp
-// holds chol(A) in place; r[i] = L[lane][i]; returns false on a non-positive
-// pivot.  Lanes >= T compute garbage, write nothing.
+// holds chol(A) in place; r[i] = L[lane][i] for i < lane.  Returns false on a
+// non-positive pivot.
+// Lanes >= T compute garbage, write nothing.
 template <int T>
 __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int lane) {
     const int my_off = tri_row_off(lane < T ? lane : 0);
@@ -56,7 +57,8 @@ __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int l
         const double d = tri_readlane(s, k);
         if (!(d > 0.0) || !(d < 1e300)) ok = false;  // later columns are garbage; caller discards
         const double sd = sqrt(d);
-        r[k] = (lane == k) ? sd : s / sd;
+        const double inv = 1.0 / sd;  // one reciprocal per column instead of a division per lane
+        r[k] = (lane == k) ? sd : s * inv;
         if (lane >= k && lane < T) Lp[my_off + k] = r[k];
         tri_wave_sync();
         __builtin_amdgcn_sched_barrier(0);  // one scheduling region per column: bounded live ranges
@@ -72,8 +74,8 @@ __device__ __forceinline__ double wave_tri_logdet(const double* Lp, int lane) {
     return v;
 }
 
-// In: Lp = packed lower-triangular L.  Out: x[i] = (L^-1)[i][lane], i.e. lane c
-// holds COLUMN c of X = L^-1 (zeros above the diagonal).
+// In: Lp = packed lower-triangular L.  Out: x[i] = (L^-1)[i][lane], i.e. lane c holds COLUMN c of X = L^-1 (zeros
+// above the diagonal).
 template <int T>
 __device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (&x)[T], int lane) {
 #pragma unroll
@@ -87,6 +89,9 @@ __device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (
             a1 = fma(v.y, x[j + 1], a1);
         }
         if (i & 1) a0 = fma(Li[i - 1], x[i - 1], a0);
+        // NB: a true division here, not a multiplication by a stored reciprocal:
+        // with the cheap form hipcc (ROCm 7.2) hoists far more of the unrolled
+        // rows' address/mask setup and spills ~230 VGPRs (measured 3x slower).
         const double rhs = (lane == i) ? 1.0 : 0.0;
         x[i] = (rhs - (a0 + a1)) / Li[i];
         // keep the scheduler from hoisting later rows' LDS loads (register pressure)
