@@ -65,9 +65,9 @@ class _LockStep:
     def _flush(self):
         keys = sorted(self.pending)
         try:
-            ll, dll = self.batch_fn(keys, np.stack([self.pending[k] for k in keys]))
+            f, G = self.batch_fn(keys, np.stack([self.pending[k] for k in keys]))
             for i, k in enumerate(keys):
-                self.results[k] = (float(ll[i]), np.array(dll[i]))
+                self.results[k] = (float(f[i]), np.array(G[i]))
         except Exception as exc:  # propagate to every waiting optimiser
             self.error = exc
             for k in keys:
@@ -94,6 +94,133 @@ class _LockStep:
                 self._flush()
 
 
+class _Lbfgsb:
+    """One bounded L-BFGS-B run as an explicit state machine.
+
+    Same algorithm, constants and stopping rules as
+    ``scipy.optimize.minimize(fun, x0, jac=True, bounds=...)`` (which selects
+    L-BFGS-B): it drives the very same reverse-communication routine
+    (``scipy.optimize._lbfgsb.setulb``) that SciPy's own driver loop
+    (``scipy/optimize/_lbfgsb_py.py:_minimize_lbfgsb``) drives, with SciPy's
+    defaults (maxcor 10, ftol 2.22e-9, gtol 1e-5, maxls 20, maxiter = maxfun =
+    15000).  Exposing the "needs f, g at x" state lets several runs share one
+    batched device evaluation per round without any threads.
+    """
+
+    MAXCOR, FTOL, GTOL, MAXLS, MAXITER, MAXFUN = 10, 2.2204460492503131e-09, 1e-5, 20, 15000, 15000
+
+    def __init__(self, setulb, x0, log_bounds):
+        self.setulb = setulb
+        lo, hi = log_bounds[:, 0].copy(), log_bounds[:, 1].copy()
+        n = x0.size
+        m = self.MAXCOR
+        self.x = np.clip(np.array(x0, dtype=np.float64), lo, hi)
+        self.lo, self.hi = lo, hi
+        self.nbd = np.full(n, 2, dtype=np.int32)  # both bounds finite
+        self.f = 0.0
+        self.g = np.zeros(n)
+        self.factr = self.FTOL / np.finfo(float).eps
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29)
+        self.nfev = 0
+        self.nit = 0
+        self.done = False
+
+    def advance(self):
+        """Run until the routine asks for (f, g) at self.x or terminates.
+        Returns True when an evaluation is wanted."""
+        while not self.done:
+            self.setulb(self.MAXCOR, self.x, self.lo, self.hi, self.nbd, self.f, self.g, self.factr,
+                        self.GTOL, self.wa, self.iwa, self.task, self.lsave, self.isave, self.dsave,
+                        self.MAXLS, self.ln_task)
+            if self.task[0] == 3:
+                return True
+            if self.task[0] == 1:  # new iterate accepted
+                self.nit += 1
+                if self.nit >= self.MAXITER:
+                    self.task[0], self.task[1] = 5, 504
+                elif self.nfev > self.MAXFUN:
+                    self.task[0], self.task[1] = 5, 502
+            else:
+                self.done = True
+        return False
+
+    def feed(self, f, g):
+        self.f = float(f)
+        self.g = np.array(g, dtype=np.float64)
+        self.nfev += 1
+
+
+def _setulb_or_none():
+    """The private reverse-communication entry point, if this SciPy has the
+    signature we know (SciPy 1.15: 17 positional arguments)."""
+    try:
+        from scipy.optimize import _lbfgsb
+
+        doc = _lbfgsb.setulb.__doc__ or ""
+        if "setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,lsave,isave,dsave,maxls,ln_task)" not in doc.replace(" ", ""):
+            return None
+        return _lbfgsb.setulb
+    except Exception:  # pragma: no cover
+        return None
+
+
+def lockstep_minimize(batch_fn, x0s, log_bounds):
+    """Minimise len(x0s) independent objectives with L-BFGS-B, evaluating all
+    pending points of a round with ONE call ``batch_fn(keys, X) -> (f, G)``
+    (f, G are the objective values / gradients to minimise).  Returns the list
+    of final x.  Single-threaded when SciPy's reverse-communication routine is
+    available, otherwise one ``scipy.optimize.minimize`` per thread with the
+    same batching (identical results either way)."""
+    setulb = _setulb_or_none()
+    if setulb is None:
+        return _lockstep_threads(batch_fn, x0s, log_bounds)
+    runs = [_Lbfgsb(setulb, x0, log_bounds) for x0 in x0s]
+    while True:
+        want = [k for k, r in enumerate(runs) if not r.done and r.advance()]
+        if not want:
+            break
+        f, G = batch_fn(want, np.stack([runs[k].x for k in want]))
+        for i, k in enumerate(want):
+            runs[k].feed(f[i], G[i])
+    return [r.x.copy() for r in runs]
+
+
+def _lockstep_threads(batch_fn, x0s, log_bounds):
+    n = len(x0s)
+    lock = _LockStep(n, batch_fn)
+    out = [None] * n
+    errors = []
+
+    def run(k):
+        try:
+            def obj(x):
+                return lock.evaluate(k, x)
+
+            out[k] = minimize(obj, x0s[k], jac=True, bounds=log_bounds).x
+        except Exception as exc:
+            errors.append(exc)
+        finally:
+            lock.retire()
+
+    if n == 1:
+        run(0)
+    else:
+        threads = [threading.Thread(target=run, args=(k,), daemon=True) for k in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
 def optimize(trials, params, config):
     """gp.optimize (vlgp/gp.py:65-97) on a DeviceTrials of equal-length segments."""
     from .engine import DeviceTrials, make_cholesky
@@ -110,39 +237,14 @@ def optimize(trials, params, config):
     bounds = np.log(np.array([(1e-3, 1.0), tuple(config["omega_bound"]),
                               (gp_noise / 2, gp_noise * 2)]))
 
-    def batch(latents, logps):
-        return eng.hstep_objective(sid, window, dt, latents, logps)
+    def batch(latents, logps):  # scipy minimises: negate ll and its gradient
+        ll, dll = eng.hstep_objective(sid, window, dt, latents, logps)
+        return -ll, -dll
 
-    lock = _LockStep(L, batch)
-    out = [None] * L
-    errors = []
-
-    def run(l):
-        try:
-            x0 = np.log(np.array([sigma[l] ** 2, omega[l], gp_noise]))
-
-            def neg(x):
-                ll, dll = lock.evaluate(l, x)
-                return -ll, -dll
-
-            out[l] = minimize(neg, x0, jac=True, bounds=bounds)
-        except Exception as exc:
-            errors.append(exc)
-        finally:
-            lock.retire()
-
-    if L == 1:
-        run(0)
-    else:
-        threads = [threading.Thread(target=run, args=(l,), daemon=True) for l in range(L)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-    if errors:
-        raise errors[0]
+    x0s = [np.log(np.array([sigma[l] ** 2, omega[l], gp_noise])) for l in range(L)]
+    xs = lockstep_minimize(batch, x0s, bounds)
     for l in range(L):
-        sig2, om, _ = np.exp(out[l].x)
+        sig2, om, _ = np.exp(xs[l])
         if not np.any(np.isclose(om, config["omega_bound"])):  # gp.py:91-92
             omega[l] = om
         sigma[l] = math.sqrt(sig2)
