@@ -591,3 +591,92 @@ def fit_given_init(trials, params, config):
     update_v(trials, params, config)
     infer(trials, params, config)
     return {"trials": trials, "params": params, "config": config}
+
+
+# --------------------------------------------------------------------------
+# Sufficient-statistics form of the M-step (the multi-GPU protocol)
+# --------------------------------------------------------------------------
+def mstep_sharded(y, x, mu, v, a, b, gauss, n_iter, allreduce=None, use_hessian=True, eps=1e-8,
+                  learning_rate=1.0, da_bound=5.0, db_bound=5.0):
+    """M-step on ONE shard of the rows, exchanging only sums with the other shards.
+
+    Mathematically ``mstep_arrays`` on the concatenation of all shards: every
+    quantity that couples rows is a sum over rows, so each rank accumulates its
+    part and ``allreduce(buf)`` (in-place sum over ranks; identity when None)
+    completes it -- one fused buffer per Newton iteration, exactly what
+    libvlgp_hip.so sends through RCCL.  Returns (a, b, da, db, noise).
+    """
+    if allreduce is None:
+        allreduce = lambda buf: buf
+    a = np.array(a, dtype=float)
+    b = np.array(b, dtype=float)
+    L, N = a.shape
+    P = b.shape[0]
+    da, db = np.zeros_like(a), np.zeros_like(b)
+    pois = ~gauss
+    # sweep-invariant moments: one fused buffer
+    pre = np.concatenate([
+        (mu.T @ y).ravel(),                          # MtY (L, N)
+        np.einsum("tpn,tn->pn", x, y).ravel(),       # XtY (P, N)
+        np.einsum("tpn,tl->npl", x, mu).ravel(),     # XtM (N, P, L)
+        np.einsum("tpn,tqn->npq", x, x).ravel(),     # XtX (N, P, P)
+        (mu.T @ mu).ravel(), v.sum(0), [float(y.shape[0])]])
+    pre = allreduce(pre)
+    o = 0
+    MtY = pre[o:o + L * N].reshape(L, N); o += L * N
+    XtY = pre[o:o + P * N].reshape(P, N); o += P * N
+    XtM = pre[o:o + N * P * L].reshape(N, P, L); o += N * P * L
+    XtX = pre[o:o + N * P * P].reshape(N, P, P); o += N * P * P
+    gram = pre[o:o + L * L].reshape(L, L); o += L * L
+    sumv = pre[o:o + L]; o += L
+    count = pre[o]
+    noise = None
+    for it in range(n_iter):
+        eta = mu @ a + np.einsum("tpn,pn->tn", x, b)
+        if it == n_iter - 1:  # noise = var(y - eta) entering the last iteration
+            s1 = allreduce((y - eta).sum(0))
+            mean = s1 / count
+            s2 = allreduce(((y - eta - mean) ** 2).sum(0))
+            noise = s2 / count
+        rate = capped_exp(eta + 0.5 * (v @ a ** 2))
+        shifted = mu[:, :, None] + v[:, :, None] * a[None, :, :]          # (T, L, N)
+        stats = np.concatenate([
+            np.einsum("tln,tn->ln", shifted, rate).ravel(),                # g1
+            np.einsum("tln,tn,tkn->nlk", shifted, rate, shifted).ravel(),  # H
+            (v.T @ rate).ravel(),                                          # rv (L, N)
+            np.einsum("tpn,tn->pn", x, rate).ravel(),                      # gb
+            np.einsum("tpn,tn,tqn->npq", x, rate, x).ravel()])             # Hb
+        stats = allreduce(stats)
+        o = 0
+        g1 = stats[o:o + L * N].reshape(L, N); o += L * N
+        H = stats[o:o + N * L * L].reshape(N, L, L); o += N * L * L
+        rv = stats[o:o + L * N].reshape(L, N); o += L * N
+        gb = stats[o:o + P * N].reshape(P, N); o += P * N
+        Hb = stats[o:o + N * P * P].reshape(N, P, P)
+        for n in range(N):
+            if pois[n]:
+                g_a = MtY[:, n] - g1[:, n]
+                step = learning_rate * g_a
+                if use_hessian:
+                    try:
+                        step = _spd_solve(H[n] + np.diag(rv[:, n]) + eps * np.eye(L), g_a)
+                    except Exception:
+                        pass
+                step = np.clip(step, -da_bound, da_bound)
+                da[:, n] = step
+                a[:, n] += step
+                g_b = XtY[:, n] - gb[:, n]
+                step = learning_rate * g_b
+                if use_hessian:
+                    try:
+                        step = _spd_solve(Hb[n] + eps * np.eye(P), g_b)
+                    except Exception:
+                        pass
+                step = np.clip(step, -db_bound, db_bound)
+                db[:, n] = step
+                b[:, n] += step
+            else:
+                a[:, n] = _spd_solve(gram + np.diag(sumv), MtY[:, n] - XtM[n].T @ b[:, n])
+                b[:, n] = _spd_solve(XtX[n], XtY[:, n] - XtM[n] @ a[:, n])
+                b[1:, n] = 0
+    return a, b, da, db, noise

@@ -1,0 +1,133 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol,
+and the host mirror of the reference interface behaves like the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+from oracle import vlgp_oracle as O
+
+HEADER = os.path.join(ROOT, "include", "vlgp_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vlgp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    from vlgp_amd import _lib
+
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), "libvlgp_hip.so lacks %s" % name
+    assert sorted(_lib.EXPORTS) == names, set(names) ^ set(_lib.EXPORTS)
+    assert lib.vlgp_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_gpu_fails_loudly():
+    import vlgp_amd
+    from vlgp_amd import _lib
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(vlgp_amd.VlgpError, match="no HIP device"):
+        vlgp_amd.Engine(4, 2, 1, 50)
+    trials = [{"y": np.zeros((50, 4))}]
+    with pytest.raises(vlgp_amd.VlgpError):
+        vlgp_amd.fit(trials, 2, verbose=False)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vlgp_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(base, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_config_defaults_are_the_references():
+    from vlgp_amd import get_config
+
+    ref = {"constrain_loading": "fro", "constrain_latent": False, "use_hessian": True, "eps": 1e-8,
+           "tol": 1e-8, "min_iter": 5, "method": "VB", "learning_rate": 1.0, "max_iter": 20, "Eniter": 25,
+           "Mniter": 25, "Hstep": True, "da_bound": 5.0, "db_bound": 5.0, "dmu_bound": 5.0,
+           "omega_bound": (5e-4, 5e-2), "window": 50, "saving_interval": 1800, "callbacks": [],
+           "parallel": False}  # vlgp/preprocess.py:85-106
+    cfg = get_config()
+    for k, v in ref.items():
+        assert cfg[k] == v, k
+    assert get_config(bogus=1, Eniter=3)["Eniter"] == 3 and "bogus" not in get_config(bogus=1)
+    assert get_config()["callbacks"] is not get_config()["callbacks"]
+
+
+def test_params_skeleton():
+    from vlgp_amd import get_params
+
+    trials = [{"y": np.zeros((10, 7))}]
+    p = get_params(trials, 3, omega_bound=(5e-4, 5e-2), lik=["poisson"] * 5 + ["gaussian"] * 2, history=2)
+    assert (p["ydim"], p["zdim"], p["xdim"], p["rank"]) == (7, 3, 2, 50)
+    assert np.all(p["omega"] == 5e-2) and np.all(p["sigma"] == 1) and p["gp_noise"] == 1e-4
+    assert list(p["likelihood"][-2:]) == ["gaussian", "gaussian"]
+
+
+def test_segment_starts_match_reference_rng_protocol():
+    from vlgp_amd.util import cut_trials, segment_starts
+
+    rng_trials = [{"y": np.arange(T * 2.0).reshape(T, 2), "x": np.ones((T, 1, 2)), "mu": np.zeros((T, 3)),
+                   "w": np.zeros((T, 3)), "v": np.zeros((T, 3))} for T in (100, 130, 50, 75)]
+    np.random.seed(5)
+    mine = cut_trials(rng_trials, None, {"window": 50})
+    np.random.seed(5)
+    ref = O.cut_trials(rng_trials, 50)
+    assert len(mine) == len(ref) == 2 + 3 + 1 + 2
+    for a, b in zip(mine, ref):
+        assert np.array_equal(a["y"], b["y"])
+        assert np.shares_memory(a["mu"], b["mu"])  # views of the parent, as in the reference
+    assert list(segment_starts(100, 50)) == [0, 50]
+
+
+def test_host_ichol_is_the_oracles():
+    from vlgp_amd.gp import ichol_gauss_host
+
+    for n, om in ((50, 5e-2), (200, 3e-3), (64, 1e-2)):
+        assert np.array_equal(ichol_gauss_host(n, om, 50), O.ichol_gauss(n, om, 50))
+
+
+def test_shard_bounds_partition():
+    from vlgp_amd.dist import shard_bounds
+
+    for n in (1, 7, 200, 203):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_mstep_sufficient_statistics_form_equals_mstep(golden):
+    for tag in ("p1", "p3", "mixed"):
+        g = golden("mstep_" + tag)
+        cat = lambda k: np.concatenate(list(g[k]), axis=0)
+        got = O.mstep_sharded(cat("y"), cat("x"), cat("mu"), cat("v"), g["a"], g["b"], g["gauss"], 25)
+        for k, arr in zip(("a", "b", "da", "db", "noise"), got):
+            if k in ("da", "db"):  # ~1e-7 increments: judge them on the scale of a, b
+                assert np.abs(arr - g[k + "_H_25"]).max() < 1e-9 * np.abs(g[k[1] + "_H_25"]).max(), (tag, k)
+            else:
+                assert relerr(arr, g[k + "_H_25"]) < 1e-9, (tag, k)
+
+
+def test_synth_is_seeded():
+    from vlgp_amd import synth
+
+    a = synth.make_trials(3, 100, 6, 4, seed=0)
+    b = synth.make_trials(3, 100, 6, 4, seed=0)
+    assert all(np.array_equal(x["y"], y["y"]) for x, y in zip(a, b))
+    assert a[0]["y"].shape == (100, 6) and a[0]["y"].min() >= 0
