@@ -415,3 +415,30 @@ def test_headline_size_properties(V):
         for k, r in zip(("mu", "v", "w"), ref):
             assert relerr(one[k].reshape(4000, 50, L)[i], r) < STAGE, (k, i)
     del chol
+
+
+# ------------------------------------------------------------------ RCCL plumbing on one GPU
+def test_single_rank_rccl_allreduce_is_identity(V, golden, monkeypatch):
+    """With VLGP_FORCE_RCCL=1 a one-rank communicator is built: dlopen of librccl,
+    unique id, ncclCommInitRank, in-stream fp64 all-reduces inside the M-step and the
+    norms.  One rank -> the sums are unchanged -> results must equal the plain run."""
+    monkeypatch.setenv("VLGP_FORCE_RCCL", "1")
+    from vlgp_amd import engine as E
+    from vlgp_amd.dist import Comm
+
+    g = golden("mstep_mixed")
+    M = g["y"].shape[0]
+    units = [{k: g[k][m].copy() for k in ("y", "x", "mu", "v")} for m in range(M)]
+    with V.Engine(20, 3, 1, 50, g["gauss"]) as eng:
+        Comm(0, 1).attach(eng)
+        buf = np.arange(5.0)
+        eng.allreduce_host(buf)
+        assert np.array_equal(buf, np.arange(5.0))
+        eng.barrier()
+        eng.set_params(g["a"], g["b"], g["noise"])
+        eng.upload(0, units)
+        eng.mstep(0, 25)
+        a, b, noise, _, _ = eng.get_params()
+        n_mu, _ = eng.norms(0)
+    assert relerr(a, g["a_H_25"]) < STAGE and relerr(b, g["b_H_25"]) < STAGE and relerr(noise, g["noise_H_25"]) < STAGE
+    assert abs(n_mu - np.linalg.norm(g["mu"])) < 1e-12 * n_mu

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -134,7 +135,7 @@ static int rccl_load(vlgp_ctx* ctx) {
 }
 
 int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n) {
-    if (ctx->world <= 1 || !ctx->comm) return VLGP_OK;
+    if (!ctx->comm) return VLGP_OK;
     const int rc = g_rccl.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
     if (rc != 0)
         return vlgp_fail(ctx, VLGP_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
@@ -155,7 +156,9 @@ extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]
     if (world < 1 || rank < 0 || rank >= world) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad rank/world %d/%d", rank, world);
     ctx->rank = rank;
     ctx->world = world;
-    if (world == 1) return VLGP_OK;
+    // a single rank needs no communicator; VLGP_FORCE_RCCL=1 builds one anyway so
+    // that the RCCL plumbing can be exercised on a one-GPU box (tests)
+    if (world == 1 && !getenv("VLGP_FORCE_RCCL")) return VLGP_OK;
     CHK(rccl_load(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     rccl_uid u;
@@ -170,7 +173,7 @@ extern "C" int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n) {
     NEED_CTX(ctx);
     if (n < 0 || (n > 0 && !buf)) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad allreduce arguments");
     HIPCHK(ctx, hipSetDevice(ctx->dev));
-    if (ctx->world <= 1 || !ctx->comm) {
+    if (!ctx->comm) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return VLGP_OK;
     }

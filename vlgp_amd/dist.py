@@ -81,7 +81,7 @@ class Comm:
         return c
 
     def attach(self, engine):
-        if self.world == 1:
+        if self.world == 1 and not os.environ.get("VLGP_FORCE_RCCL"):
             return
         if self.uid is None:
             from .engine import unique_id
