@@ -25,6 +25,7 @@
 #include "wave_tri.h"
 
 enum { FP_YA = 0, FP_RES = 1, FP_W = 2 };
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // exp(x) for x <= 10 (callers clamp): Cody-Waite reduction by ln 2, degree-13
 // Taylor polynomial on |r| <= ln2/2 (truncation 4e-18), one ldexp.  < 2 ulp.
@@ -78,10 +79,13 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
     double* part = p;    p += (int64_t)nw * Tc * L;
     p += ((p - smem) & 1);  // keep 16-byte alignment for the vector-read regions below
     double* vec_s = p;   p += nw * 128;
+    double* tile_s = p;  p += nw * 256;  // per-wave 16 x 16 MFMA staging tile
     double* Xp = p;      p += (int64_t)L * PK;
     double* G_s = p;     p += A.lds_gsz;
     int* ip = reinterpret_cast<int*>(p);
     int* gflag = ip;     ip += N;
+    int* clist = ip;     ip += N;   // Poisson channels first, then Gaussian ones
+    int* ncnt = ip;      ip += 2;   // [0] = number of Poisson channels
     int* rl_s = ip;      ip += L;
     int* goff_s = ip;    ip += L;
     int* fail_s = ip;    ip += L;
@@ -99,6 +103,14 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
         }
         rec[2 * LT] = A.b[n];
         rec[2 * LT + 1] = g ? 1.0 / A.noise[n] : 1.0;
+    }
+    if (tid == 64 || (nthr <= 64 && tid == 0)) {
+        int np = 0;
+        for (int n = 0; n < N; ++n)
+            if (!A.gauss[n]) clist[np++] = n;
+        ncnt[0] = np;
+        for (int n = 0; n < N; ++n)
+            if (A.gauss[n]) clist[np++] = n;
     }
     if (tid == 0) {
         int go = 0;
@@ -135,24 +147,23 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
     __syncthreads();
 
     // ---- (T x N) passes ----------------------------------------------------------
-    auto tn_pass = [&](auto kind_c) {
+    auto tn_pass_x = [&](auto kind_c, auto hasxb_c) {
         constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool HASXB = decltype(hasxb_c)::value;
         const int t = lane;
         const bool in = t < T;
-        double mr[LT], vr[LT], acc[LT];
+        double mr[LT], vr[LT], accA[LT], accB[LT];
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             const bool use = in && l < L && KIND != FP_YA;
             mr[l] = use ? mu_s[t * L + l] : 0.0;
             vr[l] = use ? v_s[t * L + l] : 0.0;
-            acc[l] = 0.0;
+            accA[l] = 0.0;
+            accB[l] = 0.0;
         }
-        const int n0 = (N * wid) / nw, n1 = (N * (wid + 1)) / nw;
         const double* yrow = A.y + (r0 + (in ? t : 0)) * N;
-        const double* xbrow = A.xb ? A.xb + (r0 + (in ? t : 0)) * N : nullptr;
-#pragma unroll 2
-        for (int n = n0; n < n1; ++n) {  // two channels in flight: their dependent fp64 chains interleave
-            double rv[REC];
+        const double* xbrow = HASXB ? A.xb + (r0 + (in ? t : 0)) * N : nullptr;
+        auto load_rec = [&](int n, double (&rv)[REC]) {
             const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)n * REC);
 #pragma unroll
             for (int q = 0; q < REC / 2; ++q) {
@@ -160,36 +171,62 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
                 rv[2 * q] = t2.x;
                 rv[2 * q + 1] = t2.y;
             }
-            if constexpr (KIND == FP_YA) {
+        };
+        // one Poisson channel: rate = exp(min(eta + v.a^2/2, 10)); branch-free so that two
+        // channels issued back to back interleave their dependent fp64 chains
+        auto poisson_col = [&](int n, double (&acc)[LT]) {
+            double rv[REC];
+            load_rec(n, rv);
+            double eta = HASXB ? xbrow[n] : rv[2 * LT];
+            double lin = 0.0;
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                eta = fma(mr[l], rv[l], eta);
+                lin = fma(vr[l], rv[LT + l], lin);
+            }
+            const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+#pragma unroll
+            for (int l = 0; l < LT; ++l) acc[l] = fma(rate, rv[KIND == FP_RES ? l : LT + l], acc[l]);
+        };
+        const int np = ncnt[0];
+        if constexpr (KIND == FP_YA) {
+            const int n0 = (N * wid) / nw, n1 = (N * (wid + 1)) / nw;
+            for (int n = n0; n < n1; ++n) {
+                double rv[REC];
+                load_rec(n, rv);
                 const double yc = yrow[n] * rv[2 * LT + 1];
 #pragma unroll
-                for (int l = 0; l < LT; ++l) acc[l] = fma(yc, rv[l], acc[l]);
-            } else {
-                double eta = xbrow ? xbrow[n] : rv[2 * LT];
-                double lin = 0.0;
+                for (int l = 0; l < LT; ++l) accA[l] = fma(yc, rv[l], accA[l]);
+            }
+        } else {
+            const int p0 = (np * wid) / nw, p1 = (np * (wid + 1)) / nw;
+            int i = p0;
+            for (; i + 1 < p1; i += 2) {
+                const int na = clist[i], nb = clist[i + 1];
+                poisson_col(na, accA);
+                poisson_col(nb, accB);
+            }
+            if (i < p1) poisson_col(clist[i], accA);
+            if constexpr (KIND == FP_RES) {  // Gaussian channels: residual mean is eta itself, no rate
+                const int ng = N - np;
+                const int g0 = np + (ng * wid) / nw, g1 = np + (ng * (wid + 1)) / nw;
+                for (int q = g0; q < g1; ++q) {
+                    const int n = clist[q];
+                    double rv[REC];
+                    load_rec(n, rv);
+                    double eta = HASXB ? xbrow[n] : rv[2 * LT];
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
-                    eta = fma(mr[l], rv[l], eta);
-                    lin = fma(vr[l], rv[LT + l], lin);
-                }
-                const int g = gflag[n];  // wave-uniform
-                if constexpr (KIND == FP_RES) {
-                    double mval;
-                    if (g) mval = eta * rv[2 * LT + 1];
-                    else mval = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+                    for (int l = 0; l < LT; ++l) eta = fma(mr[l], rv[l], eta);
+                    const double mval = eta * rv[2 * LT + 1];
 #pragma unroll
-                    for (int l = 0; l < LT; ++l) acc[l] = fma(mval, rv[l], acc[l]);
-                } else if (!g) {
-                    const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
-#pragma unroll
-                    for (int l = 0; l < LT; ++l) acc[l] = fma(rate, rv[LT + l], acc[l]);
+                    for (int l = 0; l < LT; ++l) accB[l] = fma(mval, rv[l], accB[l]);
                 }
             }
         }
         if (in) {
 #pragma unroll
             for (int l = 0; l < LT; ++l)
-                if (l < L) part[((int64_t)wid * Tc + t) * L + l] = acc[l];
+                if (l < L) part[((int64_t)wid * Tc + t) * L + l] = accA[l] + accB[l];
         }
         __syncthreads();
         for (int idx = tid; idx < T * L; idx += nthr) {
@@ -201,63 +238,109 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
         }
         __syncthreads();
     };
+    auto tn_pass = [&](auto kind_c) {
+        if (A.xb) tn_pass_x(kind_c, std::true_type{});
+        else tn_pass_x(kind_c, std::false_type{});
+    };
 
     // ---- factor I + G'WG, invert, optionally refresh v -------------------------------
+    unsigned long long tick2 = 0;
+    auto lap2 = [&](int slot) {
+        if (A.clk && tid == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (slot >= 0) atomicAdd(A.clk + slot, now - tick2);
+            tick2 = now;
+        }
+    };
     auto factor_phase = [&](bool do_v) {
         for (int l = wid; l < L; l += nw) {
+            lap2(-1);
             const int r = __builtin_amdgcn_readfirstlane(rl_s[l]);
             const int rs = (r + 1) & ~1;
             const double* Gl = G_s + __builtin_amdgcn_readfirstlane(goff_s[l]);
             double* Xl = Xp + (int64_t)l * PK;
             const int j = lane & (RP - 1), ch = lane / RP;
-            {
+            bool ok;
+            // H = G' diag(w) G on the matrix pipe: v_mfma_f64_16x16x4, four time bins per
+            // instruction.  Lane (col = lane & 15, kq = lane >> 4) feeds A[col][kq] = w_t G[t][col]
+            // and B[kq][col] = G[t][col], t = t0 + kq; D[row = kq + 4p][col] comes back in c[p].
+            const int col = lane & 15, kq = lane >> 4;
+            if constexpr (RP <= 16) {
+                double4_t c = {0.0, 0.0, 0.0, 0.0};
+                const bool cin = col < rs;
+                for (int t0 = 0; t0 < T; t0 += 4) {
+                    const int t = t0 + kq;
+                    double g = 0.0, wg = 0.0;
+                    if (cin && t < T) {
+                        g = Gl[t * rs + col];
+                        wg = w_s[t * L + l] * g;
+                    }
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
+                }
+                double* ht = tile_s + wid * 256;  // 16 x 16 staging tile of this wave
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ht[(kq + 4 * q) * 16 + col] = c[q];
+                tri_wave_sync();
                 double a[RP];
 #pragma unroll
-                for (int i = 0; i < RP; ++i) a[i] = 0.0;
-                if (j < rs) {
-                    for (int t = ch; t < T; t += NCH) {
-                        const double* Gt = Gl + t * rs;
-                        const double gj = w_s[t * L + l] * Gt[j];
-#pragma unroll
-                        for (int i = 0; i < RP; i += 2)
-                            if (i < rs) {
-                                const double2 g2 = *reinterpret_cast<const double2*>(Gt + i);
-                                a[i] = fma(gj, g2.x, a[i]);
-                                a[i + 1] = fma(gj, g2.y, a[i + 1]);
-                            }
-                    }
+                for (int i = 0; i < RP; i += 2) {
+                    const double2 h2 = *reinterpret_cast<const double2*>(ht + j * 16 + i);
+                    a[i] = h2.x + (i == j ? 1.0 : 0.0);
+                    a[i + 1] = h2.y + (i + 1 == j ? 1.0 : 0.0);
                 }
-#pragma unroll
-                for (int o = RP; o < 64; o <<= 1) {
-#pragma unroll
-                    for (int i = 0; i < RP; ++i) a[i] += __shfl_xor(a[i], o, 64);
-                }
-                if (lane < RP) {
-                    const int off = tri_row_off(lane);
-#pragma unroll
-                    for (int i = 0; i < RP; ++i)
-                        if (i <= lane) Xl[off + i] = a[i] + (i == lane ? 1.0 : 0.0);
-                }
-            }
-            tri_wave_sync();
-            __builtin_amdgcn_sched_barrier(0);
-            bool ok;
-            {
-                double rr[RP];
-                ok = wave_chol_rows<RP>(rr, Xl, lane);
-            }
-            {
+                lap2(6);
+                // all in registers: every lane holds row (lane mod RP) of I + G'WG
                 double x[RP];
-                wave_tri_inverse_cols<RP>(Xl, x, lane);
-                tri_wave_sync();
-                if (lane < RP) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+                ok = wave_chol_inv_regs<RP>(a, x, j);
+                if (lane < RP) {  // X row-major packed in LDS for the solves: X[i][c], i >= c
 #pragma unroll
                     for (int i = 0; i < RP; ++i)
                         if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
                 }
+            } else {
+#pragma unroll
+                for (int tile = 0; tile < 3; ++tile) {  // lower block triangle of the 32 x 32 matrix
+                    const int bi = tile == 0 ? 0 : 1, bj = tile == 2 ? 1 : 0;
+                    const int ca = 16 * bi + col, cb = 16 * bj + col;
+                    double4_t c = {0.0, 0.0, 0.0, 0.0};
+                    for (int t0 = 0; t0 < T; t0 += 4) {
+                        const int t = t0 + kq;
+                        double ga = 0.0, gb = 0.0;
+                        if (t < T) {
+                            if (ca < rs) ga = w_s[t * L + l] * Gl[t * rs + ca];
+                            if (cb < rs) gb = Gl[t * rs + cb];
+                        }
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, gb, c, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 16 * bi + kq + 4 * q;
+                        if (cb <= row) Xl[tri_row_off(row) + cb] = c[q] + (cb == row ? 1.0 : 0.0);
+                    }
+                }
+                lap2(6);
+            }
+            if constexpr (RP > 16) {
+                tri_wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    double rr[RP];
+                    ok = wave_chol_rows<RP>(rr, Xl, lane);
+                }
+                {
+                    double x[RP];
+                    wave_tri_inverse_cols<RP>(Xl, x, lane);
+                    tri_wave_sync();
+                    if (lane < RP) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+#pragma unroll
+                        for (int i = 0; i < RP; ++i)
+                            if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
+                    }
+                }
             }
             tri_wave_sync();
             __builtin_amdgcn_sched_barrier(0);
+            lap2(7);
             if (do_v && ok && lane < T) {
                 const double* Gt = Gl + lane * rs;
                 double gt[RP];
@@ -312,8 +395,10 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
             const int j = lane & (RP - 1), ch = lane / RP;
             // g1 = G' (res a_l)
             double acc = 0.0;
-            if (j < rs)
+            if (j < rs) {
+#pragma unroll 4
                 for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * rs + j], ra_s[t * L + l], acc);
+            }
 #pragma unroll
             for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
             if (lane < RP) vec[lane] = acc;
@@ -344,8 +429,10 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(Est
             tri_wave_sync();
             // rhs = (W G)' u
             acc = 0.0;
-            if (j < rs)
+            if (j < rs) {
+#pragma unroll 4
                 for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * rs + j], u[t], acc);
+            }
 #pragma unroll
             for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
             if (lane < RP) vec2[lane] = acc;
@@ -486,8 +573,8 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     const int nw = L < 4 ? 4 : L;  // L <= 8
     const int Tc = us.Tmax;
     const int64_t PK = RP == 16 ? tri_packed_size(16) : tri_packed_size(32);
-    int64_t d = (int64_t)N * (2 * LT + 2) + ((L + 1) & ~1) + 6LL * Tc * L + (int64_t)nw * Tc * L + 1 + nw * 128 +
-                L * PK + gsz + (N + 3 * L + 1) / 2 + 2;
+    int64_t d = (int64_t)N * (2 * LT + 2) + ((L + 1) & ~1) + 6LL * Tc * L + (int64_t)nw * Tc * L + 1 + nw * 384 +
+                L * PK + gsz + (2 * N + 3 * L + 3) / 2 + 2;
     if (d * 8 > 160 * 1024) return VLGP_OK;
     A.lds_gsz = (int)gsz;
     A.lds_T = Tc;

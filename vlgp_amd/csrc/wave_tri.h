@@ -99,6 +99,60 @@ __device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (
     }
 }
 
+// 1 / sqrt(d) and sqrt(d) for d > 0 from v_rsq_f64 + two Newton steps (about a
+// third of the dependent-instruction depth of sqrt() followed by a division).
+__device__ __forceinline__ void tri_rsqrt(double d, double* inv_out, double* sd_out) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-d * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    double sd = d * y;
+    sd = fma(fma(-sd, sd, d), 0.5 * y, sd);
+    *inv_out = y;
+    *sd_out = sd;
+}
+
+// Register-only Cholesky + triangular inverse for small matrices (RP <= 16):
+// lane j (and every lane congruent to j mod RP) holds the full symmetric row j in
+// a[0..RP-1]; pivot-row entries are fetched with v_readlane (static lane), so there
+// is no LDS traffic and no wave-level synchronisation at all.  Out: x[i] =
+// (L^-1)[i][j], the column j of X.  Returns false on a non-positive pivot.
+template <int RP>
+__device__ __forceinline__ bool wave_chol_inv_regs(double (&a)[RP], double (&x)[RP], int j) {
+    double invd[RP];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < RP; ++k) {
+        double s0 = a[k], s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+            const double lki = tri_readlane(a[i], k);  // L[k][i]
+            if (i & 1) s1 = fma(-a[i], lki, s1);
+            else s0 = fma(-a[i], lki, s0);
+        }
+        const double s = s0 + s1;
+        const double d = tri_readlane(s, k);
+        if (!(d > 0.0) || !(d < 1e300)) ok = false;
+        double inv, sd;
+        tri_rsqrt(d, &inv, &sd);
+        invd[k] = inv;
+        a[k] = (j == k) ? sd : s * inv;  // L[j][k] for j > k (garbage above the diagonal)
+    }
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < i; ++q) {
+            const double liq = tri_readlane(a[q], i);  // L[i][q]
+            if (q & 1) c1 = fma(liq, x[q], c1);
+            else c0 = fma(liq, x[q], c0);
+        }
+        x[i] = ((j == i ? 1.0 : 0.0) - (c0 + c1)) * invd[i];
+    }
+    return ok;
+}
+
 // Upper-packed storage of X' (row c = column c of X, entries k = c..T-1, padded
 // to an even count): offset of row c.
 __host__ __device__ constexpr int triu_row_off(int c, int T) {
