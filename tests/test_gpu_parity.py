@@ -442,3 +442,53 @@ def test_single_rank_rccl_allreduce_is_identity(V, golden, monkeypatch):
         n_mu, _ = eng.norms(0)
     assert relerr(a, g["a_H_25"]) < STAGE and relerr(b, g["b_H_25"]) < STAGE and relerr(noise, g["noise_H_25"]) < STAGE
     assert abs(n_mu - np.linalg.norm(g["mu"])) < 1e-12 * n_mu
+
+
+# ------------------------------------------------------------------ C5-like: ragged trials, mixed likelihood, ten latents
+def test_c5_like_ragged_mixed_ten_latents(V):
+    """BASELINE.json configs[4] in miniature: unequal trial lengths (multiples of the window), Poisson +
+    Gaussian channels, ten latents.  Exercises the generic E-step kernels (L > 8), long units whose ten
+    rank-50 factors do not fit LDS, the mixed-likelihood M-step and a ten-latent H-step, against the oracle
+    run on the same inputs with the same (host-made) prior factors."""
+    from vlgp_amd import synth
+
+    lengths = [250, 400, 300, 350]
+    L, N, n_gauss = 10, 24, 6
+    trials = synth.make_trials(len(lengths), max(lengths), N, L, seed=4, n_gauss=n_gauss, lengths=lengths)
+    rng = np.random.default_rng(8)
+    a0 = 0.3 * rng.standard_normal((L, N))
+    ycat = np.concatenate([t["y"] for t in trials])
+    b0 = np.zeros((1, N))
+    b0[0, :N - n_gauss] = np.log(np.maximum(ycat[:, :N - n_gauss].mean(0), 1e-8))
+    lik = ["poisson"] * (N - n_gauss) + ["gaussian"] * n_gauss
+    mu0 = [0.2 * rng.standard_normal((T, L)) for T in lengths]
+
+    def fresh():
+        return [{"ID": i, "y": t["y"].copy(), "mu": m.copy()} for i, (t, m) in enumerate(zip(trials, mu0))]
+
+    kw = dict(a=a0.copy(), b=b0.copy(), lik=lik, max_iter=3, min_iter=3, Eniter=5, Mniter=5)
+    got = V.fit(fresh(), L, ichol="host", verbose=False, **kw)
+
+    ref_trials = fresh()
+    for t in ref_trials:
+        T = t["y"].shape[0]
+        t["x"] = np.ones((T, 1, N))
+        t["w"] = np.zeros((T, L))
+        t["v"] = np.zeros((T, L))
+    cfg = O.make_config(max_iter=3, min_iter=3, Eniter=5, Mniter=5)
+    params = O.make_params(ref_trials, L, a=a0.copy(), b=b0.copy(), lik=lik)
+    O.fit_given_init(ref_trials, params, cfg)
+
+    assert relerr(got["params"]["omega"], params["omega"]) < 1e-5
+    assert relerr(got["params"]["a"], params["a"]) < 1e-5
+    assert relerr(got["params"]["b"], params["b"]) < 1e-5
+    assert relerr(got["params"]["noise"], params["noise"]) < 1e-5
+    # full-length posterior: only comparable where the factor has identical pivots; omega differs at
+    # ~1e-9 after three H-steps, which can flip pivots of a rank-exhausted factor (DESIGN.md section 6),
+    # so compare the trials whose factors did agree
+    for tg, tr in zip(got["trials"], ref_trials):
+        T = tr["y"].shape[0]
+        Gg, Gr = got["params"]["cholesky"][T], params["cholesky"][T]
+        if relerr(np.einsum("ltr,lsr->lts", Gg, Gg), np.einsum("ltr,lsr->lts", Gr, Gr)) < 1e-9:
+            assert relerr(tg["mu"], tr["mu"]) < 1e-4, T
+            assert relerr(tg["v"], tr["v"]) < 1e-4, T

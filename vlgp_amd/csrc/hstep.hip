@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
     constexpr int PK = tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
     constexpr int NW = 4;
     __shared__ __attribute__((aligned(16))) double Lp_all[NW][PK];
-    __shared__ double vec_all[NW][3][64];
+    __shared__ double vec_all[NW][4][64];
     __shared__ double kv[64], dkv[64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int e = blockIdx.y;
@@ -355,6 +355,7 @@ __global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
     double* sw = vec_all[wid][0];
     double* muv = vec_all[wid][1];
     double* alv = vec_all[wid][2];
+    double* invd = vec_all[wid][3];
     const int l = A.latent[e];
     const int64_t r0 = A.off[seg];
     const double* Ki = A.kinv + (int64_t)e * T * T;
@@ -396,11 +397,11 @@ __global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
     tri_wave_sync();
     __builtin_amdgcn_sched_barrier(0);
     double r[T];
-    const bool ok = wave_chol_rows<T>(r, Lp, lane);
+    const bool ok = wave_chol_rows<T>(r, Lp, lane, invd);
     double tr = 0.0, cacc = 0.0;
     if (ok) {
         double x[T];
-        wave_tri_inverse_cols<T>(Lp, x, lane);
+        wave_tri_inverse_cols<T>(Lp, x, lane, invd);
 #pragma unroll
         for (int k = 0; k < T; ++k) tr = fma(x[k], x[k], tr);
         tri_wave_sync();

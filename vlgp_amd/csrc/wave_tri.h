@@ -34,12 +34,26 @@ __device__ __forceinline__ double tri_readlane(double x, int src_lane) {
     return o.d;
 }
 
+// 1 / sqrt(d) and sqrt(d) for d > 0 from v_rsq_f64 + two Newton steps (about a
+// third of the dependent-instruction depth of sqrt() followed by a division).
+__device__ __forceinline__ void tri_rsqrt(double d, double* inv_out, double* sd_out) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-d * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    double sd = d * y;
+    sd = fma(fma(-sd, sd, d), 0.5 * y, sd);
+    *inv_out = y;
+    *sd_out = sd;
+}
+
 // In: Lp (LDS, packed lower) holds A: row `lane` at tri_row_off(lane).  Out: Lp
 // holds chol(A) in place; r[i] = L[lane][i] for i < lane.  Returns false on a
 // non-positive pivot.
 // Lanes >= T compute garbage, write nothing.
 template <int T>
-__device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int lane) {
+__device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int lane, double* invd = nullptr) {
     const int my_off = tri_row_off(lane < T ? lane : 0);
     bool ok = true;
 #pragma unroll
@@ -56,10 +70,11 @@ __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int l
         const double s = s0 + s1;
         const double d = tri_readlane(s, k);
         if (!(d > 0.0) || !(d < 1e300)) ok = false;  // later columns are garbage; caller discards
-        const double sd = sqrt(d);
-        const double inv = 1.0 / sd;  // one reciprocal per column instead of a division per lane
+        double inv, sd;
+        tri_rsqrt(d, &inv, &sd);  // one reciprocal root per column instead of sqrt + a division per lane
         r[k] = (lane == k) ? sd : s * inv;
         if (lane >= k && lane < T) Lp[my_off + k] = r[k];
+        if (invd && lane == k) invd[k] = inv;  // reciprocal diagonal for the inverse
         tri_wave_sync();
         __builtin_amdgcn_sched_barrier(0);  // one scheduling region per column: bounded live ranges
     }
@@ -77,7 +92,8 @@ __device__ __forceinline__ double wave_tri_logdet(const double* Lp, int lane) {
 // In: Lp = packed lower-triangular L.  Out: x[i] = (L^-1)[i][lane], i.e. lane c holds COLUMN c of X = L^-1 (zeros
 // above the diagonal).
 template <int T>
-__device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (&x)[T], int lane) {
+__device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (&x)[T], int lane,
+                                                      const double* invd = nullptr) {
 #pragma unroll
     for (int i = 0; i < T; ++i) {
         const double* Li = Lp + tri_row_off(i);
@@ -93,24 +109,11 @@ __device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (
         // with the cheap form hipcc (ROCm 7.2) hoists far more of the unrolled
         // rows' address/mask setup and spills ~230 VGPRs (measured 3x slower).
         const double rhs = (lane == i) ? 1.0 : 0.0;
-        x[i] = (rhs - (a0 + a1)) / Li[i];
+        if (invd) x[i] = (rhs - (a0 + a1)) * invd[i];
+        else x[i] = (rhs - (a0 + a1)) / Li[i];
         // keep the scheduler from hoisting later rows' LDS loads (register pressure)
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-
-// 1 / sqrt(d) and sqrt(d) for d > 0 from v_rsq_f64 + two Newton steps (about a
-// third of the dependent-instruction depth of sqrt() followed by a division).
-__device__ __forceinline__ void tri_rsqrt(double d, double* inv_out, double* sd_out) {
-    double y = __builtin_amdgcn_rsq(d);
-    double e = fma(-d * y, y, 1.0);
-    y = fma(y * 0.5, e, y);
-    e = fma(-d * y, y, 1.0);
-    y = fma(y * 0.5, e, y);
-    double sd = d * y;
-    sd = fma(fma(-sd, sd, d), 0.5 * y, sd);
-    *inv_out = y;
-    *sd_out = sd;
 }
 
 // Register-only Cholesky + triangular inverse for small matrices (RP <= 16):
