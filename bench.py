@@ -53,16 +53,30 @@ def build_inputs(name):
     return trials, params["a"], params["b"], (n_trials, n_bins, N, L)
 
 
-def algorithmic_work(n_seg, T, N, L, P, r, e_iter):
-    """SURVEY.md section 8(d) minimal-algorithm counts (nominal r = 50)."""
-    e_flops = e_iter * n_seg * (12.0 * T * L * N + L * (5.0 * T * r * r + 2.0 / 3.0 * r ** 3 + 8.0 * T * r))
-    rows = n_seg * T
-    m_flops = rows * (4.0 * L * N + N * (2.0 * L * L + 9.0 * L + 4.0 * P * P))
-    m_bytes = 8.0 * rows * (N * (1 + P) + 2 * L)
-    h_flops = n_seg * (T ** 3 + 4.0 * T * T)
-    h_bytes = 16.0 * n_seg * T
-    return {"estep_flops": e_flops, "mstep_flops": m_flops, "mstep_bytes": m_bytes,
-            "hstep_flops_per_eval": h_flops, "hstep_bytes_per_eval": h_bytes}
+def algorithmic_work(T, N, L, P, r):
+    """SURVEY.md section 8(d) minimal-algorithm counts (nominal r = 50), per work unit."""
+    return {
+        # one unit (segment) x one inner sweep of the E-step
+        "estep_flops_per_unit_sweep": 12.0 * T * L * N + L * (5.0 * T * r * r + 2.0 / 3.0 * r ** 3 + 8.0 * T * r),
+        # one row of one Newton iteration of the M-step
+        "mstep_flops_per_row": 4.0 * L * N + N * (2.0 * L * L + 9.0 * L + 4.0 * P * P),
+        "mstep_bytes_per_row": 8.0 * (N * (1 + P) + 2 * L),
+        # one segment of one H-step objective evaluation
+        "hstep_flops_per_seg_eval": T ** 3 + 4.0 * T * T,
+        "hstep_bytes_per_seg_eval": 16.0 * T,
+    }
+
+
+def pmc_traffic(kernel_key):
+    """Per-launch HBM bytes of a kernel from the committed rocprofv3 --pmc passes
+    (profiles/r1/pmc_summary.json: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM,
+    plus WRITE_SIZE; separate passes).  None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(name, budget_trials):
@@ -117,7 +131,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trials", type=int, default=4)
+    ap.add_argument("--cpu-trials", type=int, default=12)
     args = ap.parse_args()
 
     import vlgp_amd
@@ -170,33 +184,38 @@ def main():
     if rank != 0:
         return
 
-    work = algorithmic_work(n_seg_local, cfg["window"], N, L, 1, 50, cfg["Eniter"])
+    work = algorithmic_work(cfg["window"], N, L, 1, 50)
     kernels = {}
-    n_e, ms_e = prof["estep"]
+    n_e, ms_e, u_e = prof["estep"]
     if n_e:
-        kernels["estep_kernel"] = {"launches": n_e, "avg_ms": ms_e / n_e, "total_ms": ms_e,
-                                   "achieved": work["estep_flops"] / (ms_e / n_e * 1e-3) / 1e12,
-                                   "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma"}
-    n_m, ms_m = prof["mstep"]
+        flops = work["estep_flops_per_unit_sweep"] * u_e / n_e
+        kernels["estep_fast_kernel"] = {"launches": n_e, "avg_ms": ms_e / n_e, "total_ms": ms_e,
+                                        "units_per_launch": u_e / n_e, "unit": "TFLOP/s", "bound": "mfma",
+                                        "achieved": flops / (ms_e / n_e * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                        "pmc_key": "estep_fast_kernel<5, 16>"}
+    n_m, ms_m, u_m = prof["mstep"]
     if n_m:
+        nbytes = work["mstep_bytes_per_row"] * u_m / n_m
         kernels["mstep_accum<NEWTON>"] = {"launches": n_m, "avg_ms": ms_m / n_m, "total_ms": ms_m,
-                                          "achieved": work["mstep_bytes"] / (ms_m / n_m * 1e-3) / 1e9,
-                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm"}
-    n_h, ms_h = prof["hstep"]
+                                          "units_per_launch": u_m / n_m, "unit": "GB/s", "bound": "hbm",
+                                          "achieved": nbytes / (ms_m / n_m * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                          "pmc_key": "mstep_accum<5, 1, 1>"}
+    n_h, ms_h, u_h = prof["hstep"]
     if n_h:
-        # one launch evaluates up to L latents; count the average evaluations per launch
-        evals = L  # lock-step batches hold one evaluation per still-running latent
-        kernels["hstep_seg_kernel"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
-                                       "achieved": work["hstep_flops_per_eval"] * evals / (ms_h / n_h * 1e-3) / 1e12,
-                                       "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
-                                       "note": "upper bound: assumes %d evaluations per launch" % evals}
+        flops = work["hstep_flops_per_seg_eval"] * u_h / n_h
+        kernels["hstep_seg_fast"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
+                                     "units_per_launch": u_h / n_h, "unit": "TFLOP/s", "bound": "mfma",
+                                     "achieved": flops / (ms_h / n_h * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                     "pmc_key": "hstep_seg_fast<50>"}
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     roofline = None
     if dominant:
         kd = kernels[dominant]
         roofline = {"kernel": dominant, "bound": kd["bound"], "achieved": kd["achieved"], "peak": kd["peak"],
-                    "unit": kd["unit"], "frac": kd["achieved"] / kd["peak"], "traffic": None,
-                    "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"]}
+                    "unit": kd["unit"], "frac": kd["achieved"] / kd["peak"],
+                    "traffic": pmc_traffic(kd["pmc_key"]),
+                    "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"],
+                    "units_per_launch": kd["units_per_launch"]}
 
     out = {
         "metric": "EM iterations/sec", "value": args.steps / elapsed, "unit": "EM it/s",

@@ -168,8 +168,10 @@ int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n);
 #define VLGP_PROF_KINDS 4
 int vlgp_profile_enable(vlgp_ctx* ctx, int on);
 int vlgp_profile_reset(vlgp_ctx* ctx);
-/* launches and total milliseconds recorded for `kind` since the last reset. */
-int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms);
+/* launches, total milliseconds and work units recorded for `kind` since the last
+ * reset.  Units: E-step = unit-sweeps (units x inner iterations), M-step = rows
+ * streamed, H-step = segment-evaluations, prior = factors built. */
+int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms, double* units);
 /* E-step phase anatomy: when enabled, thread 0 of every workgroup adds its
  * shader-clock cycles per phase into 8 counters (0 staging, 1 y.a pass + first
  * factor, 2 residual pass, 3 mean update, 4 curvature pass, 5 factor + variance).

@@ -61,7 +61,7 @@ _SIGNATURES = {
     "vlgp_comm_allreduce_host": (C.c_int, [_h, _dp, C.c_int]),
     "vlgp_profile_enable": (C.c_int, [_h, C.c_int]),
     "vlgp_profile_reset": (C.c_int, [_h]),
-    "vlgp_profile_get": (C.c_int, [_h, C.c_int, _i64p, _dp]),
+    "vlgp_profile_get": (C.c_int, [_h, C.c_int, _i64p, _dp, _dp]),
     "vlgp_debug_phase_clock": (C.c_int, [_h, C.c_int, C.POINTER(C.c_uint64)]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -78,25 +78,27 @@ void vlgp_prof_begin(vlgp_ctx* ctx, int kind) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     (void)hipEventRecord(a, ctx->stream);
-    ctx->pending.push_back({kind, {a, b}});
+    ctx->pending.push_back({kind, a, b, 0.0});
 }
-void vlgp_prof_end(vlgp_ctx* ctx, int kind) {
+void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units) {
     if (!ctx->prof_on || ctx->pending.empty()) return;
     auto& p = ctx->pending.back();
-    if (p.first != kind) return;
-    (void)hipEventRecord(p.second.second, ctx->stream);
+    if (p.kind != kind) return;
+    p.units = units;
+    (void)hipEventRecord(p.b, ctx->stream);
 }
 static void prof_drain(vlgp_ctx* ctx) {
     if (ctx->pending.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
-            ctx->prof[p.first].launches += 1;
-            ctx->prof[p.first].ms += ms;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof[p.kind].launches += 1;
+            ctx->prof[p.kind].ms += ms;
+            ctx->prof[p.kind].units += p.units;
         }
-        (void)hipEventDestroy(p.second.first);
-        (void)hipEventDestroy(p.second.second);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
     }
     ctx->pending.clear();
 }
@@ -771,11 +773,12 @@ extern "C" int vlgp_profile_reset(vlgp_ctx* ctx) {
     for (auto& p : ctx->prof) p = ProfSlot();
     return VLGP_OK;
 }
-extern "C" int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
+extern "C" int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_ms, double* units) {
     NEED_CTX(ctx);
     if (kind < 0 || kind >= VLGP_PROF_KINDS) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad profile kind %d", kind);
     prof_drain(ctx);
     if (launches) *launches = ctx->prof[kind].launches;
     if (total_ms) *total_ms = ctx->prof[kind].ms;
+    if (units) *units = ctx->prof[kind].units;
     return VLGP_OK;
 }

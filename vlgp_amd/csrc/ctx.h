@@ -45,6 +45,7 @@ struct UnitSet {
 struct ProfSlot {
     int64_t launches = 0;
     double ms = 0.0;
+    double units = 0.0;  // work units covered by the timed launches (kernel specific)
 };
 
 struct vlgp_ctx {
@@ -78,7 +79,8 @@ struct vlgp_ctx {
     bool prof_on = false;
     ProfSlot prof[VLGP_PROF_KINDS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    struct PendingProf { int kind; hipEvent_t a, b; double units; };
+    std::vector<PendingProf> pending;
 
     // RCCL
     void* comm = nullptr;         // ncclComm_t
@@ -111,7 +113,7 @@ UnitSet* vlgp_get_set(vlgp_ctx* ctx, int set, bool must_be_valid);
 
 // profiling brackets (HIP events on ctx->stream)
 void vlgp_prof_begin(vlgp_ctx* ctx, int kind);
-void vlgp_prof_end(vlgp_ctx* ctx, int kind);
+void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units = 0.0);
 
 // ---- kernel launchers (one per translation unit) -------------------------
 // mode bits for the E-step kernel

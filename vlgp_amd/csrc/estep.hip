@@ -467,7 +467,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
         A.rg = pick_rg(us.Tmax, N, nthr);
         vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
         int rc = launch_l<true>(ctx, A, us.M, nthr, (size_t)small_d * 8);
-        vlgp_prof_end(ctx, VLGP_PROF_ESTEP);
+        vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
         return rc;
     }
 
@@ -493,6 +493,6 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.rg = 64;
     vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
     int rc = launch_l<false>(ctx, A, us.M, nthr, (size_t)long_d * 8);
-    vlgp_prof_end(ctx, VLGP_PROF_ESTEP);
+    vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
     return rc;
 }

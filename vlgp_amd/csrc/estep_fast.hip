@@ -52,7 +52,7 @@ __device__ __forceinline__ double fast_exp(double x) {
 }
 
 template <int LT, int RP>
-__global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 2)) estep_fast_kernel(EstepArgs A) {
+__global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(EstepArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int REC = 2 * LT + 2;          // a[LT], a^2[LT], b, c  (even -> 16-byte records)
     constexpr int PK = tri_packed_size(RP);  // packed lower-triangular RP x RP
@@ -535,7 +535,7 @@ static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, siz
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
     hipLaunchKernelGGL(fn, dim3(M), dim3(nthr), lds, ctx->stream, A);
-    vlgp_prof_end(ctx, VLGP_PROF_ESTEP);
+    vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)M * (A.n_iter > 0 ? A.n_iter : 1));
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }

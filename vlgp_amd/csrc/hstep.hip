@@ -447,7 +447,7 @@ static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
     HIPCHK(ctx, hipGetLastError());
     vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
     hipLaunchKernelGGL((hstep_seg_fast<T>), dim3((M + 3) / 4, n_eval), dim3(256), 0, ctx->stream, F);
-    vlgp_prof_end(ctx, VLGP_PROF_HSTEP);
+    vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }
@@ -522,7 +522,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     const size_t lds_seg = (size_t)nw * (T * (T | 1) + 2 * HS_MAXT) * 8;
     vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
     hipLaunchKernelGGL(hstep_seg_kernel, dim3((M + nw - 1) / nw, n_eval), dim3(64 * nw), lds_seg, ctx->stream, S);
-    vlgp_prof_end(ctx, VLGP_PROF_HSTEP);
+    vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red);
     HIPCHK(ctx, hipGetLastError());

@@ -622,7 +622,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
         if (any_poisson) {
             vlgp_prof_begin(ctx, VLGP_PROF_MSTEP);
             int rc = launch_accum(ctx, K_NEWTON, g, A);
-            vlgp_prof_end(ctx, VLGP_PROF_MSTEP);
+            vlgp_prof_end(ctx, VLGP_PROF_MSTEP, (double)us.rows);
             CHK(rc);
             CHK(reduce_to(Kn, d_stats));
         }

@@ -158,7 +158,7 @@ int launch_ichol(vlgp_ctx* ctx, Prior& pr, const double* d_omega, const double* 
     vlgp_prof_begin(ctx, VLGP_PROF_PRIOR);
     hipLaunchKernelGGL(ichol_kernel, dim3(L), dim3(ICH_THREADS), 0, ctx->stream, T, R, d_omega,
                        d_sigma, work, piv, pr.d_full, rank);
-    vlgp_prof_end(ctx, VLGP_PROF_PRIOR);
+    vlgp_prof_end(ctx, VLGP_PROF_PRIOR, (double)L);
     HIPCHK(ctx, hipGetLastError());
     return launch_compact_prior(ctx, pr);
 }

@@ -249,9 +249,9 @@ class Engine:
         return [int(v) for v in out]
 
     def profile_get(self, kind):
-        n, ms = C.c_int64(0), C.c_double(0)
-        self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms)))
-        return n.value, ms.value
+        n, ms, units = C.c_int64(0), C.c_double(0), C.c_double(0)
+        self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms), C.byref(units)))
+        return n.value, ms.value, units.value
 
 
 def unique_id():
