@@ -125,6 +125,16 @@ int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb,
 int vlgp_mstep(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps,
                double learning_rate, double da_bound, double db_bound, int* n_failed);
 
+/* Asynchronous form: vlgp_mstep_begin enqueues the whole M-step on the handle's
+ * second stream (after everything already queued) and returns; the H-step
+ * objective, vlgp_build_prior, vlgp_norms may run meanwhile (they touch neither a, b
+ * nor the rows the M-step reads for writing).  vlgp_mstep_end waits, reports the
+ * failure count and the device time in ms.  Every other entry point that reads or
+ * writes parameters or unit state joins a pending M-step first. */
+int vlgp_mstep_begin(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps,
+                     double learning_rate, double da_bound, double db_bound);
+int vlgp_mstep_end(vlgp_ctx* ctx, int* n_failed, double* device_ms);
+
 /* ---- H-step ----------------------------------------------------------- */
 /* The objective scipy's L-BFGS-B minimises in gp.optimze1d (vlgp/gp.py:100-123):
  * construct_posterior_cov (gp.py:126-147) + elbo (gp.py:12-43), mask [0,1,0].
@@ -152,6 +162,10 @@ int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double* sum2, doub
 /* Rank 0 makes the id, every rank passes the same id to vlgp_comm_init. */
 int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]);
 int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES], int rank, int world);
+/* Second communicator (its own unique id) for the M-step lane, so that its
+ * all-reduces may overlap the H-step's; without it a multi-rank M-step runs
+ * its collectives un-overlapped on the first communicator's stream order. */
+int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]);
 /* In-place sum over ranks of n host doubles (staged through the device, on the
  * handle's stream, synchronous).  With no communicator attached it is a no-op.
  * n == 0 is a pure barrier. */

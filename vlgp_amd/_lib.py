@@ -52,12 +52,16 @@ _SIGNATURES = {
     "vlgp_estep": (C.c_int, [_h, C.c_int, C.c_int, C.c_double, C.c_int, _ip]),
     "vlgp_mstep": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                              C.c_double, _ip]),
+    "vlgp_mstep_begin": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_double]),
+    "vlgp_mstep_end": (C.c_int, [_h, _ip, _dp]),
     "vlgp_hstep_objective": (C.c_int, [_h, C.c_int, C.c_int, C.c_double, C.c_int, _ip, _dp, _dp, _dp]),
     "vlgp_apply_latent_map": (C.c_int, [_h, C.c_int, _dp, _dp]),
     "vlgp_norms": (C.c_int, [_h, C.c_int, _dp]),
     "vlgp_latent_moments": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "vlgp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "vlgp_comm_init": (C.c_int, [_h, C.c_char_p, C.c_int, C.c_int]),
+    "vlgp_comm_init_aux": (C.c_int, [_h, C.c_char_p]),
     "vlgp_comm_allreduce_host": (C.c_int, [_h, _dp, C.c_int]),
     "vlgp_profile_enable": (C.c_int, [_h, C.c_int]),
     "vlgp_profile_reset": (C.c_int, [_h]),

@@ -47,6 +47,24 @@ int vlgp_ensure_work(vlgp_ctx* ctx, int64_t n) {
     return VLGP_OK;
 }
 
+int vlgp_ensure_work_m(vlgp_ctx* ctx, int64_t n) {
+    if (n <= ctx->work_m_len) return VLGP_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->mstream));
+    if (ctx->d_work_m) HIPCHK(ctx, hipFree(ctx->d_work_m));
+    ctx->d_work_m = nullptr;
+    ctx->work_m_len = 0;
+    const int64_t cap = n + n / 4 + 1024;
+    HIPCHK(ctx, hipMalloc(&ctx->d_work_m, (size_t)cap * sizeof(double)));
+    ctx->work_m_len = cap;
+    return VLGP_OK;
+}
+
+int vlgp_join_m(vlgp_ctx* ctx) {
+    if (!ctx->m_pending) return VLGP_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_m_done));  // m_pending is cleared by vlgp_mstep_end
+    return VLGP_OK;
+}
+
 int vlgp_ensure_pinned(vlgp_ctx* ctx, int64_t n) {
     if (n <= ctx->pinned_len) return VLGP_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -73,23 +91,24 @@ UnitSet* vlgp_get_set(vlgp_ctx* ctx, int set, bool must_be_valid) {
 }
 
 // ---- profiling -----------------------------------------------------------
-void vlgp_prof_begin(vlgp_ctx* ctx, int kind) {
+void vlgp_prof_begin(vlgp_ctx* ctx, int kind, hipStream_t st) {
     if (!ctx->prof_on) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, st ? st : ctx->stream);
     ctx->pending.push_back({kind, a, b, 0.0});
 }
-void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units) {
+void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units, hipStream_t st) {
     if (!ctx->prof_on || ctx->pending.empty()) return;
     auto& p = ctx->pending.back();
     if (p.kind != kind) return;
     p.units = units;
-    (void)hipEventRecord(p.b, ctx->stream);
+    (void)hipEventRecord(p.b, st ? st : ctx->stream);
 }
 static void prof_drain(vlgp_ctx* ctx) {
     if (ctx->pending.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->mstream);
     for (auto& p : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -144,6 +163,18 @@ int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n) {
     return VLGP_OK;
 }
 
+int vlgp_allreduce_m(vlgp_ctx* ctx, double* d_buf, int64_t n) {
+    if (!ctx->comm_m) {
+        if (ctx->comm)
+            return vlgp_fail(ctx, VLGP_ERR_STATE, "multi-rank M-step needs the second communicator (vlgp_comm_init_aux)");
+        return VLGP_OK;
+    }
+    const int rc = g_rccl.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm_m, ctx->mstream);
+    if (rc != 0)
+        return vlgp_fail(ctx, VLGP_ERR_COMM, "ncclAllReduce (M-step lane) failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]) {
     CHK(rccl_load(nullptr));
     rccl_uid u;
@@ -168,6 +199,19 @@ extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]
     const int rc = g_rccl.init_rank(&ctx->comm, world, u, rank);
     if (rc != 0)
         return vlgp_fail(ctx, VLGP_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]) {
+    NEED_CTX(ctx);
+    if (ctx->world == 1 && !getenv("VLGP_FORCE_RCCL")) return VLGP_OK;
+    if (!ctx->comm) return vlgp_fail(ctx, VLGP_ERR_STATE, "vlgp_comm_init must precede vlgp_comm_init_aux");
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    rccl_uid u;
+    memcpy(u.internal, id, VLGP_UNIQUE_ID_BYTES);
+    const int rc = g_rccl.init_rank(&ctx->comm_m, ctx->world, u, ctx->rank);
+    if (rc != 0)
+        return vlgp_fail(ctx, VLGP_ERR_COMM, "ncclCommInitRank (aux) failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
     return VLGP_OK;
 }
 
@@ -244,7 +288,18 @@ extern "C" int vlgp_create(int device, int N, int L, int P, int R, const uint8_t
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {   // the main stream carries the latency-critical H-step rounds: give it the highest
+        // priority, the M-step lane the lowest, so that M kernels only fill what H leaves idle
+        int prio_lo = 0, prio_hi = 0;
+        CREATE_CHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        CREATE_CHK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi));
+        CREATE_CHK(hipStreamCreateWithPriority(&ctx->mstream, hipStreamNonBlocking, prio_lo));
+    }
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreate(&ctx->ev_m_start));
+    CREATE_CHK(hipEventCreate(&ctx->ev_m_done));
+    CREATE_CHK(hipMalloc(&ctx->d_fail_m, sizeof(int)));
+    CREATE_CHK(hipMemset(ctx->d_fail_m, 0, sizeof(int)));
     ctx->gauss.assign(N, 0);
     std::vector<int> gi(N, 0);
     for (int n = 0; n < N; ++n) {
@@ -281,7 +336,10 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     if (!ctx) return VLGP_OK;
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->mstream) (void)hipStreamSynchronize(ctx->mstream);
+    ctx->m_pending = false;
     prof_drain(ctx);
+    if (ctx->comm_m && g_rccl.destroy) g_rccl.destroy(ctx->comm_m);
     if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
     // aliased sets first, then owners
     for (int pass = 0; pass < 2; ++pass)
@@ -290,7 +348,11 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     free_priors(ctx);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(ctx->d_gauss); fr(ctx->d_a); fr(ctx->d_b); fr(ctx->d_noise); fr(ctx->d_da); fr(ctx->d_db);
-    fr(ctx->d_fail); fr(ctx->d_clk); fr(ctx->d_work); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
+    fr(ctx->d_fail); fr(ctx->d_fail_m); fr(ctx->d_work_m); fr(ctx->d_clk); fr(ctx->d_work);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_m_start) (void)hipEventDestroy(ctx->ev_m_start);
+    if (ctx->ev_m_done) (void)hipEventDestroy(ctx->ev_m_done);
+    if (ctx->mstream) (void)hipStreamDestroy(ctx->mstream); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -299,6 +361,7 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
 
 extern "C" int vlgp_synchronize(vlgp_ctx* ctx) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return VLGP_OK;
 }
@@ -332,6 +395,7 @@ static int up(vlgp_ctx* ctx, double** dst, const double* src, int64_t n) {
 extern "C" int vlgp_upload_units(vlgp_ctx* ctx, int set, int M, const int64_t* offsets, const double* y,
                                  const double* x, const double* mu, const double* v, const double* w) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, false);
     if (!us) return VLGP_ERR_ARG;
@@ -357,6 +421,7 @@ extern "C" int vlgp_upload_units(vlgp_ctx* ctx, int set, int M, const int64_t* o
 
 extern "C" int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst, const int64_t* start, int window) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* s = vlgp_get_set(ctx, src, true);
     UnitSet* d = vlgp_get_set(ctx, dst, false);
@@ -399,6 +464,7 @@ extern "C" int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst, const 
 
 extern "C" int vlgp_merge_units(vlgp_ctx* ctx, int cut_set) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     UnitSet* c = vlgp_get_set(ctx, cut_set, true);
     if (!c) return VLGP_ERR_ARG;
     if (c->parent < 0) return vlgp_fail(ctx, VLGP_ERR_STATE, "set %d is not a cut", cut_set);
@@ -410,6 +476,7 @@ extern "C" int vlgp_merge_units(vlgp_ctx* ctx, int cut_set) {
 
 extern "C" int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v, double* w, double* dmu) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us) return VLGP_ERR_ARG;
     const size_t nb = (size_t)us->rows * ctx->L * sizeof(double);
@@ -423,6 +490,7 @@ extern "C" int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v
 
 extern "C" int vlgp_free_units(vlgp_ctx* ctx, int set) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     UnitSet* us = vlgp_get_set(ctx, set, false);
     if (!us) return VLGP_ERR_ARG;
     for (auto& other : ctx->sets)
@@ -434,6 +502,7 @@ extern "C" int vlgp_free_units(vlgp_ctx* ctx, int set) {
 // ---- parameters ------------------------------------------------------------
 extern "C" int vlgp_set_params(vlgp_ctx* ctx, const double* a, const double* b, const double* noise) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     const int N = ctx->N, L = ctx->L, P = ctx->P;
     if (a) HIPCHK(ctx, hipMemcpyAsync(ctx->d_a, a, sizeof(double) * L * N, hipMemcpyHostToDevice, ctx->stream));
     if (b) HIPCHK(ctx, hipMemcpyAsync(ctx->d_b, b, sizeof(double) * P * N, hipMemcpyHostToDevice, ctx->stream));
@@ -445,6 +514,7 @@ extern "C" int vlgp_set_params(vlgp_ctx* ctx, const double* a, const double* b, 
 
 extern "C" int vlgp_get_params(vlgp_ctx* ctx, double* a, double* b, double* noise, double* da, double* db) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     const int N = ctx->N, L = ctx->L, P = ctx->P;
     if (a) HIPCHK(ctx, hipMemcpyAsync(a, ctx->d_a, sizeof(double) * L * N, hipMemcpyDeviceToHost, ctx->stream));
     if (b) HIPCHK(ctx, hipMemcpyAsync(b, ctx->d_b, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
@@ -615,6 +685,7 @@ static int end_count(vlgp_ctx* ctx, int* n_failed) {
 
 extern "C" int vlgp_update_w(vlgp_ctx* ctx, int set) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);
@@ -624,6 +695,7 @@ extern "C" int vlgp_update_w(vlgp_ctx* ctx, int set) {
 
 extern "C" int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);
@@ -637,6 +709,7 @@ extern "C" int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed) {
 
 extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb, int* n_failed) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);
@@ -649,19 +722,50 @@ extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, 
     return end_count(ctx, n_failed);
 }
 
-extern "C" int vlgp_mstep(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps, double lr,
-                          double da_bound, double db_bound, int* n_failed) {
+extern "C" int vlgp_mstep_begin(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps, double lr,
+                                double da_bound, double db_bound) {
     NEED_CTX(ctx);
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
+    if (ctx->m_pending) return vlgp_fail(ctx, VLGP_ERR_STATE, "an M-step is already in flight (call vlgp_mstep_end)");
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us) return VLGP_ERR_ARG;
+    if (!(da_bound > 0) || !(db_bound > 0)) return vlgp_fail(ctx, VLGP_ERR_ARG, "da_bound/db_bound must be positive");
+    // fork: the M-step lane starts after everything already queued on the main stream
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->mstream, ctx->ev_fork, 0));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_fail_m, 0, sizeof(int), ctx->mstream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_m_start, ctx->mstream));
+    if (n_iter >= 1)  // core.py:131-133
+        CHK(launch_mstep(ctx, *us, n_iter, use_hessian, eps, lr, da_bound, db_bound));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_m_done, ctx->mstream));
+    // join (device side): later work on the main stream sees the new a, b
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_m_done, 0));
+    ctx->m_pending = true;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_mstep_end(vlgp_ctx* ctx, int* n_failed, double* device_ms) {
+    NEED_CTX(ctx);
+    if (!ctx->m_pending) return vlgp_fail(ctx, VLGP_ERR_STATE, "no M-step in flight");
+    CHK(vlgp_join_m(ctx));
+    ctx->m_pending = false;
+    if (device_ms) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_m_start, ctx->ev_m_done));
+        *device_ms = ms;
+    }
+    if (n_failed) HIPCHK(ctx, hipMemcpy(n_failed, ctx->d_fail_m, sizeof(int), hipMemcpyDeviceToHost));
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_mstep(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps, double lr,
+                          double da_bound, double db_bound, int* n_failed) {
+    NEED_CTX(ctx);
     if (n_failed) *n_failed = 0;
     if (n_iter < 1) return VLGP_OK;  // core.py:131-133
-    if (!(da_bound > 0) || !(db_bound > 0)) return vlgp_fail(ctx, VLGP_ERR_ARG, "da_bound/db_bound must be positive");
-    CHK(begin_count(ctx));
-    CHK(launch_mstep(ctx, *us, n_iter, use_hessian, eps, lr, da_bound, db_bound));
-    return end_count(ctx, n_failed);
+    CHK(vlgp_mstep_begin(ctx, set, n_iter, use_hessian, eps, lr, da_bound, db_bound));
+    return vlgp_mstep_end(ctx, n_failed, nullptr);
 }
 
 extern "C" int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_eval, const int* latent,
@@ -677,6 +781,7 @@ extern "C" int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double d
 // ---- constraints / norms -----------------------------------------------------
 extern "C" int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const double* shift) {
     NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us || !map) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad latent map arguments");

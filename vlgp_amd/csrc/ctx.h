@@ -68,6 +68,16 @@ struct vlgp_ctx {
 
     UnitSet sets[VLGP_MAX_SETS];
 
+    // second execution lane: the M-step runs here, concurrently with the H-step
+    // rounds on the main stream (they touch disjoint data: a, b vs omega)
+    hipStream_t mstream = nullptr;
+    double* d_work_m = nullptr;
+    int64_t work_m_len = 0;
+    int* d_fail_m = nullptr;
+    void* comm_m = nullptr;       // its own ncclComm_t (collectives of one communicator must not interleave)
+    hipEvent_t ev_fork = nullptr, ev_m_start = nullptr, ev_m_done = nullptr;
+    bool m_pending = false;
+
     int* d_fail = nullptr;        // device failure counter
     unsigned long long* d_clk = nullptr;  // E-step per-phase cycle counters (debug), 8 slots
     double* d_work = nullptr;     // general workspace (M-step partials, H-step, reductions)
@@ -107,13 +117,16 @@ int vlgp_fail(vlgp_ctx* ctx, int code, const char* fmt, ...);
 int vlgp_ensure_work(vlgp_ctx* ctx, int64_t n_doubles);
 int vlgp_ensure_pinned(vlgp_ctx* ctx, int64_t n_doubles);
 int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n);  // in place, sum, on ctx->stream
+int vlgp_allreduce_m(vlgp_ctx* ctx, double* d_buf, int64_t n);  // same on the M-step lane (comm_m, mstream)
+int vlgp_ensure_work_m(vlgp_ctx* ctx, int64_t n_doubles);
+int vlgp_join_m(vlgp_ctx* ctx);  // wait for a pending asynchronous M-step
 int vlgp_bind_priors(vlgp_ctx* ctx, UnitSet& us);             // (re)build d_unit_prior
 int vlgp_refresh_xb(vlgp_ctx* ctx, UnitSet& us);              // xb = x.b when x is general
 UnitSet* vlgp_get_set(vlgp_ctx* ctx, int set, bool must_be_valid);
 
 // profiling brackets (HIP events on ctx->stream)
-void vlgp_prof_begin(vlgp_ctx* ctx, int kind);
-void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units = 0.0);
+void vlgp_prof_begin(vlgp_ctx* ctx, int kind, hipStream_t st = nullptr);
+void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units = 0.0, hipStream_t st = nullptr);
 
 // ---- kernel launchers (one per translation unit) -------------------------
 // mode bits for the E-step kernel
@@ -122,6 +135,7 @@ void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units = 0.0);
 #define EM_W 4         // recompute w
 #define EM_V 8         // update v from the factor
 int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bound, int vb);
+// runs entirely on ctx->mstream with the M-step lane's workspace / communicator
 int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double eps, double lr,
                  double da_bound, double db_bound);
 int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,

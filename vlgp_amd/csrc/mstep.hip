@@ -493,10 +493,11 @@ static void launch_accum_k(hipStream_t st, int kind, const Geometry& g, const MA
 template <int LT>
 static int launch_accum_p(vlgp_ctx* ctx, int kind, const Geometry& g, const MArgs& A) {
     const int P = A.P;
-    if (P <= 1) launch_accum_k<LT, 1>(ctx->stream, kind, g, A);
-    else if (P <= 2) launch_accum_k<LT, 2>(ctx->stream, kind, g, A);
-    else if (P <= 4) launch_accum_k<LT, 4>(ctx->stream, kind, g, A);
-    else if (P <= 8) launch_accum_k<LT, 8>(ctx->stream, kind, g, A);
+    hipStream_t mst = ctx->mstream;
+    if (P <= 1) launch_accum_k<LT, 1>(mst, kind, g, A);
+    else if (P <= 2) launch_accum_k<LT, 2>(mst, kind, g, A);
+    else if (P <= 4) launch_accum_k<LT, 4>(mst, kind, g, A);
+    else if (P <= 8) launch_accum_k<LT, 8>(mst, kind, g, A);
     else return vlgp_fail(ctx, VLGP_ERR_ARG, "M-step kernel supports xdim <= 8, got %d", P);
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
@@ -519,24 +520,25 @@ static void launch_lat_t(hipStream_t st, int G, int L, int64_t rows, const doubl
 }
 
 // d_out: tri(L) gram | L sum_mu | L sum_v | L sum_mu^2 | 1 |dmu|^2 ; all-reduced over ranks
-static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double* d_out) {
+static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double* d_out, bool mlane) {
     const int L = ctx->L;
+    hipStream_t st = mlane ? ctx->mstream : ctx->stream;
     int G = (int)((us.rows + 255) / 256);
     if (G > 256) G = 256;
     if (G < 1) G = 1;
     const int K = tri(L) + 3 * L + 1;
-    if (L <= 2) launch_lat_t<2>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else if (L <= 3) launch_lat_t<3>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else if (L <= 5) launch_lat_t<5>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else if (L <= 8) launch_lat_t<8>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else if (L <= 10) launch_lat_t<10>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else if (L <= 16) launch_lat_t<16>(ctx->stream, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    if (L <= 2) launch_lat_t<2>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 3) launch_lat_t<3>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 5) launch_lat_t<5>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 8) launch_lat_t<8>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 10) launch_lat_t<10>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    else if (L <= 16) launch_lat_t<16>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     else return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 latents supported, got %d", L);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 63) / 64), dim3(512), 0, ctx->stream, d_partial, G,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 63) / 64), dim3(512), 0, st, d_partial, G,
                        (int64_t)K, d_out);
     HIPCHK(ctx, hipGetLastError());
-    return vlgp_allreduce(ctx, d_out, K);
+    return mlane ? vlgp_allreduce_m(ctx, d_out, K) : vlgp_allreduce(ctx, d_out, K);
 }
 
 int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out) {
@@ -545,7 +547,7 @@ int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out) {
     CHK(vlgp_ensure_work(ctx, 256LL * K + K + 64));
     // caller's d_out may live inside d_work: use the tail of the workspace for partials
     double* d_partial = ctx->d_work + K + 64;
-    CHK(latent_moments(ctx, us, d_partial, ctx->d_work));
+    CHK(latent_moments(ctx, us, d_partial, ctx->d_work, false));
     if (d_out != ctx->d_work)
         HIPCHK(ctx, hipMemcpyAsync(d_out, ctx->d_work, sizeof(double) * K, hipMemcpyDeviceToDevice, ctx->stream));
     return VLGP_OK;
@@ -565,8 +567,9 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     const int64_t o_s1 = o_lat + Kl + 8, o_mean = o_s1 + N, o_part = o_mean + N;
     int64_t part_len = (int64_t)g.G * Kmax * N;
     if (part_len < 256LL * Kl) part_len = 256LL * Kl;
-    CHK(vlgp_ensure_work(ctx, o_part + part_len));
-    double* W = ctx->d_work;
+    CHK(vlgp_ensure_work_m(ctx, o_part + part_len));
+    double* W = ctx->d_work_m;
+    hipStream_t st = ctx->mstream;
     double *d_prep = W + o_prep, *d_stats = W + o_stats, *d_lat = W + o_lat, *d_s1 = W + o_s1,
            *d_mean = W + o_mean, *d_part = W + o_part;
 
@@ -577,25 +580,25 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
 
     auto reduce_to = [&](int K, double* dst) -> int {
         const int64_t n = (int64_t)K * N;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, ctx->stream,
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, st,
                            d_part, g.G, n, dst);
         HIPCHK(ctx, hipGetLastError());
-        return vlgp_allreduce(ctx, dst, n);
+        return vlgp_allreduce_m(ctx, dst, n);
     };
 
     // sweep-invariant moments
     CHK(launch_accum(ctx, K_PREP, g, A));
     CHK(reduce_to(Kp, d_prep));
-    CHK(latent_moments(ctx, us, d_part, d_lat));
+    CHK(latent_moments(ctx, us, d_part, d_lat, true));
     double total_rows = (double)us.rows;
     if (ctx->world > 1) {
         // total row count over ranks rides along in the workspace
         double h = total_rows;
-        HIPCHK(ctx, hipMemcpyAsync(d_lat + Kl, &h, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        CHK(vlgp_allreduce(ctx, d_lat + Kl, 1));
-        HIPCHK(ctx, hipMemcpyAsync(&h, d_lat + Kl, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_lat + Kl, &h, sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        CHK(vlgp_allreduce_m(ctx, d_lat + Kl, 1));
+        HIPCHK(ctx, hipMemcpyAsync(&h, d_lat + Kl, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
         total_rows = h;
     }
 
@@ -603,7 +606,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     S.N = N; S.L = L; S.P = P; S.use_hessian = use_hessian; S.eps = eps; S.lr = lr;
     S.da_bound = da_bound; S.db_bound = db_bound;
     S.prep = d_prep; S.stats = d_stats; S.lat = d_lat; S.gauss = ctx->d_gauss;
-    S.a = ctx->d_a; S.b = ctx->d_b; S.da = ctx->d_da; S.db = ctx->d_db; S.fail = ctx->d_fail;
+    S.a = ctx->d_a; S.b = ctx->d_b; S.da = ctx->d_da; S.db = ctx->d_db; S.fail = ctx->d_fail_m;
 
     const bool any_poisson = ctx->n_gauss < N;
     for (int it = 0; it < n_iter; ++it) {
@@ -611,22 +614,22 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
             // noise = var(y - eta) with the parameters entering the last iteration (core.py:177)
             CHK(launch_accum(ctx, K_NOISE1, g, A));
             CHK(reduce_to(1, d_s1));
-            hipLaunchKernelGGL(noise_mean_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N,
+            hipLaunchKernelGGL(noise_mean_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N,
                                total_rows, d_s1, d_mean);
             CHK(launch_accum(ctx, K_NOISE2, g, A));
             CHK(reduce_to(1, d_s1));
-            hipLaunchKernelGGL(noise_final_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N,
+            hipLaunchKernelGGL(noise_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N,
                                total_rows, d_s1, ctx->d_noise);
             HIPCHK(ctx, hipGetLastError());
         }
         if (any_poisson) {
-            vlgp_prof_begin(ctx, VLGP_PROF_MSTEP);
+            vlgp_prof_begin(ctx, VLGP_PROF_MSTEP, st);
             int rc = launch_accum(ctx, K_NEWTON, g, A);
-            vlgp_prof_end(ctx, VLGP_PROF_MSTEP, (double)us.rows);
+            vlgp_prof_end(ctx, VLGP_PROF_MSTEP, (double)us.rows, st);
             CHK(rc);
             CHK(reduce_to(Kn, d_stats));
         }
-        hipLaunchKernelGGL(mstep_solve_kernel, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, S);
+        hipLaunchKernelGGL(mstep_solve_kernel, dim3((N + 63) / 64), dim3(64), 0, st, S);
         HIPCHK(ctx, hipGetLastError());
     }
     return VLGP_OK;

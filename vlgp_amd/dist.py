@@ -83,17 +83,21 @@ class Comm:
     def attach(self, engine):
         if self.world == 1 and not os.environ.get("VLGP_FORCE_RCCL"):
             return
-        if self.uid is None:
-            from .engine import unique_id
+        from .engine import unique_id
 
-            self.uid = exchange_unique_id(self.rank, self.world, unique_id, self.path)
-        engine.comm_init(self.uid, self.rank, self.world)
+        base = self.path or _rendezvous_path()
+        if self.uid is None:
+            self.uid = exchange_unique_id(self.rank, self.world, unique_id, base)
+        if getattr(self, "uid_aux", None) is None:  # second communicator: the M-step lane
+            self.uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + ".aux")
+        engine.comm_init(self.uid, self.rank, self.world, self.uid_aux)
         engine.barrier()
         if self.rank == 0:
-            try:
-                os.remove(self.path or _rendezvous_path())
-            except OSError:
-                pass
+            for path in (base, base + ".aux"):
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
 
     def shard(self, items):
         return shard(items, self.rank, self.world)
