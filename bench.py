@@ -144,6 +144,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, comm.world))
     rank, world = comm.rank, comm.world
     device = getattr(comm, "local_rank", 0) if world > 1 else 0
+    device = int(os.environ.get("VLGP_DEVICE", device))  # tests: several ranks on one GPU (shm transport)
 
     trials, a0, b0, (n_trials, n_bins, N, L) = build_inputs(args.workload)
     mine = comm.shard(trials)

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <new>
@@ -155,7 +156,81 @@ static int rccl_load(vlgp_ctx* ctx) {
     return VLGP_OK;
 }
 
+
+// ---- shared-memory test transport --------------------------------------------------
+// VLGP_COMM_TRANSPORT=shm replaces RCCL by an all-reduce through a POSIX shared-memory
+// segment (device -> host, sum in rank order, host -> device).  It exists so that the
+// full multi-rank protocol -- sharding, the per-Newton-iteration M-step reductions, the
+// H-step rounds, the norms -- can be exercised by several processes that share ONE GPU
+// (RCCL refuses two ranks on a device).  It is a test vehicle, not a data path.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#define SHM_MAX_RANKS 16
+#define SHM_SLOT_DOUBLES (1 << 17)
+struct ShmRegion {
+    volatile long long ready[SHM_MAX_RANKS];
+    volatile long long done[SHM_MAX_RANKS];
+    double slot[SHM_MAX_RANKS][SHM_SLOT_DOUBLES];
+};
+struct ShmComm {
+    ShmRegion* reg = nullptr;
+    long long seq = 0;
+    int rank = 0, world = 1;
+    char name[64];
+};
+static bool shm_mode() {
+    const char* t = getenv("VLGP_COMM_TRANSPORT");
+    return t && strcmp(t, "shm") == 0;
+}
+static ShmComm* shm_open_comm(const char id[VLGP_UNIQUE_ID_BYTES], int rank, int world) {
+    if (world > SHM_MAX_RANKS) return nullptr;
+    ShmComm* c = new ShmComm();
+    c->rank = rank; c->world = world;
+    unsigned long long h = 1469598103934665603ULL;
+    for (int i = 0; i < VLGP_UNIQUE_ID_BYTES; ++i) h = (h ^ (unsigned char)id[i]) * 1099511628211ULL;
+    snprintf(c->name, sizeof(c->name), "/vlgp_shm_%016llx", h);
+    int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { delete c; return nullptr; }
+    if (ftruncate(fd, sizeof(ShmRegion)) != 0) { close(fd); delete c; return nullptr; }
+    void* p = mmap(nullptr, sizeof(ShmRegion), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete c; return nullptr; }
+    c->reg = (ShmRegion*)p;  // a fresh segment is zero-filled: ready/done start at 0, seq at 1
+    return c;
+}
+static void shm_close_comm(ShmComm* c) {
+    if (!c) return;
+    if (c->reg) munmap((void*)c->reg, sizeof(ShmRegion));
+    if (c->rank == 0) shm_unlink(c->name);
+    delete c;
+}
+static int shm_allreduce(vlgp_ctx* ctx, ShmComm* c, hipStream_t st, double* d_buf, int64_t n) {
+    if (n > SHM_SLOT_DOUBLES) return vlgp_fail(ctx, VLGP_ERR_COMM, "shm transport: buffer of %lld doubles too large", (long long)n);
+    const long long s = ++c->seq;
+    ShmRegion* R = c->reg;
+    // nobody may still be reading my slot from the previous round
+    for (int k = 0; k < c->world; ++k)
+        while (R->done[k] < s - 1) usleep(20);
+    HIPCHK(ctx, hipMemcpyAsync((void*)R->slot[c->rank], d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    __sync_synchronize();
+    R->ready[c->rank] = s;
+    for (int k = 0; k < c->world; ++k)
+        while (R->ready[k] < s) usleep(20);
+    __sync_synchronize();
+    std::vector<double> sum((size_t)n, 0.0);
+    for (int k = 0; k < c->world; ++k)  // fixed rank order: every rank gets the same bits
+        for (int64_t i = 0; i < n; ++i) sum[(size_t)i] += R->slot[k][i];
+    __sync_synchronize();
+    R->done[c->rank] = s;
+    HIPCHK(ctx, hipMemcpyAsync(d_buf, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return VLGP_OK;
+}
+
 int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n) {
+    if (ctx->shm) return shm_allreduce(ctx, (ShmComm*)ctx->shm, ctx->stream, d_buf, n);
     if (!ctx->comm) return VLGP_OK;
     const int rc = g_rccl.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
     if (rc != 0)
@@ -164,7 +239,9 @@ int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n) {
 }
 
 int vlgp_allreduce_m(vlgp_ctx* ctx, double* d_buf, int64_t n) {
+    if (ctx->shm_m) return shm_allreduce(ctx, (ShmComm*)ctx->shm_m, ctx->mstream, d_buf, n);
     if (!ctx->comm_m) {
+        if (ctx->shm) return vlgp_fail(ctx, VLGP_ERR_STATE, "multi-rank M-step needs vlgp_comm_init_aux");
         if (ctx->comm)
             return vlgp_fail(ctx, VLGP_ERR_STATE, "multi-rank M-step needs the second communicator (vlgp_comm_init_aux)");
         return VLGP_OK;
@@ -176,6 +253,12 @@ int vlgp_allreduce_m(vlgp_ctx* ctx, double* d_buf, int64_t n) {
 }
 
 extern "C" int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]) {
+    if (shm_mode()) {  // any bytes unique to this call will do
+        memset(id, 0, VLGP_UNIQUE_ID_BYTES);
+        static int counter = 0;
+        snprintf(id, VLGP_UNIQUE_ID_BYTES, "shm-%d-%d-%ld", (int)getpid(), counter++, (long)time(nullptr));
+        return VLGP_OK;
+    }
     CHK(rccl_load(nullptr));
     rccl_uid u;
     const int rc = g_rccl.get_uid(&u);
@@ -192,6 +275,11 @@ extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]
     // a single rank needs no communicator; VLGP_FORCE_RCCL=1 builds one anyway so
     // that the RCCL plumbing can be exercised on a one-GPU box (tests)
     if (world == 1 && !getenv("VLGP_FORCE_RCCL")) return VLGP_OK;
+    if (shm_mode()) {
+        ctx->shm = shm_open_comm(id, rank, world);
+        if (!ctx->shm) return vlgp_fail(ctx, VLGP_ERR_COMM, "cannot open the shared-memory test transport");
+        return VLGP_OK;
+    }
     CHK(rccl_load(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     rccl_uid u;
@@ -205,6 +293,12 @@ extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]
 extern "C" int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]) {
     NEED_CTX(ctx);
     if (ctx->world == 1 && !getenv("VLGP_FORCE_RCCL")) return VLGP_OK;
+    if (shm_mode()) {
+        if (!ctx->shm) return vlgp_fail(ctx, VLGP_ERR_STATE, "vlgp_comm_init must precede vlgp_comm_init_aux");
+        ctx->shm_m = shm_open_comm(id, ctx->rank, ctx->world);
+        if (!ctx->shm_m) return vlgp_fail(ctx, VLGP_ERR_COMM, "cannot open the shared-memory test transport (aux)");
+        return VLGP_OK;
+    }
     if (!ctx->comm) return vlgp_fail(ctx, VLGP_ERR_STATE, "vlgp_comm_init must precede vlgp_comm_init_aux");
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     rccl_uid u;
@@ -219,7 +313,7 @@ extern "C" int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n) {
     NEED_CTX(ctx);
     if (n < 0 || (n > 0 && !buf)) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad allreduce arguments");
     HIPCHK(ctx, hipSetDevice(ctx->dev));
-    if (!ctx->comm) {
+    if (!ctx->comm && !ctx->shm) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return VLGP_OK;
     }
@@ -339,6 +433,8 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     if (ctx->mstream) (void)hipStreamSynchronize(ctx->mstream);
     ctx->m_pending = false;
     prof_drain(ctx);
+    shm_close_comm((ShmComm*)ctx->shm_m);
+    shm_close_comm((ShmComm*)ctx->shm);
     if (ctx->comm_m && g_rccl.destroy) g_rccl.destroy(ctx->comm_m);
     if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
     // aliased sets first, then owners

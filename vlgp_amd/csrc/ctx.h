@@ -94,6 +94,8 @@ struct vlgp_ctx {
 
     // RCCL
     void* comm = nullptr;         // ncclComm_t
+    void* shm = nullptr;          // shared-memory test transport (VLGP_COMM_TRANSPORT=shm), main lane
+    void* shm_m = nullptr;        // ... M-step lane
     int rank = 0, world = 1;
 
     std::string err;
