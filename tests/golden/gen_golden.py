@@ -307,6 +307,20 @@ def gen_fit():
          dmu=np.stack([t["dmu"] for t in res["trials"]]))
 
 
+def gen_init():
+    """preprocess.initialize on C1 (FactorAnalysis on the seeded 10 % subsample)."""
+    from vlgp.preprocess import initialize
+
+    n_trials, n_bins, N, L = synth.CONFIGS["C1"]
+    trials = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    cfg = get_config()
+    params = get_params(trials, L, omega_bound=cfg["omega_bound"])
+    np.random.seed(7)
+    initialize(trials, params, cfg)
+    save("init_c1", a=params["a"], b=params["b"], noise=params["noise"],
+         mu=np.stack([t["mu"] for t in trials]), x_shape=np.array(trials[0]["x"].shape))
+
+
 if __name__ == "__main__":
     os.chdir("/tmp")  # the reference writes vlgp.log into the cwd at import
     check_generator()
@@ -316,3 +330,4 @@ if __name__ == "__main__":
     gen_hstep()
     gen_vem()
     gen_fit()
+    gen_init()

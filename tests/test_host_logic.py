@@ -131,3 +131,20 @@ def test_synth_is_seeded():
     b = synth.make_trials(3, 100, 6, 4, seed=0)
     assert all(np.array_equal(x["y"], y["y"]) for x, y in zip(a, b))
     assert a[0]["y"].shape == (100, 6) and a[0]["y"].min() >= 0
+
+
+def test_initialize_matches_reference(golden):
+    """preprocess.initialize (FactorAnalysis on the seeded subsample) against the reference's."""
+    from vlgp_amd import get_config, get_params, synth
+    from vlgp_amd.preprocess import initialize
+
+    g = golden("init_c1")
+    n_trials, n_bins, N, L = synth.CONFIGS["C1"]
+    trials = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    cfg = get_config()
+    params = get_params(trials, L, omega_bound=cfg["omega_bound"])
+    np.random.seed(7)
+    initialize(trials, params, cfg)
+    assert relerr(params["a"], g["a"]) < 1e-10 and relerr(params["b"], g["b"]) < 1e-12
+    assert relerr(np.stack([t["mu"] for t in trials]), g["mu"]) < 1e-9
+    assert trials[0]["x"].shape == tuple(g["x_shape"]) and np.all(trials[0]["w"] == 0)
