@@ -78,6 +78,7 @@ struct vlgp_ctx {
     hipEvent_t ev_fork = nullptr, ev_m_start = nullptr, ev_m_done = nullptr;
     bool m_pending = false;
 
+    double* d_ecols = nullptr;    // E-step per-channel records + wconst (fast kernel), rebuilt per launch
     int* d_fail = nullptr;        // device failure counter
     unsigned long long* d_clk = nullptr;  // E-step per-phase cycle counters (debug), 8 slots
     double* d_work = nullptr;     // general workspace (M-step partials, H-step, reductions)

@@ -450,6 +450,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.scratch = nullptr; A.lc_global = nullptr; A.lc_stride = 0;
     A.fail = ctx->d_fail;
     A.clk = ctx->d_clk;
+    A.cols_g = nullptr; A.wconst_g = nullptr;
     A.lds_T = us.Tmax; A.lds_gsz = (int)gsz; A.lds_lcsz = (int)lcsz;
 
     // FAST: register-resident factorisations (estep_fast.hip); declines when it does not apply

@@ -29,7 +29,10 @@ struct EstepArgs {
     int rg;                // lanes per row in the (T x N) passes (power of two <= 64)
     int lds_T;             // SMALL: row capacity of the LDS tiles
     int lds_gsz, lds_lcsz; // doubles reserved for G tiles / factors in LDS
+    int lds_scr;           // fast kernel: doubles of the shared scratch region
     unsigned long long* clk; // optional per-phase cycle counters (thread 0 of every block), or null
+    const double* cols_g;    // fast kernel: per-channel records (a_l, a_l^2, b, 1/noise), (N, 2*LT+2), global
+    const double* wconst_g;  // fast kernel: Gaussian-channel constant of w per latent (L)
 };
 
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ double fast_exp(double x) {
 }
 
 template <int LT, int RP>
-__global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(EstepArgs A) {
+__global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(EstepArgs A, const double* __restrict__ cols_g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int REC = 2 * LT + 2;          // a[LT], a^2[LT], b, c  (even -> 16-byte records)
     constexpr int PK = tri_packed_size(RP);  // packed lower-triangular RP x RP
@@ -68,18 +68,20 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
     const double* Gbase = pidx >= 0 ? A.prior_base[pidx] : nullptr;
 
     double* p = smem;
-    double* cols = p;    p += (int64_t)N * REC;
-    double* wconst = p;  p += (L + 1) & ~1;
     double* mu_s = p;    p += Tc * L;
     double* v_s = p;     p += Tc * L;
     double* w_s = p;     p += Tc * L;
     double* ra_s = p;    p += Tc * L;
     double* ya_s = p;    p += Tc * L;
-    double* u_s = p;     p += Tc * L;
-    double* part = p;    p += (int64_t)nw * Tc * L;
     p += ((p - smem) & 1);  // keep 16-byte alignment for the vector-read regions below
-    double* vec_s = p;   p += nw * 128;
-    double* tile_s = p;  p += nw * 256;  // per-wave 16 x 16 MFMA staging tile
+    // One scratch region, three tenants that never overlap in time (workgroup barriers in
+    // between): `part` in the (T x N) passes, `vec`/`u` in the mean update, `tile` in the
+    // factor build.
+    double* scr = p;     p += A.lds_scr;
+    double* part = scr;
+    double* vec_s = scr;
+    double* u_s = scr + nw * 128;
+    double* tile_s = scr;
     double* Xp = p;      p += (int64_t)L * PK;
     double* G_s = p;     p += A.lds_gsz;
     int* ip = reinterpret_cast<int*>(p);
@@ -91,19 +93,7 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
     int* fail_s = ip;    ip += L;
 
     // ---- stage ---------------------------------------------------------------
-    for (int n = tid; n < N; n += nthr) {
-        const int g = A.gauss[n];
-        gflag[n] = g;
-        double* rec = cols + (int64_t)n * REC;
-#pragma unroll
-        for (int l = 0; l < LT; ++l) {
-            const double av = l < L ? A.a[l * N + n] : 0.0;
-            rec[l] = av;
-            rec[LT + l] = av * av;
-        }
-        rec[2 * LT] = A.b[n];
-        rec[2 * LT + 1] = g ? 1.0 / A.noise[n] : 1.0;
-    }
+    for (int n = tid; n < N; n += nthr) gflag[n] = A.gauss[n];
     if (tid == 64 || (nthr <= 64 && tid == 0)) {
         int np = 0;
         for (int n = 0; n < N; ++n)
@@ -128,12 +118,6 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
         w_s[i] = A.w[r0 * L + i];
     }
     __syncthreads();
-    if (tid < L) {
-        double s = 0.0;
-        for (int n = 0; n < N; ++n)
-            if (gflag[n]) s = fma(cols[(int64_t)n * REC + LT + tid], cols[(int64_t)n * REC + 2 * LT + 1], s);
-        wconst[tid] = s;
-    }
     for (int l = 0; l < L; ++l) {
         const int r = rl_s[l], rs = (r + 1) & ~1;
         if (r == 0) continue;
@@ -163,8 +147,11 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
         }
         const double* yrow = A.y + (r0 + (in ? t : 0)) * N;
         const double* xbrow = HASXB ? A.xb + (r0 + (in ? t : 0)) * N : nullptr;
-        auto load_rec = [&](int n, double (&rv)[REC]) {
-            const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)n * REC);
+        // the record is wave-uniform: with a scalar channel index the loads below are scalar
+        // (s_load_dwordx4) and the values feed the FMAs straight from SGPRs
+        auto load_rec = [&](int n_any, double (&rv)[REC]) {
+            const int n = __builtin_amdgcn_readfirstlane(n_any);
+            const double2* rp = reinterpret_cast<const double2*>(cols_g + (int64_t)n * REC);
 #pragma unroll
             for (int q = 0; q < REC / 2; ++q) {
                 const double2 t2 = rp[q];
@@ -234,7 +221,7 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
             for (int w = 0; w < nw; ++w) s += part[(int64_t)w * Tc * L + idx];
             if constexpr (KIND == FP_YA) ya_s[idx] = s;
             else if constexpr (KIND == FP_RES) ra_s[idx] = ya_s[idx] - s;
-            else w_s[idx] = s + wconst[idx % L];
+            else w_s[idx] = s + A.wconst_g[idx % L];
         }
         __syncthreads();
     };
@@ -291,7 +278,7 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
                 lap2(6);
                 // all in registers: every lane holds row (lane mod RP) of I + G'WG
                 double x[RP];
-                ok = wave_chol_inv_regs<RP>(a, x, j);
+                ok = wave_chol_inv_regs<RP>(a, x, j, r);
                 if (lane < RP) {  // X row-major packed in LDS for the solves: X[i][c], i >= c
 #pragma unroll
                     for (int i = 0; i < RP; ++i)
@@ -526,6 +513,30 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 3 : 1)) estep_fast_kernel(Est
     }
 }
 
+// per-channel records for the passes: (a_l, a_l^2)[LT padded], b, 1/noise (or 1), and the
+// constant Gaussian-channel part of w; one tiny launch per E-step call
+__global__ void __launch_bounds__(256)
+estep_cols_kernel(int N, int L, int LT, const double* a, const double* b, const double* noise, const int* gauss,
+                  double* cols, double* wconst) {
+    const int REC = 2 * LT + 2;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        double* rec = cols + (int64_t)n * REC;
+        for (int l = 0; l < LT; ++l) {
+            const double av = l < L ? a[l * N + n] : 0.0;
+            rec[l] = av;
+            rec[LT + l] = av * av;
+        }
+        rec[2 * LT] = b[n];
+        rec[2 * LT + 1] = gauss[n] ? 1.0 / noise[n] : 1.0;
+    }
+    if ((int)threadIdx.x < L) {  // w = U (a')^2 with U = 1/noise on Gaussian channels (core.py:103-104)
+        double s = 0.0;
+        for (int n = 0; n < N; ++n)
+            if (gauss[n]) s = fma(a[threadIdx.x * N + n] * a[threadIdx.x * N + n], 1.0 / noise[n], s);
+        wconst[threadIdx.x] = s;
+    }
+}
+
 // ---------------------------------------------------------------------------
 template <int LT, int RP>
 static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t lds) {
@@ -534,7 +545,7 @@ static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, siz
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
-    hipLaunchKernelGGL(fn, dim3(M), dim3(nthr), lds, ctx->stream, A);
+    hipLaunchKernelGGL(fn, dim3(M), dim3(nthr), lds, ctx->stream, A, A.cols_g);
     vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)M * (A.n_iter > 0 ? A.n_iter : 1));
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
@@ -573,11 +584,21 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     const int nw = L < 4 ? 4 : L;  // L <= 8
     const int Tc = us.Tmax;
     const int64_t PK = RP == 16 ? tri_packed_size(16) : tri_packed_size(32);
-    int64_t d = (int64_t)N * (2 * LT + 2) + ((L + 1) & ~1) + 6LL * Tc * L + (int64_t)nw * Tc * L + 1 + nw * 384 +
-                L * PK + gsz + (2 * N + 3 * L + 3) / 2 + 2;
+    int64_t scr = (int64_t)nw * Tc * L;                       // partial sums of the passes
+    if (scr < (int64_t)nw * 256) scr = (int64_t)nw * 256;     // 16 x 16 MFMA staging tiles
+    if (scr < (int64_t)nw * 128 + (int64_t)Tc * L) scr = (int64_t)nw * 128 + (int64_t)Tc * L;  // vec + u
+    scr = (scr + 1) & ~1LL;
+    int64_t d = 5LL * Tc * L + 1 + scr + L * PK + gsz + (2 * N + 3 * L + 3) / 2 + 2;
     if (d * 8 > 160 * 1024) return VLGP_OK;
     A.lds_gsz = (int)gsz;
     A.lds_T = Tc;
+    A.lds_scr = (int)scr;
+    if (!ctx->d_ecols) HIPCHK(ctx, hipMalloc(&ctx->d_ecols, sizeof(double) * ((size_t)N * 34 + 32)));
+    A.cols_g = ctx->d_ecols;
+    A.wconst_g = ctx->d_ecols + (int64_t)N * 34;
+    hipLaunchKernelGGL(estep_cols_kernel, dim3(1), dim3(256), 0, ctx->stream, N, L, LT, ctx->d_a, ctx->d_b, ctx->d_noise,
+                       ctx->d_gauss, ctx->d_ecols, ctx->d_ecols + (int64_t)N * 34);
+    HIPCHK(ctx, hipGetLastError());
     *handled = 1;
     const int nthr = nw * 64;
     if (RP == 16) return launch_fast_l<16>(ctx, A, us.M, nthr, (size_t)d * 8);

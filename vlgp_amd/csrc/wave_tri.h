@@ -122,36 +122,44 @@ __device__ __forceinline__ void wave_tri_inverse_cols(const double* Lp, double (
 // is no LDS traffic and no wave-level synchronisation at all.  Out: x[i] =
 // (L^-1)[i][j], the column j of X.  Returns false on a non-positive pivot.
 template <int RP>
-__device__ __forceinline__ bool wave_chol_inv_regs(double (&a)[RP], double (&x)[RP], int j) {
-    double invd[RP];
+__device__ __forceinline__ bool wave_chol_inv_regs(double (&a)[RP], double (&x)[RP], int j, int r) {
+    // r (wave-uniform, <= RP) = true dimension; rows/columns >= r are the identity padding and
+    // are skipped: the unrolled steps beyond r cost one scalar branch each.
+    // the diagonal slot a[k] of lane k keeps 1 / L[k][k]: the recurrence never reads the
+    // diagonal again and the inverse wants the reciprocal (fetched with v_readlane)
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < RP; ++k) {
-        double s0 = a[k], s1 = 0.0;
+        if (k < r) {
+            double s0 = a[k], s1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < k; ++i) {
-            const double lki = tri_readlane(a[i], k);  // L[k][i]
-            if (i & 1) s1 = fma(-a[i], lki, s1);
-            else s0 = fma(-a[i], lki, s0);
+            for (int i = 0; i < k; ++i) {
+                const double lki = tri_readlane(a[i], k);  // L[k][i]
+                if (i & 1) s1 = fma(-a[i], lki, s1);
+                else s0 = fma(-a[i], lki, s0);
+            }
+            const double s = s0 + s1;
+            const double d = tri_readlane(s, k);
+            if (!(d > 0.0) || !(d < 1e300)) ok = false;
+            double inv, sd;
+            tri_rsqrt(d, &inv, &sd);
+            a[k] = (j == k) ? inv : s * inv;  // L[j][k] for j > k (garbage above the diagonal)
         }
-        const double s = s0 + s1;
-        const double d = tri_readlane(s, k);
-        if (!(d > 0.0) || !(d < 1e300)) ok = false;
-        double inv, sd;
-        tri_rsqrt(d, &inv, &sd);
-        invd[k] = inv;
-        a[k] = (j == k) ? sd : s * inv;  // L[j][k] for j > k (garbage above the diagonal)
     }
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
-        double c0 = 0.0, c1 = 0.0;
+        if (i < r) {
+            double c0 = 0.0, c1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < i; ++q) {
-            const double liq = tri_readlane(a[q], i);  // L[i][q]
-            if (q & 1) c1 = fma(liq, x[q], c1);
-            else c0 = fma(liq, x[q], c0);
+            for (int q = 0; q < i; ++q) {
+                const double liq = tri_readlane(a[q], i);  // L[i][q]
+                if (q & 1) c1 = fma(liq, x[q], c1);
+                else c0 = fma(liq, x[q], c0);
+            }
+            x[i] = ((j == i ? 1.0 : 0.0) - (c0 + c1)) * tri_readlane(a[i], i);
+        } else {
+            x[i] = (j == i) ? 1.0 : 0.0;
         }
-        x[i] = ((j == i ? 1.0 : 0.0) - (c0 + c1)) * invd[i];
     }
     return ok;
 }
