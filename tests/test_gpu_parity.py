@@ -492,3 +492,40 @@ def test_c5_like_ragged_mixed_ten_latents(V):
         if relerr(np.einsum("ltr,lsr->lts", Gg, Gg), np.einsum("ltr,lsr->lts", Gr, Gr)) < 1e-9:
             assert relerr(tg["mu"], tr["mu"]) < 1e-4, T
             assert relerr(tg["v"], tr["v"]) < 1e-4, T
+
+
+# ------------------------------------------------------------------ other windows / likelihoods through fit
+@pytest.mark.parametrize("window,lik_gauss", [(25, 0), (40, 0), (50, 12)])
+def test_fit_other_windows_and_all_gaussian(V, window, lik_gauss):
+    """window != 50 takes the generic H-step kernels (the register-resident fast path is
+    compiled for the reference's default window); lik_gauss = N makes every channel Gaussian
+    (closed-form M-step, no exp anywhere).  Three EM iterations against the oracle."""
+    from vlgp_amd import synth
+
+    N, L, n_bins = 12, 3, 200
+    trials = synth.make_trials(6, n_bins, N, L, seed=9, n_gauss=lik_gauss)
+    rng = np.random.default_rng(2)
+    a0 = 0.3 * rng.standard_normal((L, N))
+    ycat = np.concatenate([t["y"] for t in trials])
+    b0 = np.zeros((1, N))
+    npois = N - lik_gauss
+    if npois:
+        b0[0, :npois] = np.log(np.maximum(ycat[:, :npois].mean(0), 1e-8))
+    lik = ["poisson"] * npois + ["gaussian"] * lik_gauss
+    mu0 = [0.2 * rng.standard_normal((n_bins, L)) for _ in trials]
+    fresh = lambda: [{"ID": i, "y": t["y"].copy(), "mu": m.copy()} for i, (t, m) in enumerate(zip(trials, mu0))]
+    kw = dict(a=a0.copy(), b=b0.copy(), lik=lik, max_iter=3, min_iter=3, window=window)
+    got = V.fit(fresh(), L, ichol="host", verbose=False, **kw)
+
+    ref = fresh()
+    for t in ref:
+        t["x"] = np.ones((n_bins, 1, N))
+        t["w"] = np.zeros((n_bins, L))
+        t["v"] = np.zeros((n_bins, L))
+    cfg = O.make_config(max_iter=3, min_iter=3, window=window)
+    params = O.make_params(ref, L, a=a0.copy(), b=b0.copy(), lik=lik)
+    O.fit_given_init(ref, params, cfg)
+    assert relerr(got["params"]["omega"], params["omega"]) < 1e-5
+    assert relerr(got["params"]["a"], params["a"]) < 1e-5
+    assert relerr(got["params"]["b"], params["b"]) < 1e-5
+    assert relerr(got["params"]["noise"], params["noise"]) < 1e-5
