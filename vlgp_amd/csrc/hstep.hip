@@ -411,15 +411,20 @@ __global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
 #pragma unroll
         for (int j = 0; j < T; ++j) {
             const double* Xj = Lp + off.v[j];
-            double a0 = 0.0, a1 = 0.0;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
             for (int k = j; k < T; k += 2) {
                 const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-                a0 = fma(x[k], v.x, a0);
-                if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
+                if ((k - j) & 2) {
+                    a2 = fma(x[k], v.x, a2);
+                    if (k + 1 < T) a3 = fma(x[k + 1], v.y, a3);
+                } else {
+                    a0 = fma(x[k], v.x, a0);
+                    if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
+                }
             }
             const int dd = lane > j ? lane - j : j - lane;
-            cacc = fma((a0 + a1) * sw[j], dkv[dd & 63], cacc);
+            cacc = fma(((a0 + a1) + (a2 + a3)) * sw[j], dkv[dd & 63], cacc);
             __builtin_amdgcn_sched_barrier(0);
         }
         cacc = in ? cacc * sw_t : 0.0;
