@@ -446,12 +446,166 @@ __global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
     }
 }
 
+
+// Two tasks per wave, two rows per lane (wave_tri.h "duo"): halves the LDS broadcast
+// traffic per FMA and drops the finished rows' upper-triangle work.
+template <int T>
+__global__ void __launch_bounds__(128, 2) hstep_seg_duo(HFastArgs A) {
+    constexpr int H = T / 2;
+    constexpr int PK = tri_packed_size(T);  // == upper-packed size for even T
+    constexpr int NW = 2;  // 2 waves x 2 tasks x 10.4 KB factors + vectors = 52 KB: three blocks per CU
+    __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PK];
+    __shared__ double vec_all[NW][2][5][64];
+    __shared__ double kv[64], dkv[64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int h = lane >> 5, q = lane & 31;
+    const int e = blockIdx.y;
+    const int seg = (blockIdx.x * NW + wid) * 2 + h;
+    if (threadIdx.x < 64) kv[threadIdx.x] = A.kcol[(int64_t)e * 128 + threadIdx.x];
+    else if (threadIdx.x < 128) dkv[threadIdx.x - 64] = A.kcol[(int64_t)e * 128 + threadIdx.x];
+    __syncthreads();
+    if ((blockIdx.x * NW + wid) * 2 >= A.M) return;  // whole wave idle
+    const bool valid = seg < A.M;
+    const bool in = q < H && valid;
+    double* Lp = Lp_all[wid][h];
+    double* sw = vec_all[wid][h][0];
+    double* muv = vec_all[wid][h][1];
+    double* alv = vec_all[wid][h][2];
+    double* invd = vec_all[wid][h][3];
+    double* stash = vec_all[wid][h][4];  // long-lived per-lane scalars parked in LDS (register pressure)
+    const int l = A.latent[e];
+    const int64_t r0row = A.off[valid ? seg : 0];
+    const double* Ki = A.kinv + (int64_t)e * T * T;
+
+    double mu0 = 0.0, mu1 = 0.0, w0 = 0.0, w1 = 0.0;
+    if (in) {
+        mu0 = A.mu[(r0row + q) * A.L + l];
+        mu1 = A.mu[(r0row + q + H) * A.L + l];
+        w0 = A.w[(r0row + q) * A.L + l];
+        w1 = A.w[(r0row + q + H) * A.L + l];
+    }
+    const double sw0 = sqrt(w0), sw1 = sqrt(w1);
+    if (q < H) {
+        sw[q] = sw0; sw[q + H] = sw1;
+        muv[q] = mu0; muv[q + H] = mu1;
+    }
+    tri_wave_sync();
+    // alpha = K^-1 mu for rows q and q + H (K^-1 symmetric: coalesced column reads)
+    double al0 = 0.0, al1 = 0.0;
+    if (in) {
+#pragma unroll 5
+        for (int j = 0; j < T; ++j) {
+            const double mj = muv[j];
+            al0 = fma(Ki[j * T + q], mj, al0);
+            al1 = fma(Ki[j * T + q + H], mj, al1);
+        }
+    }
+    if (q < H) { alv[q] = al0; alv[q + H] = al1; }
+    tri_wave_sync();
+    double quad = mu0 * al0 + mu1 * al1, gq = 0.0;
+    if (in) {
+        double g0 = 0.0, g1 = 0.0;
+#pragma unroll 5
+        for (int j = 0; j < T; ++j) {
+            const double aj = alv[j];
+            const int d0 = q > j ? q - j : j - q;
+            const int d1 = q + H > j ? q + H - j : j - q - H;
+            g0 = fma(dkv[d0], aj, g0);
+            g1 = fma(dkv[d1], aj, g1);
+        }
+        gq = g0 * al0 + g1 * al1;
+    }
+    stash[q] = quad;
+    stash[32 + q] = gq;
+    // rows q and q + H of A = I + W^1/2 K W^1/2 (lower parts) into packed LDS
+    if (q < H) {
+        const int o0 = tri_row_off(q), o1 = tri_row_off(q + H);
+#pragma nounroll
+        for (int i = 0; i <= q; ++i) Lp[o0 + i] = sw0 * sw[i] * kv[q - i] + (i == q ? 1.0 : 0.0);
+#pragma nounroll
+        for (int i = 0; i <= q + H; ++i) Lp[o1 + i] = sw1 * sw[i] * kv[q + H - i] + (i == q + H ? 1.0 : 0.0);
+    }
+    tri_wave_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    bool ok;
+    {
+        double r0[H], r1[T];
+        ok = wave_chol_rows_duo<T>(r0, r1, Lp, invd, q, h);
+    }
+    double tr = 0.0, cacc = 0.0;
+    {
+        double x0[T], x1[H];
+        wave_tri_inverse_cols_duo<T>(Lp, invd, x0, x1, q);
+#pragma unroll
+        for (int k = 0; k < T; ++k) tr = fma(x0[k], x0[k], tr);
+#pragma unroll
+        for (int k = 0; k < H; ++k) tr = fma(x1[k], x1[k], tr);
+        tri_wave_sync();
+        // X columns -> upper-packed rows of X' (overwrites L)
+        if (q < H) {
+            const int my0 = triu_off_even(q, T), my1 = triu_off_even(q + H, T);
+#pragma unroll
+            for (int k = 0; k < T; ++k)
+                if (k >= q) Lp[my0 + k - q] = x0[k];
+            if ((T - q) & 1) Lp[my0 + T - q] = 0.0;
+#pragma unroll
+            for (int k = H; k < T; ++k)
+                if (k >= q + H) Lp[my1 + k - q - H] = x1[k - H];
+            if ((T - q - H) & 1) Lp[my1 + T - q - H] = 0.0;
+        }
+        tri_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        double c0acc = 0.0, c1acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const double* Xj = Lp + triu_off_even(j, T);
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int k = j; k < T; k += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
+                a0 = fma(x0[k], v.x, a0);
+                if (k + 1 < T) a1 = fma(x0[k + 1], v.y, a1);
+                if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
+                if (k + 1 >= H && k + 1 < T) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
+                if (((k - j) & 14) == 14) __builtin_amdgcn_sched_barrier(0);
+            }
+            const double swj = sw[j];
+            const int d0 = q > j ? q - j : j - q;
+            const int d1 = q + H > j ? q + H - j : j - q - H;
+            c0acc = fma((a0 + a1) * swj, dkv[d0 & 63], c0acc);
+            c1acc = fma((b0 + b1) * swj, dkv[d1 & 63], c1acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cacc = c0acc * sw[q < H ? q : 0] + c1acc * sw[q < H ? q + H : 0];
+    }
+    quad = stash[q];
+    gq = stash[32 + q];
+    if (!in) { tr = 0.0; cacc = 0.0; quad = 0.0; gq = 0.0; }
+    for (int o = 16; o > 0; o >>= 1) {  // reduce within each 32-lane half
+        quad += __shfl_xor(quad, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+        tr += __shfl_xor(tr, o, 64);
+        cacc += __shfl_xor(cacc, o, 64);
+    }
+    if (q == 0 && valid) {
+        const double logdet = A.scal[4 * e + 0];
+        double ll = -0.5 * quad - 0.5 * tr - logdet;
+        double dll = 0.5 * (gq - cacc);
+        if (!ok) { ll = nan(""); dll = nan(""); }
+        A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
+        A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
+    }
+}
+
 template <int T>
 static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
     hipLaunchKernelGGL((hstep_prep_fast<T>), dim3(n_eval), dim3(64), 0, ctx->stream, F);
     HIPCHK(ctx, hipGetLastError());
     vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-    hipLaunchKernelGGL((hstep_seg_fast<T>), dim3((M + 3) / 4, n_eval), dim3(256), 0, ctx->stream, F);
+    if (!getenv("VLGP_HSTEP_SOLO"))
+        hipLaunchKernelGGL((hstep_seg_duo<T>), dim3((M + 3) / 4, n_eval), dim3(128), 0, ctx->stream, F);
+    else
+        hipLaunchKernelGGL((hstep_seg_fast<T>), dim3((M + 3) / 4, n_eval), dim3(256), 0, ctx->stream, F);
     vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;

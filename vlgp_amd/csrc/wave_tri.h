@@ -25,6 +25,13 @@ __device__ __forceinline__ void tri_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+// Intra-wave LDS hand-off: the LDS executes one wavefront's DS instructions in issue order,
+// so a lane's ds_write is visible to a later ds_read of any lane of the SAME wave without
+// waiting for the write to be acknowledged.  Only the compiler must keep the order.
+__device__ __forceinline__ void tri_wave_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ double tri_readlane(double x, int src_lane) {
     union { double d; int i[2]; } u, o;
@@ -55,7 +62,7 @@ __device__ __forceinline__ void tri_rsqrt(double d, double* inv_out, double* sd_
 template <int T>
 __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int lane, double* invd = nullptr) {
     const int my_off = tri_row_off(lane < T ? lane : 0);
-    bool ok = true;
+    int bad = 0;  // eager failure flag (see wave_chol_rows_duo)
 #pragma unroll
     for (int k = 0; k < T; ++k) {  // no early exit: a `break` would defeat the full unroll
         const double* Lk = Lp + tri_row_off(k);
@@ -69,7 +76,8 @@ __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int l
         if (k & 1) s0 = fma(-r[k - 1], Lk[k - 1], s0);
         const double s = s0 + s1;
         const double d = tri_readlane(s, k);
-        if (!(d > 0.0) || !(d < 1e300)) ok = false;  // later columns are garbage; caller discards
+        bad |= (!(d > 0.0) || !(d < 1e300)) ? 1 : 0;  // later columns are garbage; caller discards
+        asm volatile("" : "+v"(bad));
         double inv, sd;
         tri_rsqrt(d, &inv, &sd);  // one reciprocal root per column instead of sqrt + a division per lane
         r[k] = (lane == k) ? sd : s * inv;
@@ -78,7 +86,7 @@ __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int l
         tri_wave_sync();
         __builtin_amdgcn_sched_barrier(0);  // one scheduling region per column: bounded live ranges
     }
-    return ok;
+    return bad == 0;
 }
 
 // sum_k log L[k][k] of a packed factor: one log per lane, then a wave reduction
@@ -199,4 +207,113 @@ __device__ __forceinline__ void wave_store_cols(const double (&x)[T], double* Xp
         if ((T - lane) & 1) Xp[my + T - lane] = 0.0;  // zero the pad so pair reads are exact
     }
     tri_wave_sync();
+}
+
+// ===========================================================================
+// "Duo" variants: ONE wavefront factors TWO matrices (task A in lanes 0..31,
+// task B in lanes 32..63) and every lane holds TWO rows of its matrix (row q and
+// row q + T/2, q = lane & 31).  Why: a wave-uniform pivot value read from LDS
+// serves one FMA per lane in the one-row scheme; the CU's single LDS pipe (one
+// broadcast ds_read_b128 = 4 LDS cycles for 2 doubles) then caps the four SIMDs
+// at half their fp64 FMA rate (measured: 53 % issue utilisation).  With two rows
+// per lane each broadcast value feeds two FMAs, the two halves read two
+// addresses per instruction at no extra LDS cost, and the static upper-triangle
+// work of rows < T/2 disappears for steps k >= T/2 (762 instead of 1225 FMA
+// instructions per matrix and phase).
+// ===========================================================================
+__device__ __forceinline__ double tri_pick_half(double v, int src_q, int h) {
+    // value of lane (32 h + src_q): two static readlanes and a per-half select
+    const double a = tri_readlane(v, src_q);
+    const double b = tri_readlane(v, 32 + src_q);
+    return h ? b : a;
+}
+
+// In: Lp = this lane's task buffer (packed lower, holds A).  Out: chol(A) in place,
+// r0[i] = L[q][i], r1[i] = L[q + T/2][i]; invd[k] = 1 / L[k][k] (per-task LDS array).
+// Returns per-lane ok flag (identical within a half).
+template <int T>
+__device__ __forceinline__ bool wave_chol_rows_duo(double (&r0)[T / 2], double (&r1)[T], double* Lp, double* invd,
+                                                   int q, int h) {
+    constexpr int H = T / 2;
+    const bool in = q < H;
+    const int off0 = tri_row_off(in ? q : 0), off1 = tri_row_off(in ? q + H : H);
+    int bad = 0;  // materialised every step (asm below): a lazily evaluated `ok &= d > 0` chain
+                  // keeps all T pivots alive to the end (measured: +74 VGPRs)
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const double* Lk = Lp + tri_row_off(k);
+        double s0 = (k < H) ? Lp[off0 + (k < H ? k : 0)] : 0.0, s0b = 0.0;  // A[q][k]
+        double s1 = Lp[off1 + k], s1b = 0.0;                              // A[q + H][k]
+#pragma unroll
+        for (int i = 0; i + 1 < k; i += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Lk + i);
+            if (k < H) {  // rows < H are finished once k >= H: no work for them (static)
+                s0 = fma(-r0[i < H ? i : 0], v.x, s0);
+                s0b = fma(-r0[i + 1 < H ? i + 1 : 0], v.y, s0b);
+            }
+            s1 = fma(-r1[i], v.x, s1);
+            s1b = fma(-r1[i + 1], v.y, s1b);
+            // bound the number of pivot-row loads in flight (registers): at most 8 b128 ahead
+            if ((i & 14) == 14) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k & 1) {
+            const double lv = Lk[k - 1];
+            if (k < H) s0 = fma(-r0[k - 1 < H ? k - 1 : 0], lv, s0);
+            s1 = fma(-r1[k - 1], lv, s1);
+        }
+        s0 += s0b;
+        s1 += s1b;
+        const double d = tri_pick_half(k < H ? s0 : s1, k < H ? k : k - H, h);  // pivot of this half's matrix
+        bad |= (!(d > 0.0) || !(d < 1e300)) ? 1 : 0;
+        asm volatile("" : "+v"(bad));
+        double inv, sd;
+        tri_rsqrt(d, &inv, &sd);
+        if (k < H) {
+            r0[k < H ? k : 0] = (q == k) ? sd : s0 * inv;
+            if (in && q >= k) Lp[off0 + k] = r0[k < H ? k : 0];
+        }
+        r1[k] = (q + H == k) ? sd : s1 * inv;
+        if (in && q + H >= k) Lp[off1 + k] = r1[k];
+        if (q == 0) invd[k] = inv;
+        tri_wave_order();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return bad == 0;
+}
+
+// Columns q and q + T/2 of X = L^-1 in registers: x0[i] = X[i][q], x1[i - T/2] = X[i][q + T/2]
+// (the latter is zero for i < T/2 and not stored).
+template <int T>
+__device__ __forceinline__ void wave_tri_inverse_cols_duo(const double* Lp, const double* invd, double (&x0)[T],
+                                                          double (&x1)[T / 2], int q) {
+    constexpr int H = T / 2;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const double* Li = Lp + tri_row_off(i);
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int j = 0; j + 1 < i; j += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Li + j);
+            a0 = fma(v.x, x0[j], a0);
+            a1 = fma(v.y, x0[j + 1], a1);
+            if (j >= H) b0 = fma(v.x, x1[j - H < 0 ? 0 : j - H], b0);
+            if (j + 1 >= H) b1 = fma(v.y, x1[j + 1 - H < 0 ? 0 : j + 1 - H], b1);
+            if ((j & 14) == 14) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i & 1) {
+            const double lv = Li[i - 1];
+            a0 = fma(lv, x0[i - 1], a0);
+            if (i - 1 >= H) b0 = fma(lv, x1[i - 1 - H < 0 ? 0 : i - 1 - H], b0);
+        }
+        const double di = invd[i];
+        x0[i] = ((q == i ? 1.0 : 0.0) - (a0 + a1)) * di;
+        if (i >= H) x1[i - H < 0 ? 0 : i - H] = ((q + H == i ? 1.0 : 0.0) - (b0 + b1)) * di;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// offset of row c in the upper-packed X' storage (rows padded to an even length), T even
+__host__ __device__ constexpr int triu_off_even(int c, int T) {
+    return (c & 1) ? 2 * T * (c / 2) - 2 * (c / 2) * (c / 2 - 1) + (T - 2 * (c / 2))
+                   : 2 * T * (c / 2) - 2 * (c / 2) * (c / 2 - 1);
 }
