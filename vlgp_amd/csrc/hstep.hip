@@ -230,7 +230,8 @@ __global__ void __launch_bounds__(256) hstep_seg_kernel(HSegArgs A) {
 }
 
 // out[e][c] = sum_i in[e][i][c]  (fixed order: strided partial sums, then a tree)
-__global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* in, double* out) {
+__global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* in, double* out,
+                                                           const double* scal = nullptr, double* ok_out = nullptr) {
     __shared__ double r0[256], r1[256];
     const int e = blockIdx.x;
     double a = 0.0, b = 0.0;
@@ -251,6 +252,7 @@ __global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* 
     if (threadIdx.x == 0) {
         out[2 * e + 0] = r0[0];
         out[2 * e + 1] = r1[0];
+        if (scal) ok_out[e] = scal[4 * e + 3];
     }
 }
 
@@ -270,8 +272,8 @@ struct HFastArgs {
     const int64_t* off;
     const double* mu;
     const double* w;
-    const int* latent;
-    const double* logp;
+    int latent[16];      // by value: no host->device copies on the round's critical path
+    double logp[48];
     double* kinv;   // (n_eval, T, T)
     double* kcol;   // (n_eval, 2, 64): first column of K, first column of dK
     double* scal;   // (n_eval, 4): logdet, -, omega_used, ok
@@ -620,37 +622,33 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     const int64_t TT = (int64_t)T * T;
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
     const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
-    const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 2 * n_eval;
+    const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
     const int64_t o_lat = o_logp + 3 * n_eval, total = o_lat + n_eval + 8;
     CHK(vlgp_ensure_work(ctx, total));
     CHK(vlgp_ensure_pinned(ctx, 12 * n_eval + 32));
     double* W = ctx->d_work;
     double* hp = ctx->h_pinned;
-    for (int i = 0; i < 3 * n_eval; ++i) hp[i] = logp[i];
-    int* hlat = reinterpret_cast<int*>(hp + 3 * n_eval);
-    for (int i = 0; i < n_eval; ++i) {
+    if (n_eval > 16) return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 evaluations per call, got %d", n_eval);
+    for (int i = 0; i < n_eval; ++i)
         if (latent[i] < 0 || latent[i] >= L) return vlgp_fail(ctx, VLGP_ERR_ARG, "latent index out of range");
-        hlat[i] = latent[i];
-    }
-    HIPCHK(ctx, hipMemcpyAsync(W + o_logp, hp, sizeof(double) * 3 * n_eval, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(W + o_lat, hlat, sizeof(int) * n_eval, hipMemcpyHostToDevice, ctx->stream));
 
     if (T == 50 && !getenv("VLGP_HSTEP_GENERIC")) {
         HFastArgs F;
         F.L = L; F.M = M; F.dt = dt; F.off = us.d_off; F.mu = us.mu; F.w = us.w;
-        F.latent = reinterpret_cast<const int*>(W + o_lat); F.logp = W + o_logp;
+        for (int i = 0; i < n_eval; ++i) F.latent[i] = latent[i];
+        for (int i = 0; i < 3 * n_eval; ++i) F.logp[i] = logp[i];
         F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
         CHK(launch_fast<50>(ctx, F, n_eval, M));
-        hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red);
+        // red: [2 n_eval] (ll, dll) pairs, then [n_eval] "K factored" flags -> one device->host copy
+        hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red,
+                           W + o_scal, W + o_red + 2 * n_eval);
         HIPCHK(ctx, hipGetLastError());
         CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
         double* hres = hp + 4 * n_eval + 8;
-        double* hscal = hres + 2 * n_eval;
-        HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 2 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hscal, W + o_scal, sizeof(double) * 4 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         bool all_ok = true;
-        for (int e = 0; e < n_eval; ++e) all_ok = all_ok && hscal[4 * e + 3] != 0.0;
+        for (int e = 0; e < n_eval; ++e) all_ok = all_ok && hres[2 * n_eval + e] != 0.0;
         if (all_ok) {
             for (int e = 0; e < n_eval; ++e) {
                 ll[e] = hres[2 * e + 0];
@@ -663,6 +661,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
         // K did not factor for some evaluation: fall through to the generic path,
         // which implements the reference's omega bump
     }
+    for (int i = 0; i < 3 * n_eval; ++i) hp[i] = logp[i];
+    int* hlat = reinterpret_cast<int*>(hp + 3 * n_eval);
+    for (int i = 0; i < n_eval; ++i) hlat[i] = latent[i];
+    HIPCHK(ctx, hipMemcpyAsync(W + o_logp, hp, sizeof(double) * 3 * n_eval, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(W + o_lat, hlat, sizeof(int) * n_eval, hipMemcpyHostToDevice, ctx->stream));
     HPrepArgs P;
     P.T = T; P.dt = dt; P.logp = W + o_logp; P.kinv = W + o_kinv; P.q = W + o_q; P.dk = W + o_dk;
     P.scal = W + o_scal;

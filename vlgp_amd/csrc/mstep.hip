@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "ctx.h"
+#include "fast_exp.h"
 
 #define M_TILE 64
 
@@ -89,7 +90,8 @@ __global__ void __launch_bounds__(512) mstep_accum(MArgs A) {
         __syncthreads();
         if (!active) continue;
         if (KIND == K_NEWTON && gch) continue;  // Gaussian channels need no rate statistics
-        for (int rr = s; rr < nr; rr += S) {
+#pragma unroll 2
+        for (int rr = s; rr < nr; rr += S) {  // two rows in flight: independent exp / FMA chains
             const int64_t row = t0 + rr;
             double xv[PT];
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(512) mstep_accum(MArgs A) {
                     lin = fma(vr[l] * al[l], al[l], lin);
                 }
                 if constexpr (KIND == K_NEWTON) {
-                    const double rate = exp(fmin(fma(0.5, lin, eta), 10.0));
+                    const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
                     double mt[LT], q[LT];
 #pragma unroll
                     for (int l = 0; l < LT; ++l) {
