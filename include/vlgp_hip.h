@@ -146,6 +146,15 @@ int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_ev
                          const int* latent, const double* logp, double* ll,
                          double* dll);
 
+/* Brackets the objective calls of one gp.optimize run (vlgp/gp.py:65-97), during
+ * which the set's mu and w do not change: the per-latent second-moment matrices
+ * sum_i mu_i mu_i' that the quadratic terms of every evaluation share are then built
+ * once (by the first objective call) instead of on every call.  The caller must not
+ * modify the set between begin and end.  Optional: without it every
+ * vlgp_hstep_objective call is self-contained. */
+int vlgp_hstep_begin(vlgp_ctx* ctx, int set, int window);
+int vlgp_hstep_end(vlgp_ctx* ctx);
+
 /* ---- constraints / norms --------------------------------------------- */
 /* mu <- (mu - shift) @ map for every unit (map (L, L) row-major, shift (L) or
  * NULL).  Covers core.constrain_loading (vlgp/core.py:392-416: map = s I, or

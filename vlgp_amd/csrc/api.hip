@@ -450,6 +450,8 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     if (ctx->ev_m_done) (void)hipEventDestroy(ctx->ev_m_done);
     if (ctx->mstream) (void)hipStreamDestroy(ctx->mstream); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_hres) (void)hipHostFree(ctx->h_hres);
+    fr(ctx->d_hsync); fr(ctx->d_hmom);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VLGP_OK;
@@ -491,6 +493,7 @@ static int up(vlgp_ctx* ctx, double** dst, const double* src, int64_t n) {
 extern "C" int vlgp_upload_units(vlgp_ctx* ctx, int set, int M, const int64_t* offsets, const double* y,
                                  const double* x, const double* mu, const double* v, const double* w) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, false);
@@ -517,6 +520,7 @@ extern "C" int vlgp_upload_units(vlgp_ctx* ctx, int set, int M, const int64_t* o
 
 extern "C" int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst, const int64_t* start, int window) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* s = vlgp_get_set(ctx, src, true);
@@ -560,6 +564,7 @@ extern "C" int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst, const 
 
 extern "C" int vlgp_merge_units(vlgp_ctx* ctx, int cut_set) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     UnitSet* c = vlgp_get_set(ctx, cut_set, true);
     if (!c) return VLGP_ERR_ARG;
@@ -586,6 +591,7 @@ extern "C" int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v
 
 extern "C" int vlgp_free_units(vlgp_ctx* ctx, int set) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     UnitSet* us = vlgp_get_set(ctx, set, false);
     if (!us) return VLGP_ERR_ARG;
@@ -781,6 +787,7 @@ static int end_count(vlgp_ctx* ctx, int* n_failed) {
 
 extern "C" int vlgp_update_w(vlgp_ctx* ctx, int set) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
@@ -805,6 +812,7 @@ extern "C" int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed) {
 
 extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb, int* n_failed) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
@@ -874,9 +882,27 @@ extern "C" int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double d
     return launch_hstep(ctx, *us, window, dt, n_eval, latent, logp, ll, dll);
 }
 
+extern "C" int vlgp_hstep_begin(vlgp_ctx* ctx, int set, int window) {
+    NEED_CTX(ctx);
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    (void)window;
+    ctx->hmom_bracket = true;
+    ctx->hmom_us = nullptr;  // the first objective call inside the bracket builds the moments
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_hstep_end(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    ctx->hmom_bracket = false;
+    ctx->hmom_us = nullptr;
+    return VLGP_OK;
+}
+
 // ---- constraints / norms -----------------------------------------------------
 extern "C" int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const double* shift) {
     NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);

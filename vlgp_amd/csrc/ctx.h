@@ -85,6 +85,16 @@ struct vlgp_ctx {
     int64_t work_len = 0;
     double* h_pinned = nullptr;   // small pinned staging buffer
     int64_t pinned_len = 0;
+    // H-step round kernel: device flags/counter and the mapped host mailbox it publishes to
+    unsigned* d_hsync = nullptr;
+    double* h_hres = nullptr;     // 48 results + sequence word
+    double* d_hres = nullptr;     // device view of h_hres
+    unsigned h_seq = 0;
+    double* d_hmom = nullptr;     // (L, T, T) second moments of mu for the quadratic terms
+    int64_t hmom_len = 0;
+    const UnitSet* hmom_us = nullptr;
+    int hmom_T = 0;
+    bool hmom_bracket = false;    // inside vlgp_hstep_begin/end: d_hmom stays valid across objective calls
 
     // profiling
     bool prof_on = false;

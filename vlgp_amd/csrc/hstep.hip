@@ -12,6 +12,7 @@
 // Cholesky of K^-1 + W, its triangular inverse X, and the two Frobenius
 // products <X'X, K^-1>, <X'X, Q> accumulated without materialising S.
 #include <stdlib.h>
+#include <string.h>
 
 #include "ctx.h"
 #include "wave_tri.h"
@@ -281,11 +282,14 @@ struct HFastArgs {
 };
 
 template <int T>
-__global__ void __launch_bounds__(64, 3) hstep_prep_fast(HFastArgs A) {
-    constexpr int PK = tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
-    __shared__ __attribute__((aligned(16))) double Lp[PK];
-    __shared__ double kv[64], dkv[64];
-    const int e = blockIdx.x, lane = threadIdx.x;
+constexpr int hstep_prep_lds() {
+    return tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
+}
+
+// One wave: K = sigma^2 exp(-omega d^2) + eps I -> K^-1, log det chol(K), first columns of K and dK.
+template <int T>
+__device__ __forceinline__ void hstep_prep_body(const HFastArgs& A, int e, int lane, double* Lp, double* kv,
+                                                double* dkv) {
     const double sigmasq = exp(A.logp[3 * e + 0]);
     double omega = exp(A.logp[3 * e + 1]);
     const double eps = exp(A.logp[3 * e + 2]);
@@ -337,6 +341,13 @@ __global__ void __launch_bounds__(64, 3) hstep_prep_fast(HFastArgs A) {
         A.scal[4 * e + 2] = omega;
         A.scal[4 * e + 3] = ok ? 1.0 : 0.0;
     }
+}
+
+template <int T>
+__global__ void __launch_bounds__(64, 3) hstep_prep_fast(HFastArgs A) {
+    __shared__ __attribute__((aligned(16))) double Lp[hstep_prep_lds<T>()];
+    __shared__ double kv[64], dkv[64];
+    hstep_prep_body<T>(A, blockIdx.x, threadIdx.x, Lp, kv, dkv);
 }
 
 template <int T>
@@ -569,13 +580,17 @@ __global__ void __launch_bounds__(128, 2) hstep_seg_duo(HFastArgs A) {
                 if (k + 1 < T) a1 = fma(x0[k + 1], v.y, a1);
                 if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
                 if (k + 1 >= H && k + 1 < T) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
-                if (((k - j) & 14) == 14) __builtin_amdgcn_sched_barrier(0);
+                if (((k - j) & 14) == 14) {
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             const double swj = sw[j];
             const int d0 = q > j ? q - j : j - q;
             const int d1 = q + H > j ? q + H - j : j - q - H;
             c0acc = fma((a0 + a1) * swj, dkv[d0 & 63], c0acc);
             c1acc = fma((b0 + b1) * swj, dkv[d1 & 63], c1acc);
+            asm volatile("" : "+v"(c0acc), "+v"(c1acc));
             __builtin_amdgcn_sched_barrier(0);
         }
         cacc = c0acc * sw[q < H ? q : 0] + c1acc * sw[q < H ? q + H : 0];
@@ -596,6 +611,339 @@ __global__ void __launch_bounds__(128, 2) hstep_seg_duo(HFastArgs A) {
         if (!ok) { ll = nan(""); dll = nan(""); }
         A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
         A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Second moments of the latent means, C_l = sum_i mu_i[:, l] mu_i[:, l]' (T x T per
+// latent, summed over the set's units).  The quadratic terms of the objective depend
+// on the units only through C_l:
+//     sum_i mu_i' K^-1 mu_i              = tr(K^-1 C_l)
+//     sum_i alpha_i' dK alpha_i          = tr(K^-1 dK K^-1 C_l),   alpha_i = K^-1 mu_i
+// and mu does not change during one gp.optimize call, so C_l is built once per
+// H-step (vlgp_hstep_begin) and every evaluation's K block reduces it in ~10 us.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, const int64_t* off, const double* mu,
+                                                           int nchunk, double* part) {
+    constexpr int NE = (T * T + 255) / 256;
+    __shared__ double s[4][64];
+    const int l = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int per = (M + nchunk - 1) / nchunk;
+    const int m0 = c * per, m1 = (m0 + per < M) ? m0 + per : M;
+    double acc[NE];
+    int jj[NE], kk[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int idx = tid + 256 * i;
+        acc[i] = 0.0;
+        jj[i] = idx < T * T ? idx / T : 0;
+        kk[i] = idx < T * T ? idx - jj[i] * T : 0;
+    }
+    for (int m = m0; m < m1; m += 4) {
+        __syncthreads();
+        {
+            const int sg = tid >> 6, t = tid & 63;
+            s[sg][t] = (m + sg < m1 && t < T) ? mu[(off[m + sg] + t) * L + l] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] = fma(s[sg][jj[i]], s[sg][kk[i]], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < T * T) part[((int64_t)l * nchunk + c) * T * T + idx] = acc[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) hstep_moment_reduce(int nchunk, int TT, const double* part, double* mom) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (idx >= TT) return;
+    double a = 0.0;
+    for (int c = 0; c < nchunk; ++c) a += part[((int64_t)l * nchunk + c) * TT + idx];  // fixed order
+    mom[(int64_t)l * TT + idx] = a;
+}
+
+// One wave, after hstep_prep_body: (tr(K^-1 C), tr(K^-1 dK K^-1 C)) -> qsum[2e], qsum[2e + 1].
+// Lane j owns row j of K^-1 (kj) and of C (cj); row b of K^-1 and dK are LDS broadcasts:
+//     gq = sum_j sum_b (C K^-1)[j][b] (K^-1 dK)[j][b].
+// Kl: T*T doubles of LDS, dk2: 128 doubles of LDS (dK mirrored: dk2[63 + d] = dK[|d|]).
+template <int T>
+__device__ __forceinline__ void hstep_prep_moments(const HFastArgs& A, const double* mom, double* qsum, int e,
+                                                   int lane, double* Kl, double* dk2, const double* dkv) {
+    static_assert(T % 2 == 0 && T <= 64, "window must be even and at most 64");
+    const int row = lane < T ? lane : 0;
+    const double* Ki = A.kinv + (int64_t)e * T * T + (int64_t)row * T;
+    const double* Cj = mom + (int64_t)A.latent[e] * T * T + (int64_t)row * T;
+    double kj[T], cj[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        kj[k] = Ki[k];  // written by this very lane in hstep_prep_body
+        cj[k] = Cj[k];
+    }
+    if (lane < T) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) Kl[lane * T + k] = kj[k];
+    }
+    dk2[lane] = dkv[63 - lane];                                  // i = lane      -> |i - 63| = 63 - lane
+    dk2[64 + lane] = dkv[(lane + 1) & 63];                       // i = 64 + lane -> lane + 1 (entry 127 unused)
+    tri_wave_sync();
+    double quad = 0.0, gq = 0.0;
+#pragma unroll
+    for (int k = 0; k < T; ++k) quad = fma(kj[k], cj[k], quad);
+#pragma nounroll
+    for (int b = 0; b < T; ++b) {
+        const double* Kb = Kl + b * T;
+        const double* Db = dk2 + (63 - b);  // Db[a] = dK[|a - b|]
+        double e0 = 0.0, e1 = 0.0, f0 = 0.0, f1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < T; k += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Kb + k);
+            e0 = fma(cj[k], v.x, e0);
+            e1 = fma(cj[k + 1], v.y, e1);
+            f0 = fma(kj[k], Db[k], f0);
+            f1 = fma(kj[k + 1], Db[k + 1], f1);
+        }
+        gq = fma(e0 + e1, f0 + f1, gq);
+    }
+    if (lane >= T) { quad = 0.0; gq = 0.0; }
+    for (int o = 32; o > 0; o >>= 1) {
+        quad += __shfl_xor(quad, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+    }
+    if (lane == 0) {
+        qsum[2 * e + 0] = quad;
+        qsum[2 * e + 1] = gq;
+    }
+}
+
+// The A_i part for one pair of tasks: factor A (packed in Lp), X = L^-1, returns
+// (tr(A^-1), sum_jk sqrt(w_j w_k) dK_jk (A^-1)_jk) per lane-partial (caller reduces
+// over the 32-lane half); x = NaN when A did not factor.  The empty asm statements pin
+// the load/FMA interleave and force the c*acc chain to be evaluated per row: without
+// them the compiler defers the chain and hoists whole rows of loads (2800 spilled VGPRs
+// measured when the quadratic part follows instead of precedes this code).
+template <int T>
+__device__ __forceinline__ double2 hstep_apart_duo(double* Lp, const double* sw, double* invd, const double* dkv, int q,
+                                                 int h) {
+    constexpr int H = T / 2;
+    bool ok;
+    {
+        double r0[H], r1[T];
+        ok = wave_chol_rows_duo<T>(r0, r1, Lp, invd, q, h);
+    }
+    double tr = 0.0, cacc = 0.0;
+    {
+        double x0[T], x1[H];
+        wave_tri_inverse_cols_duo<T>(Lp, invd, x0, x1, q);
+#pragma unroll
+        for (int k = 0; k < T; ++k) tr = fma(x0[k], x0[k], tr);
+#pragma unroll
+        for (int k = 0; k < H; ++k) tr = fma(x1[k], x1[k], tr);
+        tri_wave_sync();
+        // X columns -> upper-packed rows of X' (overwrites L)
+        if (q < H) {
+            const int my0 = triu_off_even(q, T), my1 = triu_off_even(q + H, T);
+#pragma unroll
+            for (int k = 0; k < T; ++k)
+                if (k >= q) Lp[my0 + k - q] = x0[k];
+            if ((T - q) & 1) Lp[my0 + T - q] = 0.0;
+#pragma unroll
+            for (int k = H; k < T; ++k)
+                if (k >= q + H) Lp[my1 + k - q - H] = x1[k - H];
+            if ((T - q - H) & 1) Lp[my1 + T - q - H] = 0.0;
+        }
+        tri_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        double c0acc = 0.0, c1acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const double* Xj = Lp + triu_off_even(j, T);
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int k = j; k < T; k += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
+                a0 = fma(x0[k], v.x, a0);
+                if (k + 1 < T) a1 = fma(x0[k + 1], v.y, a1);
+                if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
+                if (k + 1 >= H && k + 1 < T) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
+                if (((k - j) & 14) == 14) {
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const double swj = sw[j];
+            const int d0 = q > j ? q - j : j - q;
+            const int d1 = q + H > j ? q + H - j : j - q - H;
+            c0acc = fma((a0 + a1) * swj, dkv[d0 & 63], c0acc);
+            c1acc = fma((b0 + b1) * swj, dkv[d1 & 63], c1acc);
+            asm volatile("" : "+v"(c0acc), "+v"(c1acc));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cacc = c0acc * sw[q < H ? q : 0] + c1acc * sw[q < H ? q + H : 0];
+    }
+    double2 out;
+    out.x = ok ? tr : nan("");
+    out.y = cacc;
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// One launch per L-BFGS-B round.  Blocks [0, n_eval) factor K and reduce the
+// moment matrices (hstep_prep_body + hstep_prep_moments, one wave); the others
+// take four segments each and compute only the A_i terms, which need nothing
+// from the K blocks (first columns of K and dK are recomputed inline), so all
+// blocks run concurrently.  Every block leaves one partial sum and takes a
+// ticket (release); the block that draws the last ticket adds the partials in a
+// fixed order and publishes (ll, dll, ok) per evaluation -- to mapped host memory
+// when the host polls (single rank), else to `red` for the all-reduce.
+// ---------------------------------------------------------------------------
+struct HRoundArgs {
+    HFastArgs F;
+    int n_eval, nb;        // nb = segment blocks per evaluation
+    unsigned seq;          // launch sequence number published with the results
+    unsigned* sync;        // [16]: finished-block counter
+    const double* mom;     // (L, T, T) second moments of mu
+    double* qsum;          // (n_eval, 2): tr(K^-1 C), tr(K^-1 dK K^-1 C)
+    double* red;           // device: (ll, dll) x n_eval, then ok x n_eval
+    double* host;          // mapped pinned copy of `red` + sequence word at [48], or null
+};
+
+template <int T>
+__global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
+    constexpr int H = T / 2;
+    constexpr int PK = tri_packed_size(T);
+    constexpr int NW = 2;
+    static_assert(4 * PK >= hstep_prep_lds<T>() + 1 + T * T, "K block: factor + K^-1 must fit in the task buffers");
+    __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PK];
+    __shared__ double vec_all[NW][2][4][64];
+    __shared__ double kv[64], dkv[64];
+    __shared__ double part[2 * NW][2];
+    __shared__ int s_last;
+    const HFastArgs& A = R.F;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if ((int)blockIdx.x < R.n_eval) {
+        const int e = blockIdx.x;
+        if (wid == 0) {
+            double* base = &Lp_all[0][0][0];
+            hstep_prep_body<T>(A, e, lane, base, kv, dkv);
+            tri_wave_sync();
+            hstep_prep_moments<T>(A, R.mom, R.qsum, e, lane, base + ((hstep_prep_lds<T>() + 1) & ~1), &vec_all[0][0][0][0], dkv);
+        }
+    } else {
+        const int b = blockIdx.x - R.n_eval;
+        const int e = b / R.nb, bx = b - e * R.nb;
+        const int h = lane >> 5, q = lane & 31;
+        const int seg = (bx * NW + wid) * 2 + h;
+        if (threadIdx.x < 64) {
+            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
+            const double d = lane * A.dt, d2 = d * d;
+            const double kk = sigmasq * exp(-omega * d2);
+            kv[lane] = kk + (lane == 0 ? eps : 0.0);
+            dkv[lane] = -kk * d2 * omega;
+        }
+        __syncthreads();
+        double tr = 0.0, cacc = 0.0;
+        if ((bx * NW + wid) * 2 < A.M) {
+            const bool valid = seg < A.M;
+            const bool in = q < H && valid;
+            double* Lp = Lp_all[wid][h];
+            double* sw = vec_all[wid][h][0];
+            double* invd = vec_all[wid][h][3];
+            const int l = A.latent[e];
+            const int64_t r0row = A.off[valid ? seg : 0];
+            double w0 = 0.0, w1 = 0.0;
+            if (in) {
+                w0 = A.w[(r0row + q) * A.L + l];
+                w1 = A.w[(r0row + q + H) * A.L + l];
+            }
+            const double sw0 = sqrt(w0), sw1 = sqrt(w1);
+            if (q < H) { sw[q] = sw0; sw[q + H] = sw1; }
+            tri_wave_sync();
+            // rows q and q + H of A = I + W^1/2 K W^1/2 (lower parts) into packed LDS
+            if (q < H) {
+                const int o0 = tri_row_off(q), o1 = tri_row_off(q + H);
+#pragma nounroll
+                for (int i = 0; i <= q; ++i) Lp[o0 + i] = sw0 * sw[i] * kv[q - i] + (i == q ? 1.0 : 0.0);
+#pragma nounroll
+                for (int i = 0; i <= q + H; ++i) Lp[o1 + i] = sw1 * sw[i] * kv[q + H - i] + (i == q + H ? 1.0 : 0.0);
+            }
+            tri_wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            const double2 tc = hstep_apart_duo<T>(Lp, sw, invd, dkv, q, h);
+            tr = tc.x;  // NaN marks a failed factorisation and propagates into ll
+            cacc = tc.x == tc.x ? tc.y : tc.x;
+            if (!in) { tr = 0.0; cacc = 0.0; }
+            for (int o = 16; o > 0; o >>= 1) {  // reduce within each 32-lane half
+                tr += __shfl_xor(tr, o, 64);
+                cacc += __shfl_xor(cacc, o, 64);
+            }
+        }
+        if ((lane & 31) == 0) {
+            part[wid * 2 + (lane >> 5)][0] = tr;
+            part[wid * 2 + (lane >> 5)][1] = cacc;
+        }
+    }
+    // ---- completion: one partial per block, then the last block reduces and publishes ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if ((int)blockIdx.x >= R.n_eval) {
+            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
+            o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+            o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+        }
+        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double* rs = &Lp_all[0][0][0];  // 2 x 128 partials
+    for (int e = 0; e < R.n_eval; ++e) {
+        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int m = threadIdx.x; m < R.nb; m += 128) {
+            const double2 v = in[m];
+            s0 += v.x;
+            s1 += v.y;
+        }
+        __syncthreads();
+        rs[threadIdx.x] = s0;
+        rs[128 + threadIdx.x] = s1;
+        __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                rs[threadIdx.x] += rs[threadIdx.x + o];
+                rs[128 + threadIdx.x] += rs[128 + threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double okf = A.scal[4 * e + 3];
+            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
+            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[128]);
+            R.red[2 * e + 0] = ll;
+            R.red[2 * e + 1] = dll;
+            R.red[2 * R.n_eval + e] = okf;
+            if (R.host) {
+                R.host[2 * e + 0] = ll;
+                R.host[2 * e + 1] = dll;
+                R.host[2 * R.n_eval + e] = okf;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        R.sync[16] = 0;  // next launch is stream-ordered after this one
+        if (R.host) {
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -623,7 +971,8 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
     const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
-    const int64_t o_lat = o_logp + 3 * n_eval, total = o_lat + n_eval + 8;
+    const int64_t o_lat = o_logp + 3 * n_eval, o_qsum = o_lat + n_eval + 8, o_mpart = o_qsum + 2 * n_eval + 2;
+    const int64_t total = o_mpart + (T == 50 ? (int64_t)L * 64 * TT : 0);
     CHK(vlgp_ensure_work(ctx, total));
     CHK(vlgp_ensure_pinned(ctx, 12 * n_eval + 32));
     double* W = ctx->d_work;
@@ -638,15 +987,72 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
         for (int i = 0; i < n_eval; ++i) F.latent[i] = latent[i];
         for (int i = 0; i < 3 * n_eval; ++i) F.logp[i] = logp[i];
         F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
-        CHK(launch_fast<50>(ctx, F, n_eval, M));
-        // red: [2 n_eval] (ll, dll) pairs, then [n_eval] "K factored" flags -> one device->host copy
-        hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red,
-                           W + o_scal, W + o_red + 2 * n_eval);
-        HIPCHK(ctx, hipGetLastError());
-        CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
         double* hres = hp + 4 * n_eval + 8;
-        HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (getenv("VLGP_HSTEP_UNFUSED")) {
+            CHK(launch_fast<50>(ctx, F, n_eval, M));
+            // red: [2 n_eval] (ll, dll) pairs, then [n_eval] "K factored" flags -> one device->host copy
+            hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red,
+                               W + o_scal, W + o_red + 2 * n_eval);
+            HIPCHK(ctx, hipGetLastError());
+            CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
+            HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            if (!ctx->d_hsync) {
+                HIPCHK(ctx, hipMalloc(&ctx->d_hsync, 32 * sizeof(unsigned)));
+                HIPCHK(ctx, hipMemsetAsync(ctx->d_hsync, 0, 32 * sizeof(unsigned), ctx->stream));
+                HIPCHK(ctx, hipHostMalloc(&ctx->h_hres, 64 * sizeof(double), hipHostMallocMapped));
+                memset(ctx->h_hres, 0, 64 * sizeof(double));
+                HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_hres), ctx->h_hres, 0));
+            }
+            constexpr int HT = 50, NCH = 64;
+            if (!ctx->d_hmom || ctx->hmom_len < (int64_t)L * HT * HT) {
+                if (ctx->d_hmom) HIPCHK(ctx, hipFree(ctx->d_hmom));
+                ctx->d_hmom = nullptr;
+                HIPCHK(ctx, hipMalloc(&ctx->d_hmom, sizeof(double) * L * HT * HT));
+                ctx->hmom_len = (int64_t)L * HT * HT;
+                ctx->hmom_us = nullptr;
+            }
+            if (!ctx->hmom_bracket || ctx->hmom_us != &us || ctx->hmom_T != T) {
+                // second moments of mu: once per vlgp_hstep_begin bracket, else per call
+                hipLaunchKernelGGL((hstep_moment_kernel<HT>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, us.d_off,
+                                   us.mu, NCH, W + o_mpart);
+                hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, ctx->stream, NCH,
+                                   HT * HT, W + o_mpart, ctx->d_hmom);
+                HIPCHK(ctx, hipGetLastError());
+                ctx->hmom_us = &us;
+                ctx->hmom_T = T;
+            }
+            HRoundArgs R;
+            R.F = F;
+            R.n_eval = n_eval; R.nb = (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
+            R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
+            R.red = W + o_red;
+            const bool mailbox = ctx->world == 1;  // multi-rank: the sums go through the all-reduce first
+            R.host = mailbox ? ctx->d_hres : nullptr;
+            vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
+            hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
+            vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
+            HIPCHK(ctx, hipGetLastError());
+            if (mailbox) {
+                volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->h_hres + 48);
+                unsigned spins = 0;
+                while (*flag != (unsigned long long)R.seq) {
+                    if ((++spins & 0xfff) == 0) {  // a faulted kernel must not hang the host
+                        const hipError_t qe = hipStreamQuery(ctx->stream);
+                        if (qe == hipSuccess) break;
+                        if (qe != hipErrorNotReady)
+                            return vlgp_fail(ctx, VLGP_ERR_HIP, "H-step round kernel failed: %s", hipGetErrorString(qe));
+                    }
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                for (int i = 0; i < 3 * n_eval; ++i) hres[i] = ctx->h_hres[i];
+            } else {
+                CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
+                HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
         bool all_ok = true;
         for (int e = 0; e < n_eval; ++e) all_ok = all_ok && hres[2 * n_eval + e] != 0.0;
         if (all_ok) {

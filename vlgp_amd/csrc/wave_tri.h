@@ -254,7 +254,10 @@ __device__ __forceinline__ bool wave_chol_rows_duo(double (&r0)[T / 2], double (
             s1 = fma(-r1[i], v.x, s1);
             s1b = fma(-r1[i + 1], v.y, s1b);
             // bound the number of pivot-row loads in flight (registers): at most 8 b128 ahead
-            if ((i & 14) == 14) __builtin_amdgcn_sched_barrier(0);
+            if ((i & 14) == 14) {
+                asm volatile("" : "+v"(s0), "+v"(s0b), "+v"(s1), "+v"(s1b) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (k & 1) {
             const double lv = Lk[k - 1];
@@ -298,7 +301,10 @@ __device__ __forceinline__ void wave_tri_inverse_cols_duo(const double* Lp, cons
             a1 = fma(v.y, x0[j + 1], a1);
             if (j >= H) b0 = fma(v.x, x1[j - H < 0 ? 0 : j - H], b0);
             if (j + 1 >= H) b1 = fma(v.y, x1[j + 1 - H < 0 ? 0 : j + 1 - H], b1);
-            if ((j & 14) == 14) __builtin_amdgcn_sched_barrier(0);
+            if ((j & 14) == 14) {
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (i & 1) {
             const double lv = Li[i - 1];

@@ -213,6 +213,13 @@ class Engine:
                                                iptr(latents), dptr(logp), dptr(ll), dptr(dll)))
         return ll, dll
 
+    def hstep_begin(self, set_id, window):
+        """Start of one gp.optimize run: mu, w of the set stay fixed until hstep_end."""
+        self._ck(self.lib.vlgp_hstep_begin(self.h, set_id, int(window)))
+
+    def hstep_end(self):
+        self._ck(self.lib.vlgp_hstep_end(self.h))
+
     # -- constraints / norms ----------------------------------------------
     def apply_latent_map(self, set_id, mat, shift=None):
         mat = _f64(mat)

@@ -242,7 +242,11 @@ def optimize(trials, params, config):
         return -ll, -dll
 
     x0s = [np.log(np.array([sigma[l] ** 2, omega[l], gp_noise])) for l in range(L)]
-    xs = lockstep_minimize(batch, x0s, bounds)
+    eng.hstep_begin(sid, window)
+    try:
+        xs = lockstep_minimize(batch, x0s, bounds)
+    finally:
+        eng.hstep_end()
     for l in range(L):
         sig2, om, _ = np.exp(xs[l])
         if not np.any(np.isclose(om, config["omega_bound"])):  # gp.py:91-92
