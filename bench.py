@@ -204,10 +204,10 @@ def main():
     n_h, ms_h, u_h = prof["hstep"]
     if n_h:
         flops = work["hstep_flops_per_seg_eval"] * u_h / n_h
-        kernels["hstep_seg_fast"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
+        kernels["hstep_round_duo"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
                                      "units_per_launch": u_h / n_h, "unit": "TFLOP/s", "bound": "mfma",
                                      "achieved": flops / (ms_h / n_h * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                     "pmc_key": "hstep_seg_fast<50>"}
+                                     "pmc_key": "hstep_round_duo<50>"}
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     roofline = None
     if dominant:
