@@ -148,3 +148,26 @@ def test_initialize_matches_reference(golden):
     assert relerr(params["a"], g["a"]) < 1e-10 and relerr(params["b"], g["b"]) < 1e-12
     assert relerr(np.stack([t["mu"] for t in trials]), g["mu"]) < 1e-9
     assert trials[0]["x"].shape == tuple(g["x_shape"]) and np.all(trials[0]["w"] == 0)
+
+
+@pytest.mark.parametrize("shape", [(10, 200, 20, 3), (20, 300, 40, 10), (30, 400, 60, 5)])
+def test_factor_analysis_matches_sklearn(shape):
+    """vlgp_amd/fa.py restates sklearn's FactorAnalysis(random_state=0) from the second-moment matrix alone;
+    scikit-learn is the reference's own dependency for this step (vlgp/preprocess.py:18-19)."""
+    sk = pytest.importorskip("sklearn.decomposition")
+    from vlgp_amd import synth
+    from vlgp_amd.fa import fit_factor_analysis
+
+    n_trials, n_bins, N, L = shape
+    trials = synth.make_trials(n_trials, n_bins, N, L, seed=1)
+    y = np.concatenate([t["y"] for t in trials], axis=0)
+    rng = np.random.RandomState(3)
+    sub = y[rng.choice(y.shape[0], y.shape[0] // 10)]
+    fa = sk.FactorAnalysis(n_components=L, random_state=0)
+    z_ref = fa.fit_transform(sub)
+    own = fit_factor_analysis(sub, L, seed=0)
+    assert own.n_iter == fa.n_iter_
+    assert relerr(own.components, fa.components_) < 1e-9
+    assert relerr(own.noise_variance, fa.noise_variance_) < 1e-9
+    assert relerr(own.transform(sub), z_ref) < 1e-9
+    assert relerr(own.transform(y[:500]), fa.transform(y[:500])) < 1e-9

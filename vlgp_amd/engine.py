@@ -34,6 +34,14 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def _all_ones(x):
+    """x == 1 everywhere; O(1) for the zero-stride view preprocess.initialize hands out."""
+    x = np.asarray(x)
+    if x.size and all(st == 0 for st in x.strides):
+        return bool(x.flat[0] == 1.0)
+    return bool(np.all(x == 1.0))
+
+
 class Engine:
     """One GPU, one handle (include/vlgp_hip.h)."""
 
@@ -88,13 +96,15 @@ class Engine:
             raise ValueError("trial y has %d channels, engine was built for %d" % (y.shape[1], self.N))
         x = None
         if any(tr.get("x") is not None for tr in trials):
-            xs = [tr["x"] if tr.get("x") is not None else np.ones((tr["y"].shape[0], self.P, self.N))
-                  for tr in trials]
-            x = _f64(np.concatenate(xs, axis=0))
-            if x.shape[1:] != (self.P, self.N):
-                raise ValueError("trial x must be (T, %d, %d)" % (self.P, self.N))
-            if self.P == 1 and np.all(x == 1.0):
-                x = None  # the default regressors of preprocess.initialize: x == 1
+            given = [tr.get("x") for tr in trials]
+            for tr, xi in zip(trials, given):
+                if xi is not None and tuple(xi.shape) != (tr["y"].shape[0], self.P, self.N):
+                    raise ValueError("trial x must be (T, %d, %d)" % (self.P, self.N))
+            # the default regressors of preprocess.initialize are x == 1: detected per trial, never packed
+            if not (self.P == 1 and all(xi is None or _all_ones(xi) for xi in given)):
+                xs = [xi if xi is not None else np.ones((tr["y"].shape[0], self.P, self.N))
+                      for tr, xi in zip(trials, given)]
+                x = _f64(np.concatenate(xs, axis=0))
         elif self.P != 1:
             raise ValueError("trials without x need xdim == 1")
 

@@ -7,6 +7,8 @@ subsample drawn from the global NumPy RNG.
 """
 import numpy as np
 
+_ONE = np.ones(())
+
 _DEFAULTS = (
     ("constrain_loading", "fro"), ("constrain_latent", False), ("use_hessian", True),
     ("eps", 1e-8), ("tol", 1e-8), ("min_iter", 5), ("method", "VB"), ("learning_rate", 1.0),
@@ -48,11 +50,13 @@ def initialize(trials, params, config):
     pick = np.random.choice(y.shape[0], max(y.shape[0] // 10, 50))
     ydim = y.shape[-1]
     if params.get("transform") is None:
-        from sklearn.decomposition import FactorAnalysis
+        # FactorAnalysis(n_components=zdim, random_state=0) of preprocess.py:18-19, restated
+        # without scikit-learn (vlgp_amd/fa.py: same estimator, same random test vectors)
+        from .fa import fit_factor_analysis
 
-        fa = FactorAnalysis(n_components=zdim, random_state=0)
-        z = fa.fit_transform(y[pick, :])
-        a = fa.components_
+        fa = fit_factor_analysis(y[pick, :], zdim, seed=0)
+        z = fa.transform(y[pick, :])
+        a = fa.components
         params["transform"] = fa.transform
         if params.get("a") is None:
             params["a"] = a
@@ -61,12 +65,19 @@ def initialize(trials, params, config):
         if params.get("noise") is None:
             params["noise"] = np.var(y[pick, :] - z @ a, ddof=0, axis=0)
     to_latent = params["transform"]
+    mu_all = None
+    if not any(tr.get("mu") is not None for tr in trials):
+        mu_all = np.asarray(to_latent(y), dtype=float)  # one product over all rows instead of one per trial
+    row = 0
     for tr in trials:
         T = tr["y"].shape[0]
         if tr.get("mu") is None:
-            tr["mu"] = to_latent(tr["y"])
+            tr["mu"] = mu_all[row:row + T].copy() if mu_all is not None else to_latent(tr["y"])
+        row += T
         if tr.get("x") is None:
-            tr["x"] = np.ones((T, xdim, ydim))
+            # the reference allocates np.ones((T, xdim, ydim)) per trial (preprocess.py:43-44): the same
+            # values as a zero-stride read-only view -- 160 MB less to write and re-scan at C3
+            tr["x"] = np.broadcast_to(_ONE, (T, xdim, ydim))
         tr["w"] = np.zeros((T, zdim))
         tr["v"] = np.zeros((T, zdim))
 
