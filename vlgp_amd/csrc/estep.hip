@@ -460,6 +460,13 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
         if (handled) return VLGP_OK;
     }
 
+    // LONG units: all waves on the per-latent phases, MFMA builds (estep_long.hip)
+    if (us.Tmax > 64) {
+        int handled = 0;
+        CHK(launch_estep_long(ctx, us, A, &handled));
+        if (handled) return VLGP_OK;
+    }
+
     // SMALL: whole unit state lives in LDS
     int nw_s = L < 4 ? 4 : (L > 8 ? 8 : L);
     const int64_t small_d = common + 2LL * nw_s * 64 + 6LL * us.Tmax * L + gsz + lcsz + ints;

@@ -39,3 +39,7 @@ struct EstepArgs {
 // estep_fast.hip: sets *handled = 1 and launches when the fast kernel applies
 // (T <= 64, every effective rank <= 32, L <= 8, LDS fits), else leaves 0.
 int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);
+
+// estep_long.hip: long units (T > 64) with every wave of the workgroup on the per-latent phases;
+// declines (leaves *handled = 0) when rank > 50, L > 10 or the LDS budget does not fit.
+int launch_estep_long(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);
