@@ -175,6 +175,8 @@ def _random_problem(rng, lengths, N, L, P, n_gauss, rank=50):
     dict(lengths=[20, 45], N=1, L=2, P=1, g=0),          # one channel
     dict(lengths=[300, 150, 700], N=24, L=3, P=2, g=4),  # long ragged units, regressors
     dict(lengths=[50] * 3, N=40, L=10, P=1, g=10),       # ten latents
+    dict(lengths=[1000, 1000], N=30, L=5, P=1, g=6),     # full-length trials: rank-exhausted prior (r = 50)
+    dict(lengths=[65, 128, 1200], N=18, L=8, P=1, g=0),  # long-unit kernel, eight latents, just above 64 bins
 ])
 def test_estep_random_vs_oracle(V, case):
     import zlib
@@ -265,6 +267,42 @@ def test_hstep_objective_golden(V, golden):
             assert abs(ll[l, i] - g["ll"][l, i]) <= STAGE * abs(g["ll"][l, i]), (l, i)
             assert abs(dll[l, i, 1] - g["dll"][l, i, 1]) <= STAGE * max(abs(g["dll"][l, i, 1]), 1e-3 * abs(g["ll"][l, i])), (l, i)
             assert dll[l, i, 0] == 0 and dll[l, i, 2] == 0
+
+
+def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
+    """vlgp_hstep_begin/_end only caches the second moments of mu: same numbers with and without the
+    bracket, through the three-launch form, and after the set changes inside a bracket-free sequence."""
+    g = golden("hstep")
+    M, T, L = g["mu"].shape
+    rng = np.random.default_rng(5)
+    units = [{"y": np.zeros((T, 2)), "mu": g["mu"][m].copy(), "w": g["w"][m].copy(),
+              "v": np.zeros((T, L))} for m in range(M)]
+    lat = np.arange(L)
+    logp = np.tile(g["logp"][1], (L, 1))
+    with V.Engine(2, L, 1, 50) as eng:
+        eng.upload(0, units)
+        plain = eng.hstep_objective(0, T, 1.0, lat, logp)
+        eng.hstep_begin(0, T)
+        first = eng.hstep_objective(0, T, 1.0, lat, logp)
+        again = eng.hstep_objective(0, T, 1.0, lat, logp + 0.0)
+        eng.hstep_end()
+        monkeypatch.setenv("VLGP_HSTEP_UNFUSED", "1")
+        unfused = eng.hstep_objective(0, T, 1.0, lat, logp)
+        monkeypatch.delenv("VLGP_HSTEP_UNFUSED")
+        for other in (first, again):
+            assert np.array_equal(other[0], plain[0]) and np.array_equal(other[1], plain[1])
+        assert relerr(unfused[0], plain[0]) < 1e-12 and relerr(unfused[1], plain[1]) < 1e-10
+        # new mu: the cached moments must not survive the upload
+        for u in units:
+            u["mu"] = u["mu"] + 0.1 * rng.standard_normal(u["mu"].shape)
+        eng.upload(0, units)
+        moved = eng.hstep_objective(0, T, 1.0, lat, logp)
+    t = np.arange(T) * 1.0
+    for l in range(L):
+        ll, dll = O.gp_objective(logp[l], t, np.stack([u["mu"][:, l] for u in units], 1),
+                                 np.stack([u["w"][:, l] for u in units], 1))
+        assert abs(moved[0][l] - ll) <= STAGE * abs(ll)
+        assert abs(moved[1][l, 1] - dll[1]) <= STAGE * max(abs(dll[1]), 1e-3 * abs(ll))
 
 
 def test_hstep_optimize_golden(V, golden):
