@@ -21,7 +21,7 @@
 #include "ctx.h"
 #include "fast_exp.h"
 
-#define M_TILE 64
+#define M_TILE 256
 
 enum { K_PREP = 0, K_NEWTON = 1, K_NOISE1 = 2, K_NOISE2 = 3 };
 
@@ -55,7 +55,7 @@ static inline int nstat_rt(int L, int P, int kind) {
 }
 
 template <int LT, int PT, int KIND>
-__global__ void __launch_bounds__(512) mstep_accum(MArgs A) {
+__global__ void __launch_bounds__(512, 4) mstep_accum(MArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NA = nacc<LT, PT, KIND>();
     const int N = A.N, L = A.L, P = A.P, CT = A.CT, S = A.S;
@@ -476,7 +476,7 @@ static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
     if (G > cap) G = cap;
     if (G < 1) G = 1;
     g.rows_per_wg = (int)((rows + G - 1) / G);
-    g.rows_per_wg = ((g.rows_per_wg + M_TILE - 1) / M_TILE) * M_TILE;
+    g.rows_per_wg = ((g.rows_per_wg + 7) / 8) * 8;  // an even split over the workgroups: every CU gets the same share
     g.G = (int)((rows + g.rows_per_wg - 1) / g.rows_per_wg);
     g.lds = (size_t)(2 * M_TILE * L + g.S * g.CT) * 8;
     return g;
