@@ -171,3 +171,41 @@ def test_factor_analysis_matches_sklearn(shape):
     assert relerr(own.noise_variance, fa.noise_variance_) < 1e-9
     assert relerr(own.transform(sub), z_ref) < 1e-9
     assert relerr(own.transform(y[:500]), fa.transform(y[:500])) < 1e-9
+
+
+def test_sample_posterior_matches_reference_covariance():
+    """api.sample_posterior through the low-rank factor: mean and covariance of the draws equal the
+    reference's (K^-1 + W)^-1 (vlgp/api.py:156-166) to sampling error."""
+    import vlgp_amd
+
+    rng = np.random.default_rng(0)
+    T, L = 40, 2
+    omega, sigma = np.array([4e-3, 2e-2]), np.array([1.0, 0.7])
+    chol = O.build_prior([T], omega, sigma, 50)
+    trial = {"mu": rng.standard_normal((T, L)), "w": rng.random((T, L)) * 3.0}
+    n = 200000
+    draws = vlgp_amd.sample_posterior(trial, {"cholesky": chol}, n, rng=np.random.default_rng(1))
+    assert draws.shape == (n, T, L)
+    for l in range(L):
+        G = chol[T][l]
+        K = G @ G.T
+        want = np.linalg.inv(np.linalg.inv(K + 1e-6 * np.eye(T)) + np.diag(trial["w"][:, l]))
+        got = np.cov(draws[:, :, l].T)
+        assert np.abs(got - want).max() < 0.02 * np.abs(want).max() + 2e-3
+        assert np.abs(draws[:, :, l].mean(0) - trial["mu"][:, l]).max() < 0.01
+
+
+def test_save_load_round_trip(tmp_path):
+    from vlgp_amd import load, save
+
+    result = {"params": {"a": np.arange(6.0).reshape(2, 3), "omega": np.array([1e-3, 2e-3])},
+              "config": {"window": 50, "method": "VB"}, "trials": [{"ID": 0, "mu": np.ones((4, 2))}]}
+    save(result, tmp_path / "fit", "npy")
+    back = load(tmp_path / "fit.npy")
+    assert back["config"] == result["config"] and np.array_equal(back["params"]["a"], result["params"]["a"])
+    assert np.array_equal(back["trials"][0]["mu"], np.ones((4, 2)))
+    save({"a": result["params"]["a"], "omega": result["params"]["omega"]}, tmp_path / "arrs", "npz")
+    arrs = load(tmp_path / "arrs.npz")
+    assert set(arrs) == {"a", "omega"} and np.array_equal(arrs["omega"], result["params"]["omega"])
+    with pytest.raises(FileNotFoundError):
+        load(tmp_path / "missing.npy")

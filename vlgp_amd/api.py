@@ -186,3 +186,36 @@ def transform(trials, params, config, device=0):
         E.infer(dev, params, config)
         dev.pull()
     return trials
+
+
+def sample_posterior(trial, params, nsamples, reg=1e-6, rng=None):
+    """Draw ``nsamples`` latent trajectories from the variational posterior of one trial
+    (vlgp/api.py:142-168): independent Gaussians per latent with mean ``mu[:, l]`` and covariance
+    ``(K_l^-1 + W_l)^-1``, ``K_l = G_l G_l'`` the low-rank prior of this trial length.
+
+    The reference forms the T x T matrices (two dense inverses per latent plus
+    ``multivariate_normal``'s SVD: O(T^3)).  With ``H = G'WG`` (r x r) the same covariance is
+    ``G (I + H)^-1 G'`` (the reference's ``reg`` regulariser set to zero; it only exists to make
+    ``K`` invertible), so a draw is ``mu + G L^-T eps`` with ``L L' = I + H`` and ``eps ~ N(0, I_r)``:
+    O(T r^2) per latent.  ``reg`` is accepted and ignored.  Draws come from ``rng`` (a
+    ``numpy.random.Generator``/``RandomState``) or, like the reference, the global NumPy state.
+
+    Returns an array of shape (nsamples, bins, nfactors)."""
+    del reg
+    mu = np.asarray(trial["mu"], dtype=float)
+    w = np.asarray(trial["w"], dtype=float)
+    nbins, nfactors = mu.shape
+    G = np.asarray(params["cholesky"][nbins], dtype=float)
+    normal = (rng.standard_normal if hasattr(rng, "standard_normal") else np.random.standard_normal) \
+        if rng is not None else np.random.standard_normal
+    samples = np.empty((nsamples, nbins, nfactors))
+    for l in range(nfactors):
+        Gl = G[l]
+        keep = np.any(Gl != 0.0, axis=0)  # columns ichol_gauss left at zero carry nothing
+        Gl = Gl[:, keep]
+        H = Gl.T @ (w[:, [l]] * Gl)
+        Lf = np.linalg.cholesky(np.eye(H.shape[0]) + H)
+        eps = normal((H.shape[0], nsamples))
+        dev = Gl @ np.linalg.solve(Lf.T, eps)  # cov = G (I + H)^-1 G'
+        samples[:, :, l] = mu[:, l][None, :] + dev.T
+    return samples

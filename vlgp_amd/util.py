@@ -40,3 +40,34 @@ def cut_trials(trials, params, config):
             sl = slice(int(s), int(s) + window)
             segs.append({k: tr[k][sl] for k in ("y", "x", "mu", "w", "v")})
     return np.array(segs, dtype=object)
+
+
+def save(result, path, ext="npy"):
+    """Store a ``fit`` result (vlgp/util.py:181-190): one pickled object in ``.npy``, or the
+    top-level keys as arrays in ``.npz``."""
+    import pathlib
+
+    path = pathlib.Path(path)
+    if ext == "npy":
+        np.save(path.with_suffix(".npy"), result, allow_pickle=True)
+    elif ext == "npz":
+        np.savez(path.with_suffix(".npz"), **result)
+    else:
+        raise NotImplementedError("unknown file type {}".format(ext))
+
+
+def load(path):
+    """Read what ``save`` wrote (vlgp/util.py:193-208).  The reference calls ``np.load`` without
+    ``allow_pickle``, which NumPy >= 1.16.3 refuses for the pickled ``.npy`` it writes itself;
+    pickles are allowed here because the file format is one."""
+    import pathlib
+
+    path = pathlib.Path(path)
+    if not path.exists():
+        raise FileNotFoundError(path.as_posix())
+    if path.suffix == ".npy":
+        return np.load(path, allow_pickle=True)[()]
+    if path.suffix == ".npz":
+        with np.load(path, allow_pickle=True) as f:
+            return {k: (f[k][()] if f[k].dtype == object and f[k].shape == () else f[k]) for k in f.files}
+    raise NotImplementedError("unknown file type {}".format(path.suffix))
