@@ -163,6 +163,11 @@ int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const doubl
 /* out[0] = sum mu^2, out[1] = sum dmu^2 over the set (and over ranks):
  * the convergence test of core.vem (vlgp/core.py:300-305,350-354). */
 int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]);
+/* Initial latents of preprocess.initialize (vlgp/preprocess.py:30-41) on the device: for every row of the
+ * set mu = y . proj - shift, proj (N, L) row-major the posterior-mean map of the factor-analysis fit
+ * (FactorAnalysis.transform: (y - mean) W'Psi^-1 (I + W Psi^-1 W')^-1), shift = mean . proj (L).
+ * colsum (N, may be NULL) receives the column sums of y over THIS rank's rows (b = log mean y). */
+int vlgp_project_units(vlgp_ctx* ctx, int set, const double* proj, const double* shift, double* colsum);
 /* Column sums over the set (and ranks): sum1[l] = sum mu[:,l], sum2[l] = sum mu[:,l]^2,
  * *count = number of rows.  For core.constrain_latent. */
 int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double* sum2, double* count);

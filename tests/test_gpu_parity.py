@@ -567,3 +567,32 @@ def test_fit_other_windows_and_all_gaussian(V, window, lik_gauss):
     assert relerr(got["params"]["a"], params["a"]) < 1e-5
     assert relerr(got["params"]["b"], params["b"]) < 1e-5
     assert relerr(got["params"]["noise"], params["noise"]) < 1e-5
+
+
+def test_deferred_initialisation_matches_host(V):
+    """fit's device-side half of preprocess.initialize (mu = transform(y), b = log mean y through
+    vlgp_project_units) against the host path, which test_host_logic pins to the reference."""
+    from vlgp_amd import synth
+    from vlgp_amd.preprocess import get_config, get_params, initialize
+
+    n_trials, n_bins, N, L = 12, 130, 37, 4
+    host = synth.make_trials(n_trials, n_bins, N, L, seed=3)
+    dev = synth.make_trials(n_trials, n_bins, N, L, seed=3)
+    cfg = get_config()
+    ph = get_params(host, L, omega_bound=cfg["omega_bound"])
+    pd = get_params(dev, L, omega_bound=cfg["omega_bound"])
+    np.random.seed(11)
+    assert initialize(host, ph, cfg) is None
+    np.random.seed(11)
+    plan = initialize(dev, pd, cfg, defer_latent=True)
+    assert plan is not None and plan["need_b"] and "b" not in {k for k, v in pd.items() if v is not None}
+    assert relerr(pd["a"], ph["a"]) < 1e-12 and relerr(pd["noise"], ph["noise"]) < 1e-12
+    with V.Engine(N, L, 1, 50) as eng:
+        from vlgp_amd.preprocess import fill_trials
+        fill_trials(dev)
+        eng.upload(0, dev)
+        colsum = eng.project_latent(0, plan["proj"], plan["shift"])
+        mu = eng.download(0, keys=("mu",))["mu"]
+    b = np.log(np.maximum(colsum[None, :] / plan["rows"], cfg["eps"]))
+    assert relerr(b, ph["b"]) < 1e-13
+    assert relerr(mu, np.concatenate([t["mu"] for t in host])) < 1e-12

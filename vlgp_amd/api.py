@@ -66,23 +66,28 @@ class FitSession:
 
         if echo:
             echo("Initializing")
-        initialize(trials, params, config)
-        if echo:
-            echo("Initialized")
-        fill_params(params)
+        plan = initialize(trials, params, config, defer_latent=True)
         fill_trials(trials)
-        for key in ("a", "b", "noise", "omega", "sigma"):
-            params[key] = np.array(params[key], dtype=float)
 
         eng = E.Engine(params["ydim"], params["zdim"], params["xdim"], params["rank"],
                        np.asarray(params["likelihood"]) == "gaussian", device=device)
         self.eng = eng
         try:
+            eng.upload(SET_TRIALS, trials)
+            if plan is not None:
+                # the two full passes over y of preprocess.initialize, on the device: mu = transform(y), b = log mean y
+                colsum = eng.project_latent(SET_TRIALS, plan["proj"], plan["shift"])
+                if plan["need_b"]:
+                    params["b"] = np.log(np.maximum(colsum[None, :] / plan["rows"], config["eps"]))
+            if echo:
+                echo("Initialized")
+            fill_params(params)
+            for key in ("a", "b", "noise", "omega", "sigma"):
+                params[key] = np.array(params[key], dtype=float)
             if comm is not None and comm.world > 1:
                 comm.attach(eng)
                 self._replicate_params()
             eng.set_params(params["a"], params["b"], params["noise"])
-            eng.upload(SET_TRIALS, trials)
             self.dev_trials = E.DeviceTrials(trials, eng, SET_TRIALS)
             E.make_cholesky(self.dev_trials, params, config)
             E.update_w(self.dev_trials, params, config)

@@ -970,6 +970,33 @@ extern "C" int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double*
     return VLGP_OK;
 }
 
+extern "C" int vlgp_project_units(vlgp_ctx* ctx, int set, const double* proj, const double* shift, double* colsum) {
+    NEED_CTX(ctx);
+    ctx->hmom_us = nullptr;  // mu changes
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    CHK(vlgp_join_m(ctx));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (!proj || !shift) return vlgp_fail(ctx, VLGP_ERR_ARG, "null projection");
+    if (us->alias) return vlgp_fail(ctx, VLGP_ERR_STATE, "project the owning set, not an aliased cut");
+    const int N = ctx->N, L = ctx->L;
+    const int64_t G = (us->rows + 63) / 64;
+    const int64_t o_proj = 0, o_shift = (int64_t)N * L, o_out = o_shift + L + (L & 1), o_part = o_out + N + (N & 1);
+    CHK(vlgp_ensure_work(ctx, o_part + G * N));
+    CHK(vlgp_ensure_pinned(ctx, o_out + N + 8));
+    memcpy(ctx->h_pinned, proj, sizeof(double) * N * L);
+    memcpy(ctx->h_pinned + o_shift, shift, sizeof(double) * L);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_pinned, sizeof(double) * (o_shift + L), hipMemcpyHostToDevice,
+                               ctx->stream));
+    CHK(launch_project(ctx, *us, ctx->d_work + o_proj, ctx->d_work + o_shift, ctx->d_work + o_part,
+                       ctx->d_work + o_out));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned + o_out, ctx->d_work + o_out, sizeof(double) * N, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (colsum) memcpy(colsum, ctx->h_pinned + o_out, sizeof(double) * N);
+    return VLGP_OK;
+}
+
 // ---- measurement -------------------------------------------------------------
 extern "C" int vlgp_debug_phase_clock(vlgp_ctx* ctx, int on, uint64_t out[8]) {
     NEED_CTX(ctx);

@@ -158,5 +158,7 @@ int launch_compact_prior(vlgp_ctx* ctx, Prior& pr);  // d_full -> rl, d_compact
 int launch_xb(vlgp_ctx* ctx, UnitSet& us);
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
 int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out /* 2L+2: sum1, sum2, |mu|^2, |dmu|^2 */);
+int launch_project(vlgp_ctx* ctx, UnitSet& us, const double* d_proj, const double* d_shift, double* d_part,
+                   double* d_out);  // mu = y proj - shift; d_out = column sums of y
 int launch_gather(vlgp_ctx* ctx, UnitSet& src, UnitSet& dst, int window);
 int launch_scatter(vlgp_ctx* ctx, UnitSet& cut, UnitSet& dst, int window);

@@ -126,3 +126,72 @@ int launch_scatter(vlgp_ctx* ctx, UnitSet& cut, UnitSet& dst, int window) {
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Initial latents (preprocess.initialize, vlgp/preprocess.py:30-41): mu = y P - shift with P the
+// (N, L) posterior-mean map of the factor-analysis fit, plus the column sums of y (for b =
+// log mean y).  One workgroup per 64 rows: the y tile goes through LDS once (coalesced), thread
+// (row, latent) takes a dot product, thread n a column sum; per-workgroup column sums are added
+// in a fixed order by project_colsum_kernel.
+// ---------------------------------------------------------------------------
+#define PROJ_ROWS 64
+__global__ void __launch_bounds__(512)
+project_kernel(int N, int L, int64_t rows, const double* y, const double* proj, const double* shift, double* mu,
+               double* part) {
+    extern __shared__ double ys[];  // PROJ_ROWS x (N | 1)
+    const int ld = N | 1;
+    const int64_t r0 = (int64_t)blockIdx.x * PROJ_ROWS;
+    const int nr = (int)((rows - r0) < PROJ_ROWS ? (rows - r0) : PROJ_ROWS);
+    for (int i = threadIdx.x; i < nr * N; i += blockDim.x) {
+        const int r = i / N, n = i - r * N;
+        ys[r * ld + n] = y[r0 * N + i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * L; i += blockDim.x) {
+        const int r = i % nr, l = i / nr;  // consecutive threads take consecutive rows: conflict-free LDS (odd ld)
+        double s0 = 0.0, s1 = 0.0;
+        int n = 0;
+        for (; n + 1 < N; n += 2) {
+            s0 = fma(ys[r * ld + n], proj[n * L + l], s0);
+            s1 = fma(ys[r * ld + n + 1], proj[(n + 1) * L + l], s1);
+        }
+        if (n < N) s0 = fma(ys[r * ld + n], proj[n * L + l], s0);
+        mu[(r0 + r) * L + l] = (s0 + s1) - shift[l];
+    }
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < nr; ++r) s += ys[r * ld + n];
+        part[(int64_t)blockIdx.x * N + n] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) project_colsum_kernel(int N, int G, const double* part, double* out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+        s0 += part[(int64_t)g * N + n];
+        s1 += part[(int64_t)(g + 1) * N + n];
+        s2 += part[(int64_t)(g + 2) * N + n];
+        s3 += part[(int64_t)(g + 3) * N + n];
+    }
+    for (; g < G; ++g) s0 += part[(int64_t)g * N + n];
+    out[n] = (s0 + s1) + (s2 + s3);
+}
+
+// d_in: proj (N*L) then shift (L) at the start of d_work; the column sums land in d_out (N doubles)
+int launch_project(vlgp_ctx* ctx, UnitSet& us, const double* d_proj, const double* d_shift, double* d_part,
+                   double* d_out) {
+    const int N = ctx->N, L = ctx->L;
+    const int G = (int)((us.rows + PROJ_ROWS - 1) / PROJ_ROWS);
+    const size_t lds = (size_t)PROJ_ROWS * (N | 1) * 8;
+    if (lds > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(project_kernel, dim3(G), dim3(512), lds, ctx->stream, N, L, us.rows, us.y, d_proj, d_shift,
+                       us.mu, d_part);
+    hipLaunchKernelGGL(project_colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N, G, d_part, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}

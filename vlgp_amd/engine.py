@@ -223,6 +223,16 @@ class Engine:
                                                iptr(latents), dptr(logp), dptr(ll), dptr(dll)))
         return ll, dll
 
+    def project_latent(self, set_id, proj, shift):
+        """mu = y @ proj - shift on the device for every row of the set; returns the column sums of y."""
+        proj = _f64(proj)
+        shift = _f64(shift)
+        if proj.shape != (self.N, self.L) or shift.shape != (self.L,):
+            raise ValueError("projection must be (N, L) with an (L,) shift")
+        colsum = np.empty(self.N)
+        self._ck(self.lib.vlgp_project_units(self.h, set_id, dptr(proj), dptr(shift), dptr(colsum)))
+        return colsum
+
     def hstep_begin(self, set_id, window):
         """Start of one gp.optimize run: mu, w of the set stay fixed until hstep_end."""
         self._ck(self.lib.vlgp_hstep_begin(self.h, set_id, int(window)))

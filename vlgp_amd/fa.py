@@ -57,6 +57,15 @@ class FactorModel:
         self._proj = wpsi.T @ cov_z                 # (n_features, k): posterior-mean map
         self._shift = mean @ self._proj
 
+    @property
+    def projection(self):
+        """(n_features, k) map P with transform(X) = X @ P - shift."""
+        return self._proj
+
+    @property
+    def shift(self):
+        return self._shift
+
     def transform(self, X):
         """Posterior mean of the factors, E[z | x] = (x - mean) W'Psi^-1 (I + W Psi^-1 W')^-1."""
         return np.asarray(X, dtype=float) @ self._proj - self._shift
