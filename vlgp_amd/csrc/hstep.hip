@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) hstep_moment_reduce(int nchunk, int TT, c
 // Lane j owns row j of K^-1 (kj) and of C (cj); row b of K^-1 and dK are LDS broadcasts:
 //     gq = sum_j sum_b (C K^-1)[j][b] (K^-1 dK)[j][b].
 // Kl: T*T doubles of LDS, dk2: 128 doubles of LDS (dK mirrored: dk2[63 + d] = dK[|d|]).
-template <int T>
+template <int T, bool KL_LDS = true>
 __device__ __forceinline__ void hstep_prep_moments(const HFastArgs& A, const double* mom, double* qsum, int e,
                                                    int lane, double* Kl, double* dk2, const double* dkv) {
     static_assert(T % 2 == 0 && T <= 64, "window must be even and at most 64");
@@ -685,7 +685,7 @@ __device__ __forceinline__ void hstep_prep_moments(const HFastArgs& A, const dou
         kj[k] = Ki[k];  // written by this very lane in hstep_prep_body
         cj[k] = Cj[k];
     }
-    if (lane < T) {
+    if (KL_LDS && lane < T) {
 #pragma unroll
         for (int k = 0; k < T; ++k) Kl[lane * T + k] = kj[k];
     }
@@ -697,7 +697,8 @@ __device__ __forceinline__ void hstep_prep_moments(const HFastArgs& A, const dou
     for (int k = 0; k < T; ++k) quad = fma(kj[k], cj[k], quad);
 #pragma nounroll
     for (int b = 0; b < T; ++b) {
-        const double* Kb = Kl + b * T;
+        // row b of K^-1: LDS copy, or (single-wave blocks, no room) the global one this wave just wrote
+        const double* Kb = KL_LDS ? Kl + b * T : A.kinv + (int64_t)e * T * T + b * T;
         const double* Db = dk2 + (63 - b);  // Db[a] = dK[|a - b|]
         double e0 = 0.0, e1 = 0.0, f0 = 0.0, f1 = 0.0;
 #pragma unroll
@@ -813,15 +814,19 @@ struct HRoundArgs {
     double* host;          // mapped pinned copy of `red` + sequence word at [48], or null
 };
 
-template <int T>
-__global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
+template <int T, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
     constexpr int H = T / 2;
     constexpr int PK = tri_packed_size(T);
-    constexpr int NW = 2;
-    static_assert(4 * PK >= hstep_prep_lds<T>() + 1 + T * T, "K block: factor + K^-1 must fit in the task buffers");
+    // NW = 2: two waves, four tasks, 47 KB -> three blocks per CU (six waves).
+    // NW = 1: one wave, two tasks, 22.9 KB -> seven blocks per CU (seven waves): the per-task vectors
+    // shrink to T entries and the reciprocal diagonal of task 0 reuses kv, dead after A is built.
+    constexpr int VS = NW == 1 ? T : 64;
+    static_assert(2 * NW * PK >= hstep_prep_lds<T>() + 2 + (NW == 1 ? 256 : T * T), "K block scratch must fit");
     __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PK];
-    __shared__ double vec_all[NW][2][4][64];
-    __shared__ double kv[64], dkv[64];
+    __shared__ double sw_all[NW][2][VS];
+    __shared__ double invd_all[NW == 1 ? 1 : 2 * NW][VS];
+    __shared__ double kv[VS], dkv[64];
     __shared__ double part[2 * NW][2];
     __shared__ int s_last;
     const HFastArgs& A = R.F;
@@ -830,9 +835,17 @@ __global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
         const int e = blockIdx.x;
         if (wid == 0) {
             double* base = &Lp_all[0][0][0];
-            hstep_prep_body<T>(A, e, lane, base, kv, dkv);
-            tri_wave_sync();
-            hstep_prep_moments<T>(A, R.mom, R.qsum, e, lane, base + ((hstep_prep_lds<T>() + 1) & ~1), &vec_all[0][0][0][0], dkv);
+            double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);
+            if constexpr (NW == 1) {
+                // kv / dkv of the K block need 64 entries each: carve them (and dk2) from the second task buffer
+                hstep_prep_body<T>(A, e, lane, base, extra, extra + 64);
+                tri_wave_sync();
+                hstep_prep_moments<T, false>(A, R.mom, R.qsum, e, lane, nullptr, extra + 128, extra + 64);
+            } else {
+                hstep_prep_body<T>(A, e, lane, base, extra + T * T, extra + T * T + 64);
+                tri_wave_sync();
+                hstep_prep_moments<T, true>(A, R.mom, R.qsum, e, lane, extra, extra + T * T + 128, extra + T * T + 64);
+            }
         }
     } else {
         const int b = blockIdx.x - R.n_eval;
@@ -843,7 +856,7 @@ __global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
             const double d = lane * A.dt, d2 = d * d;
             const double kk = sigmasq * exp(-omega * d2);
-            kv[lane] = kk + (lane == 0 ? eps : 0.0);
+            if (lane < VS) kv[lane] = kk + (lane == 0 ? eps : 0.0);
             dkv[lane] = -kk * d2 * omega;
         }
         __syncthreads();
@@ -852,8 +865,10 @@ __global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
             const bool valid = seg < A.M;
             const bool in = q < H && valid;
             double* Lp = Lp_all[wid][h];
-            double* sw = vec_all[wid][h][0];
-            double* invd = vec_all[wid][h][3];
+            double* sw = sw_all[wid][h];
+            // NW = 1: task 0 parks its reciprocal diagonal in kv (both halves finish reading kv -- the A
+            // build below -- before either writes invd in the factorisation: same wave, program order)
+            double* invd = NW == 1 ? (h == 0 ? kv : invd_all[0]) : invd_all[wid * 2 + h];
             const int l = A.latent[e];
             const int64_t r0row = A.off[valid ? seg : 0];
             double w0 = 0.0, w1 = 0.0;
@@ -893,8 +908,13 @@ __global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
     if (threadIdx.x == 0) {
         if ((int)blockIdx.x >= R.n_eval) {
             double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
-            o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-            o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+            if constexpr (NW == 1) {
+                o[0] = part[0][0] + part[1][0];
+                o[1] = part[0][1] + part[1][1];
+            } else {
+                o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+                o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+            }
         }
         const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         s_last = ticket == gridDim.x - 1;
@@ -902,12 +922,13 @@ __global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
     __syncthreads();
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    constexpr int NT = 64 * NW;
     double* rs = &Lp_all[0][0][0];  // 2 x 128 partials
     for (int e = 0; e < R.n_eval; ++e) {
         const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
-        for (int m = threadIdx.x; m < R.nb; m += 128) {
+        for (int m = threadIdx.x; m < R.nb; m += NT) {
             const double2 v = in[m];
             s0 += v.x;
             s1 += v.y;
@@ -916,7 +937,7 @@ __global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
         rs[threadIdx.x] = s0;
         rs[128 + threadIdx.x] = s1;
         __syncthreads();
-        for (int o = 64; o > 0; o >>= 1) {
+        for (int o = NT / 2; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) {
                 rs[threadIdx.x] += rs[threadIdx.x + o];
                 rs[128 + threadIdx.x] += rs[128 + threadIdx.x + o];
@@ -1025,13 +1046,19 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             }
             HRoundArgs R;
             R.F = F;
-            R.n_eval = n_eval; R.nb = (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
+            // single-wave blocks put a seventh wave on every CU but measured no faster (235 vs 260 us at three
+            // evaluations): the kernel is bound by the CU's LDS pipe, not by occupancy.  Kept for experiments.
+            static const bool one_wave = getenv("VLGP_HSTEP_NW1") != nullptr;
+            R.n_eval = n_eval; R.nb = one_wave ? (M + 1) / 2 : (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
             const bool mailbox = ctx->world == 1;  // multi-rank: the sums go through the all-reduce first
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-            hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
+            if (one_wave)
+                hipLaunchKernelGGL((hstep_round_duo<50, 1>), dim3(n_eval + n_eval * R.nb), dim3(64), 0, ctx->stream, R);
+            else
+                hipLaunchKernelGGL((hstep_round_duo<50, 2>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
             HIPCHK(ctx, hipGetLastError());
             if (mailbox) {
