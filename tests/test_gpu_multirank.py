@@ -77,3 +77,18 @@ def test_bench_launch_line_two_ranks_one_gpu():
     assert len(lines) == 1  # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+
+
+def test_rccl_failure_falls_back_to_shared_memory():
+    """Two ranks on ONE device make ncclCommInitRank fail on both ranks ("duplicate GPU"): the job must
+    carry on through the shared-memory all-reduce (Comm.attach) and say so, not abort."""
+    env = {k: v for k, v in os.environ.items() if k != "VLGP_COMM_TRANSPORT"}
+    env["VLGP_DEVICE"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C1"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert "using the shared-memory all-reduce" in done.stderr
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2

@@ -8,6 +8,10 @@ import os
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's (and any cross-process
+# device-memory sharing's) hipIpcGetMemHandle fails; it must be in the environment before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlgp_hip.so")
 

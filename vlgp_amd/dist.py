@@ -81,23 +81,70 @@ class Comm:
         return c
 
     def attach(self, engine):
+        """Bind ``engine`` to this launch's communicators (main lane + M-step lane).
+
+        RCCL is the transport.  If it cannot be used on this node -- ``librccl.so`` missing on some
+        rank, or ``ncclCommInitRank`` failing (on this pool e.g. ``hipIpcGetMemHandle: invalid
+        argument`` when ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is not exported) -- every rank switches to the
+        host shared-memory all-reduce of ``libvlgp_hip.so`` (``VLGP_COMM_TRANSPORT=shm``: same call
+        sites, same deterministic rank-order sum) and says so on stderr, instead of aborting the job.
+        The ranks agree on the first case through per-rank status files before anyone enters
+        ``ncclCommInitRank`` (a rank that went ahead alone would block forever)."""
         if self.world == 1 and not os.environ.get("VLGP_FORCE_RCCL"):
             return
-        from .engine import unique_id
+        import sys
+
+        from .engine import VlgpError, unique_id
 
         base = self.path or _rendezvous_path()
-        if self.uid is None:
-            self.uid = exchange_unique_id(self.rank, self.world, unique_id, base)
-        if getattr(self, "uid_aux", None) is None:  # second communicator: the M-step lane
-            self.uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + ".aux")
-        engine.comm_init(self.uid, self.rank, self.world, self.uid_aux)
+        if os.environ.get("VLGP_COMM_TRANSPORT") != "shm" and self.world > 1 and self.uid is None:
+            try:
+                unique_id()  # probes dlopen(librccl) + ncclGetUniqueId on this rank
+                mine = b"ok"
+            except VlgpError:
+                mine = b"no"
+            votes = [exchange_unique_id(0 if r == self.rank else 1, 2, lambda: mine, "%s.vote%d" % (base, r))
+                     for r in range(self.world)]
+            if any(v != b"ok" for v in votes):
+                if self.rank == 0:
+                    print("vlgp_amd: RCCL unavailable on some rank, using the shared-memory all-reduce",
+                          file=sys.stderr, flush=True)
+                os.environ["VLGP_COMM_TRANSPORT"] = "shm"
+
+        def connect(tag):
+            uid = exchange_unique_id(self.rank, self.world, unique_id, base + tag)
+            uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + tag + ".aux")
+            engine.comm_init(uid, self.rank, self.world, uid_aux)
+            return uid, uid_aux
+
+        tags = [""]
+        try:
+            if self.uid is not None:  # ids handed in by the caller
+                if getattr(self, "uid_aux", None) is None:
+                    self.uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + ".aux")
+                engine.comm_init(self.uid, self.rank, self.world, self.uid_aux)
+            else:
+                self.uid, self.uid_aux = connect("")
+        except VlgpError as err:
+            if os.environ.get("VLGP_COMM_TRANSPORT") == "shm":
+                raise
+            print("vlgp_amd: rank %d: RCCL initialisation failed (%s); using the shared-memory all-reduce"
+                  % (self.rank, err), file=sys.stderr, flush=True)
+            os.environ["VLGP_COMM_TRANSPORT"] = "shm"
+            tags.append(".shm")
+            self.uid, self.uid_aux = connect(".shm")
         engine.barrier()
         if self.rank == 0:
-            for path in (base, base + ".aux"):
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
+            for tag in tags:
+                for path in (base + tag, base + tag + ".aux"):
+                    try:
+                        os.remove(path)
+                    except OSError:
+                        pass
+        try:
+            os.remove("%s.vote%d" % (base, self.rank))
+        except OSError:
+            pass
 
     def shard(self, items):
         return shard(items, self.rank, self.world)
