@@ -207,7 +207,7 @@ def main():
         kernels["hstep_round_duo"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
                                      "units_per_launch": u_h / n_h, "unit": "TFLOP/s", "bound": "mfma",
                                      "achieved": flops / (ms_h / n_h * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                     "pmc_key": "hstep_round_duo<50>"}
+                                     "pmc_key": "hstep_round_duo<50, 2>"}
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     roofline = None
     if dominant:

@@ -15,7 +15,8 @@ def collect(path, name):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            kname = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            acc[kname.split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return acc
 
 
