@@ -566,7 +566,6 @@ int launch_estep_long(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     A.lc_global = us.d_scratch + need;  // here: per-unit partial-sum area
     A.lc_stride = part;
     A.rg = N >= 16 ? 4 : 1;  // lanes per row in the (T x N) passes (measured: 4 beats 64 by 6x at N = 100)
-    if (getenv("VLGP_LONG_RG")) A.rg = atoi(getenv("VLGP_LONG_RG"));
     vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
     int rc;
     if (LT == 3) rc = launch_long_t<3>(ctx, A, us.M, lds);

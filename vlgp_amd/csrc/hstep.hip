@@ -350,115 +350,6 @@ __global__ void __launch_bounds__(64, 3) hstep_prep_fast(HFastArgs A) {
     hstep_prep_body<T>(A, blockIdx.x, threadIdx.x, Lp, kv, dkv);
 }
 
-template <int T>
-__global__ void __launch_bounds__(256, 3) hstep_seg_fast(HFastArgs A) {
-    constexpr int PK = tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
-    constexpr int NW = 4;
-    __shared__ __attribute__((aligned(16))) double Lp_all[NW][PK];
-    __shared__ double vec_all[NW][4][64];
-    __shared__ double kv[64], dkv[64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int e = blockIdx.y;
-    const int seg = blockIdx.x * NW + wid;
-    if (threadIdx.x < 64) kv[threadIdx.x] = A.kcol[(int64_t)e * 128 + threadIdx.x];
-    else if (threadIdx.x < 128) dkv[threadIdx.x - 64] = A.kcol[(int64_t)e * 128 + threadIdx.x];
-    __syncthreads();
-    if (seg >= A.M) return;
-    double* Lp = Lp_all[wid];
-    double* sw = vec_all[wid][0];
-    double* muv = vec_all[wid][1];
-    double* alv = vec_all[wid][2];
-    double* invd = vec_all[wid][3];
-    const int l = A.latent[e];
-    const int64_t r0 = A.off[seg];
-    const double* Ki = A.kinv + (int64_t)e * T * T;
-    const bool in = lane < T;
-    double mu_t = 0.0, w_t = 0.0;
-    if (in) {
-        mu_t = A.mu[(r0 + lane) * A.L + l];
-        w_t = A.w[(r0 + lane) * A.L + l];
-    }
-    const double sw_t = sqrt(w_t);
-    sw[lane] = sw_t;
-    muv[lane] = mu_t;
-    tri_wave_sync();
-    // alpha = K^-1 mu (K^-1 symmetric: read a column, coalesced)
-    double al = 0.0;
-    if (in) {
-#pragma unroll 5
-        for (int j = 0; j < T; ++j) al = fma(Ki[j * T + lane], muv[j], al);
-    }
-    alv[lane] = al;
-    tri_wave_sync();
-    double quad = mu_t * al, gq = 0.0;
-    {
-        double sacc = 0.0;
-#pragma unroll 5
-        for (int j = 0; j < T; ++j) {
-            const int dd = lane > j ? lane - j : j - lane;
-            sacc = fma(dkv[dd & 63], alv[j], sacc);
-        }
-        gq = in ? sacc * al : 0.0;
-    }
-    // row `lane` of A = I + W^1/2 K W^1/2, lower part, into packed LDS
-    if (in) {
-        const int my_off = tri_row_off(lane);
-#pragma nounroll
-        for (int i = 0; i <= lane; ++i)
-            Lp[my_off + i] = sw_t * sw[i] * kv[lane - i] + (i == lane ? 1.0 : 0.0);
-    }
-    tri_wave_sync();
-    __builtin_amdgcn_sched_barrier(0);
-    double r[T];
-    const bool ok = wave_chol_rows<T>(r, Lp, lane, invd);
-    double tr = 0.0, cacc = 0.0;
-    if (ok) {
-        double x[T];
-        wave_tri_inverse_cols<T>(Lp, x, lane, invd);
-#pragma unroll
-        for (int k = 0; k < T; ++k) tr = fma(x[k], x[k], tr);
-        tri_wave_sync();
-        wave_store_cols<T>(x, Lp, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr TriuOff<T> off{};
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const double* Xj = Lp + off.v[j];
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-            for (int k = j; k < T; k += 2) {
-                const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-                if ((k - j) & 2) {
-                    a2 = fma(x[k], v.x, a2);
-                    if (k + 1 < T) a3 = fma(x[k + 1], v.y, a3);
-                } else {
-                    a0 = fma(x[k], v.x, a0);
-                    if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
-                }
-            }
-            const int dd = lane > j ? lane - j : j - lane;
-            cacc = fma(((a0 + a1) + (a2 + a3)) * sw[j], dkv[dd & 63], cacc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cacc = in ? cacc * sw_t : 0.0;
-        if (!in) tr = 0.0;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        quad += __shfl_xor(quad, o, 64);
-        gq += __shfl_xor(gq, o, 64);
-        tr += __shfl_xor(tr, o, 64);
-        cacc += __shfl_xor(cacc, o, 64);
-    }
-    if (lane == 0) {
-        const double logdet = A.scal[4 * e + 0];
-        double ll = -0.5 * quad - 0.5 * tr - logdet;
-        double dll = 0.5 * (gq - cacc);
-        if (!ok) { ll = nan(""); dll = nan(""); }
-        A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
-        A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
-    }
-}
-
 
 // Two tasks per wave, two rows per lane (wave_tri.h "duo"): halves the LDS broadcast
 // traffic per FMA and drops the finished rows' upper-triangle work.
@@ -973,10 +864,7 @@ static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
     hipLaunchKernelGGL((hstep_prep_fast<T>), dim3(n_eval), dim3(64), 0, ctx->stream, F);
     HIPCHK(ctx, hipGetLastError());
     vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-    if (!getenv("VLGP_HSTEP_SOLO"))
-        hipLaunchKernelGGL((hstep_seg_duo<T>), dim3((M + 3) / 4, n_eval), dim3(128), 0, ctx->stream, F);
-    else
-        hipLaunchKernelGGL((hstep_seg_fast<T>), dim3((M + 3) / 4, n_eval), dim3(256), 0, ctx->stream, F);
+    hipLaunchKernelGGL((hstep_seg_duo<T>), dim3((M + 3) / 4, n_eval), dim3(128), 0, ctx->stream, F);
     vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;

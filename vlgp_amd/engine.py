@@ -17,6 +17,7 @@ Two layers:
 """
 import ctypes as C
 import logging
+import os
 import time
 
 import numpy as np
@@ -620,7 +621,7 @@ def em_iteration(trials, params, config, runtime, echo=None):
     # With several ranks the two lanes' RCCL collectives would be in flight at once on two
     # communicators; ranks could enqueue them in different orders, so the overlap is a
     # single-GPU optimisation and multi-rank runs finish M before starting H.
-    if m_async and eng.world > 1:
+    if m_async and (eng.world > 1 or os.environ.get("VLGP_M_SEQUENTIAL")):
         m_ms = finish_m()
         m_async = False
     t2 = time.perf_counter()
