@@ -305,6 +305,26 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
         assert abs(moved[1][l, 1] - dll[1]) <= STAGE * max(abs(dll[1]), 1e-3 * abs(ll))
 
 
+@pytest.mark.parametrize("T", [25, 64, 100, 128])
+def test_hstep_objective_other_windows_vs_oracle(V, T):
+    """Windows other than 50 take the generic kernels (one T x T matrix per wave in LDS, lane-strided rows
+    above 64 bins): (ll, dll) against gp.obj_func's restatement."""
+    rng = np.random.default_rng(T)
+    M, L = 6, 2
+    units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": 2.0 * rng.random((T, L)),
+              "v": np.zeros((T, L))} for _ in range(M)]
+    logp = np.log(np.array([[1.0, 3e-3, 1e-4], [0.6, 2e-2, 1e-4]]))
+    with V.Engine(2, L, 1, 50) as eng:
+        eng.upload(0, units)
+        ll, dll = eng.hstep_objective(0, T, 1.0, np.arange(L), logp)
+    t = np.arange(T) * 1.0
+    for l in range(L):
+        want_ll, want_dll = O.gp_objective(logp[l], t, np.stack([u["mu"][:, l] for u in units], 1),
+                                           np.stack([u["w"][:, l] for u in units], 1))
+        assert abs(ll[l] - want_ll) <= STAGE * abs(want_ll), (T, l)
+        assert abs(dll[l, 1] - want_dll[1]) <= 1e-7 * max(abs(want_dll[1]), 1e-3 * abs(want_ll)), (T, l)
+
+
 def test_hstep_optimize_golden(V, golden):
     g = golden("hstep")
     M, T, L = g["mu"].shape
@@ -533,7 +553,7 @@ def test_c5_like_ragged_mixed_ten_latents(V):
 
 
 # ------------------------------------------------------------------ other windows / likelihoods through fit
-@pytest.mark.parametrize("window,lik_gauss", [(25, 0), (40, 0), (50, 12)])
+@pytest.mark.parametrize("window,lik_gauss", [(25, 0), (40, 0), (50, 12), (100, 0)])
 def test_fit_other_windows_and_all_gaussian(V, window, lik_gauss):
     """window != 50 takes the generic H-step kernels (the register-resident fast path is
     compiled for the reference's default window); lik_gauss = N makes every channel Gaussian

@@ -17,7 +17,7 @@
 #include "ctx.h"
 #include "wave_tri.h"
 
-#define HS_MAXT 64
+#define HS_MAXT 128  // generic kernels: rows are lane-strided, one T x T matrix per wave in LDS
 
 struct HPrepArgs {
     int T;
@@ -27,6 +27,7 @@ struct HPrepArgs {
     double* q;           // (n_eval, T, T)
     double* dk;          // (n_eval, T, T)
     double* scal;        // (n_eval, 4): logdet, tr(Kinv dK), omega_used, ok
+    double* tm;          // (n_eval, T, T) scratch for K^-1 dK when the four matrices do not fit LDS, else null
 };
 
 __device__ __forceinline__ void hs_wave_sync() {
@@ -39,28 +40,39 @@ __device__ __forceinline__ void hs_wave_sync() {
 // lower triangle holds X = chol^-1 and *logdet = sum log diag(chol).
 __device__ bool wave_chol_inv(double* Amat, int n, int ls, int lane, double* logdet) {
     double ld = 0.0;
-    for (int k = 0; k < n; ++k) {
-        double s = 0.0;
-        const bool act = lane >= k && lane < n;
-        if (act) {
-            s = Amat[lane * ls + k];
-            for (int i = 0; i < k; ++i) s = fma(-Amat[lane * ls + i], Amat[k * ls + i], s);
+    for (int k = 0; k < n; ++k) {  // left-looking; lane owns rows lane, lane + 64, ...
+        for (int r = k + ((lane - k) & 63); r < n; r += 64) {
+            double s = Amat[r * ls + k];
+            for (int i = 0; i < k; ++i) s = fma(-Amat[r * ls + i], Amat[k * ls + i], s);
+            Amat[r * ls + k] = s;
         }
-        const double d = __shfl(s, k, 64);
+        hs_wave_sync();
+        const double d = Amat[k * ls + k];
         if (!(d > 0.0) || !(d < 1e300)) return false;
         const double sd = sqrt(d);
         ld += log(sd);
-        if (act) Amat[lane * ls + k] = (lane == k) ? sd : s / sd;
+        hs_wave_sync();
+        for (int r = k + ((lane - k) & 63); r < n; r += 64) Amat[r * ls + k] = (r == k) ? sd : Amat[r * ls + k] / sd;
         hs_wave_sync();
     }
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i) {  // X = L^-1 in place, row by row; lane owns columns lane, lane + 64, ...
         const double lii = Amat[i * ls + i];
-        double acc = 0.0;
-        if (lane < i)
-            for (int j = lane; j < i; ++j) acc = fma(Amat[i * ls + j], Amat[j * ls + lane], acc);
+        double acc[HS_MAXT / 64];
+#pragma unroll
+        for (int m = 0; m < HS_MAXT / 64; ++m) {
+            const int c = lane + 64 * m;
+            double a = 0.0;
+            if (c < i)
+                for (int j = c; j < i; ++j) a = fma(Amat[i * ls + j], Amat[j * ls + c], a);
+            acc[m] = a;
+        }
         hs_wave_sync();
-        if (lane < i) Amat[i * ls + lane] = -acc / lii;
-        else if (lane == i) Amat[i * ls + i] = 1.0 / lii;
+#pragma unroll
+        for (int m = 0; m < HS_MAXT / 64; ++m) {
+            const int c = lane + 64 * m;
+            if (c < i) Amat[i * ls + c] = -acc[m] / lii;
+            else if (c == i) Amat[i * ls + i] = 1.0 / lii;
+        }
         hs_wave_sync();
     }
     *logdet = ld;
@@ -74,10 +86,12 @@ __global__ void __launch_bounds__(256) hstep_prep_kernel(HPrepArgs A) {
     __shared__ double s_logdet;
     const int T = A.T, ls = T | 1;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t base = (int64_t)e * T * T;
     double* Km = smem;            // T x ls : K, then chol, then X
-    double* Ki = Km + T * ls;     // T x T  : K^-1
-    double* Dk = Ki + T * T;      // T x T  : dK/dln omega
-    double* Tm = Dk + T * T;      // T x T  : K^-1 dK
+    // small windows keep all four matrices in LDS; large ones work on the output buffers in L2
+    double* Ki = A.tm ? A.kinv + base : Km + T * ls;     // T x T  : K^-1
+    double* Dk = A.tm ? A.dk + base : Ki + T * T;        // T x T  : dK/dln omega
+    double* Tm = A.tm ? A.tm + base : Dk + T * T;        // T x T  : K^-1 dK
     const double sigmasq = exp(A.logp[3 * e + 0]);
     double omega = exp(A.logp[3 * e + 1]);
     const double eps = exp(A.logp[3 * e + 2]);
@@ -125,14 +139,16 @@ __global__ void __launch_bounds__(256) hstep_prep_kernel(HPrepArgs A) {
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    const int64_t base = (int64_t)e * T * T;
+    __syncthreads();
     for (int i = tid; i < T * T; i += 256) {
         const int r = i / T, c = i - r * T;
         double s = 0.0;
         for (int k = 0; k < T; ++k) s = fma(Tm[r * T + k], Ki[k * T + c], s);
         A.q[base + i] = s;
-        A.kinv[base + i] = Ki[i];
-        A.dk[base + i] = Dk[i];
+        if (!A.tm) {
+            A.kinv[base + i] = Ki[i];
+            A.dk[base + i] = Dk[i];
+        }
     }
     if (tid == 0) {
         A.scal[4 * e + 0] = s_logdet;
@@ -172,30 +188,26 @@ __global__ void __launch_bounds__(256) hstep_seg_kernel(HSegArgs A) {
     const double* Q = A.q + (int64_t)e * T * T;
     const double* Dk = A.dk + (int64_t)e * T * T;
 
-    double mu_t = 0.0, w_t = 0.0;
-    if (lane < T) {
-        mu_t = A.mu[(r0 + lane) * A.L + l];
-        w_t = A.w[(r0 + lane) * A.L + l];
-    }
-    muv[lane] = mu_t;
+    for (int t = lane; t < T; t += 64) muv[t] = A.mu[(r0 + t) * A.L + l];
     for (int i = lane; i < T * T; i += 64) {
         const int r = i / T, c = i - r * T;
         B[r * ls + c] = Ki[i];
     }
     hs_wave_sync();
-    if (lane < T) B[lane * ls + lane] += w_t;
+    for (int t = lane; t < T; t += 64) B[t * ls + t] += A.w[(r0 + t) * A.L + l];
     // alpha = K^-1 mu (K^-1 symmetric: read columns for coalescing)
-    double al = 0.0;
-    if (lane < T)
-        for (int j = 0; j < T; ++j) al = fma(Ki[j * T + lane], muv[j], al);
-    alv[lane] = al;
+    for (int t = lane; t < T; t += 64) {
+        double al = 0.0;
+        for (int j = 0; j < T; ++j) al = fma(Ki[j * T + t], muv[j], al);
+        alv[t] = al;
+    }
     hs_wave_sync();
-    double quad = mu_t * al;
-    double gq = 0.0;
-    if (lane < T) {
+    double quad = 0.0, gq = 0.0;
+    for (int t = lane; t < T; t += 64) {
         double s = 0.0;
-        for (int j = 0; j < T; ++j) s = fma(Dk[j * T + lane], alv[j], s);
-        gq = s * al;
+        for (int j = 0; j < T; ++j) s = fma(Dk[j * T + t], alv[j], s);
+        quad = fma(muv[t], alv[t], quad);
+        gq = fma(s, alv[t], gq);
     }
     double ld;
     const bool ok = wave_chol_inv(B, T, ls, lane, &ld);
@@ -881,7 +893,8 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
     const int64_t o_lat = o_logp + 3 * n_eval, o_qsum = o_lat + n_eval + 8, o_mpart = o_qsum + 2 * n_eval + 2;
-    const int64_t total = o_mpart + (T == 50 ? (int64_t)L * 64 * TT : 0);
+    const int64_t o_tm = o_mpart + (T == 50 ? (int64_t)L * 64 * TT : 0);
+    const int64_t total = o_tm + (T > 64 ? n_eval * TT : 0);
     CHK(vlgp_ensure_work(ctx, total));
     CHK(vlgp_ensure_pinned(ctx, 12 * n_eval + 32));
     double* W = ctx->d_work;
@@ -990,7 +1003,12 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     HPrepArgs P;
     P.T = T; P.dt = dt; P.logp = W + o_logp; P.kinv = W + o_kinv; P.q = W + o_q; P.dk = W + o_dk;
     P.scal = W + o_scal;
-    const size_t lds_prep = (size_t)(T * (T | 1) + 3 * TT) * 8;
+    size_t lds_prep = (size_t)(T * (T | 1) + 3 * TT) * 8;
+    P.tm = nullptr;
+    if (lds_prep > 150 * 1024) {  // large window: only the factor stays in LDS
+        P.tm = W + o_tm;
+        lds_prep = (size_t)(T * (T | 1)) * 8;
+    }
     if (lds_prep > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
@@ -1001,8 +1019,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     S.T = T; S.L = L; S.M = M; S.off = us.d_off; S.mu = us.mu; S.w = us.w;
     S.latent = reinterpret_cast<const int*>(W + o_lat);
     S.kinv = W + o_kinv; S.q = W + o_q; S.dk = W + o_dk; S.scal = W + o_scal; S.out = W + o_out;
-    const int nw = 2;
+    const int nw = (size_t)2 * (T * (T | 1) + 2 * HS_MAXT) * 8 <= 160 * 1024 ? 2 : 1;
     const size_t lds_seg = (size_t)nw * (T * (T | 1) + 2 * HS_MAXT) * 8;
+    if (lds_seg > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_seg_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
     vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
     hipLaunchKernelGGL(hstep_seg_kernel, dim3((M + nw - 1) / nw, n_eval), dim3(64 * nw), lds_seg, ctx->stream, S);
     vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
