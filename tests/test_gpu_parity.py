@@ -616,3 +616,50 @@ def test_deferred_initialisation_matches_host(V):
     b = np.log(np.maximum(colsum[None, :] / plan["rows"], cfg["eps"]))
     assert relerr(b, ph["b"]) < 1e-13
     assert relerr(mu, np.concatenate([t["mu"] for t in host])) < 1e-12
+
+
+def test_overlapping_cut_and_merge(V):
+    """Trial lengths that are not multiples of the window: segments overlap at random offsets
+    (util.cut_trial's multinomial draw), the device set is a gathered copy, and merging scatters the
+    segments back in order (the later segment wins an overlap, as sequential in-place updates of the
+    reference's views would leave it)."""
+    from vlgp_amd.api import SET_SEGMENTS, SET_TRIALS, _segments
+
+    rng = np.random.default_rng(4)
+    lengths, N, L, window = [230, 170, 50, 120], 6, 2, 50
+    trials = [{"y": rng.poisson(0.4, (T, N)).astype(float), "mu": rng.standard_normal((T, L)),
+               "v": rng.random((T, L)), "w": rng.random((T, L))} for T in lengths]
+    for tr in trials:
+        tr["x"] = np.ones((tr["y"].shape[0], 1, N))
+    with V.Engine(N, L, 1, 50) as eng:
+        eng.upload(SET_TRIALS, trials)
+        np.random.seed(21)
+        segs = _segments(trials, window, eng)
+        from vlgp_amd.util import segment_starts
+        np.random.seed(21)
+        starts = [segment_starts(T, window) for T in lengths]
+        assert len(segs) == sum(len(s) for s in starts) == 5 + 4 + 1 + 3
+        got = eng.download(SET_SEGMENTS, keys=("mu", "v", "w"))
+        want = {k: np.concatenate([tr[k][int(s):int(s) + window] for tr, st in zip(trials, starts) for s in st])
+                for k in ("mu", "v", "w")}
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+        # change the segments on the device, merge, and compare with the host emulation of the scatter
+        eng.apply_latent_map(SET_SEGMENTS, np.array([[2.0, 0.5], [0.0, -1.0]]), np.array([0.25, -0.5]))
+        seg_mu = eng.download(SET_SEGMENTS, keys=("mu",))["mu"]
+        eng.merge(SET_SEGMENTS)
+        merged = eng.download(SET_TRIALS, keys=("mu",))["mu"]
+    expect = np.concatenate([tr["mu"] for tr in trials])
+    row0, i = 0, 0
+    for T, st in zip(lengths, starts):
+        for s in st:
+            expect[row0 + int(s):row0 + int(s) + window] = seg_mu[i * window:(i + 1) * window]
+            i += 1
+        row0 += T
+    assert np.array_equal(merged, expect)
+    with pytest.raises(ValueError, match="shorter than window"):
+        with V.Engine(N, L, 1, 50) as eng:
+            short = [{"y": np.zeros((30, N)), "mu": np.zeros((30, L)), "v": np.zeros((30, L)), "w": np.zeros((30, L)),
+                      "x": np.ones((30, 1, N))}]
+            eng.upload(SET_TRIALS, short)
+            _segments(short, window, eng)

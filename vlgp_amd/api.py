@@ -31,6 +31,10 @@ def _segments(trials, window, eng):
     starts, segs, row0 = [], [], 0
     for tr in trials:
         T = tr["y"].shape[0]
+        if T < window:
+            # the reference would cut a shorter segment here and then fail in gp.optimize (np.stack of
+            # unequal segments); the device cut needs equal lengths, so say it up front
+            raise ValueError("trial of %d bins is shorter than window=%d; pass a smaller window" % (T, window))
         for s in segment_starts(T, window):
             sl = slice(int(s), int(s) + window)
             segs.append({k: tr[k][sl] for k in ("y", "x", "mu", "w", "v")})
