@@ -192,6 +192,28 @@ def test_estep_random_vs_oracle(V, case):
             assert relerr(u[k], r) < STAGE, (k, u["y"].shape)
 
 
+@pytest.mark.parametrize("omega,lo,hi", [(2e-2, 17, 24), (4.5e-2, 25, 32)])
+def test_estep_mid_rank_buckets_vs_oracle(V, omega, lo, hi):
+    """Effective ranks 17..24 and 25..32 take their own instantiations of the fast E-step kernel
+    (register arrays of 24 / 32 entries): pin both against the oracle."""
+    rng = np.random.default_rng(12)
+    units, params, gauss = _random_problem(rng, [50] * 6, 30, 5, 1, 4)
+    params["omega"] = np.full(5, omega)
+    params["cholesky"] = O.build_prior([50], params["omega"], params["sigma"], 50)
+    ranks = [int(np.any(params["cholesky"][50][l] != 0, axis=0).sum()) for l in range(5)]
+    assert lo <= max(ranks) <= hi, ranks
+    for u in units:
+        u["w"] = O.curvature_unit(u["y"], u["x"], u["mu"], np.zeros_like(u["mu"]), params["a"], params["b"],
+                                  params["noise"], gauss)
+        u["v"] = O.variance_unit(u["w"], np.zeros_like(u["mu"]), params["cholesky"][50])[0]
+    want = [O.estep_unit(u["y"], u["x"], u["mu"], u["v"], u["w"], params["a"], params["b"], params["noise"],
+                         gauss, params["cholesky"][50], 5) for u in units]
+    V.estep(units, params, V.get_config(Eniter=5))
+    for u, ref in zip(units, want):
+        for k, r in zip(("mu", "v", "w", "dmu"), ref):
+            assert relerr(u[k], r) < STAGE, k
+
+
 def test_estep_singular_system_zeroes_update(V):
     # a NaN curvature makes I + G'WG non-factorisable: the reference logs and
     # applies a zero update for that latent (core.py:92-94); other latents move

@@ -28,11 +28,15 @@
 enum { FP_YA = 0, FP_RES = 1, FP_W = 2 };
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <int LT, int RP>
-__global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(EstepArgs A, const double* __restrict__ cols_g) {
+// RP: lane mapping of the per-latent phases (power of two); RA <= RP: size of the register arrays and of
+// the unrolled factor / solve loops (RA = 24 serves ranks 17..24 with 3/4 of the registers of RA = 32,
+// which is what lets two workgroups share a CU).
+template <int LT, int RP, int RA = RP>
+__global__ void __launch_bounds__(512, (RP <= 16 ? 4 : (RA <= 24 ? 3 : 1)))
+estep_fast_kernel(EstepArgs A, const double* __restrict__ cols_g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int REC = 2 * LT + 2;          // a[LT], a^2[LT], b, c  (even -> 16-byte records)
-    constexpr int PK = tri_packed_size(RP);  // packed lower-triangular RP x RP
+    constexpr int PK = tri_packed_size(RA);  // packed lower-triangular RA x RA
     constexpr int NCH = 64 / RP;             // time chunks per wave in the (row, chunk) mapping
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
@@ -279,7 +283,7 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(Est
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = 16 * bi + kq + 4 * q;
-                        if (cb <= row) Xl[tri_row_off(row) + cb] = c[q] + (cb == row ? 1.0 : 0.0);
+                        if (cb <= row && row < RA) Xl[tri_row_off(row) + cb] = c[q] + (cb == row ? 1.0 : 0.0);
                     }
                 }
                 lap2(6);
@@ -288,16 +292,16 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(Est
                 tri_wave_sync();
                 __builtin_amdgcn_sched_barrier(0);
                 {
-                    double rr[RP];
-                    ok = wave_chol_rows<RP>(rr, Xl, lane);
+                    double rr[RA];
+                    ok = wave_chol_rows<RA>(rr, Xl, lane);
                 }
                 {
-                    double x[RP];
-                    wave_tri_inverse_cols<RP>(Xl, x, lane);
+                    double x[RA];
+                    wave_tri_inverse_cols<RA>(Xl, x, lane);
                     tri_wave_sync();
-                    if (lane < RP) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+                    if (lane < RA) {  // X overwrites L, row-major packed: X[i][c] for i >= c
 #pragma unroll
-                        for (int i = 0; i < RP; ++i)
+                        for (int i = 0; i < RA; ++i)
                             if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
                     }
                 }
@@ -307,9 +311,9 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(Est
             lap2(7);
             if (do_v && ok && lane < T) {
                 const double* Gt = Gl + lane * rs;
-                double gt[RP];
+                double gt[RA];
 #pragma unroll
-                for (int i = 0; i < RP; i += 2) {
+                for (int i = 0; i < RA; i += 2) {
                     double2 g2 = {0.0, 0.0};
                     if (i < rs) g2 = *reinterpret_cast<const double2*>(Gt + i);
                     gt[i] = g2.x;
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(Est
                 }
                 double vv = 0.0;
 #pragma unroll
-                for (int i = 0; i < RP; ++i) {
+                for (int i = 0; i < RA; ++i) {
                     if (i < r) {
                         const double* Xi = Xl + tri_row_off(i);
                         double z0 = 0.0, z1 = 0.0;
@@ -365,16 +369,16 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(Est
             }
 #pragma unroll
             for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
-            if (lane < RP) vec[lane] = acc;
+            if (lane < RA) vec[lane] = acc;
             tri_wave_sync();
             // u = G g1 - mu_l   (row t of G stays in registers for the last step)
-            double gt[RP];
+            double gt[RA];
             double ut = 0.0;
             {
                 const double* Gt = Gl + (lane < T ? lane : 0) * rs;
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int i = 0; i < RP; i += 2) {
+                for (int i = 0; i < RA; i += 2) {
                     double2 g2 = {0.0, 0.0};
                     if (i < rs) {
                         g2 = *reinterpret_cast<const double2*>(Gt + i);
@@ -399,32 +403,32 @@ __global__ void __launch_bounds__(512, (RP <= 16 ? 4 : 1)) estep_fast_kernel(Est
             }
 #pragma unroll
             for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
-            if (lane < RP) vec2[lane] = acc;
+            if (lane < RA) vec2[lane] = acc;
             tri_wave_sync();
             // z = X rhs, sol = X' z   (lane = row, then lane = column)
             double z = 0.0;
-            if (lane < RP) {
+            if (lane < RA) {
                 const double* Xi = Xl + tri_row_off(lane);
 #pragma unroll
-                for (int q = 0; q < RP; ++q)
+                for (int q = 0; q < RA; ++q)
                     if (q <= lane) z = fma(Xi[q], vec2[q], z);
             }
             tri_wave_sync();
-            if (lane < RP) vec[lane] = z;
+            if (lane < RA) vec[lane] = z;
             tri_wave_sync();
             double sol = 0.0;
-            if (lane < RP) {
+            if (lane < RA) {
 #pragma unroll
-                for (int q = 0; q < RP; ++q)
+                for (int q = 0; q < RA; ++q)
                     if (q >= lane) sol = fma(Xl[tri_row_off(q) + lane], vec[q], sol);
             }
             tri_wave_sync();
-            if (lane < RP) vec2[lane] = sol;
+            if (lane < RA) vec2[lane] = sol;
             tri_wave_sync();
             if (lane < T) {
                 double s0 = ut, s1 = 0.0;
 #pragma unroll
-                for (int i = 0; i < RP; i += 2)
+                for (int i = 0; i < RA; i += 2)
                     if (i < rs) {
                         const double2 c2 = *reinterpret_cast<const double2*>(vec2 + i);
                         s0 = fma(-gt[i], c2.x, s0);
@@ -515,9 +519,9 @@ estep_cols_kernel(int N, int L, int LT, const double* a, const double* b, const 
 }
 
 // ---------------------------------------------------------------------------
-template <int LT, int RP>
+template <int LT, int RP, int RA>
 static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t lds) {
-    auto fn = estep_fast_kernel<LT, RP>;
+    auto fn = estep_fast_kernel<LT, RP, RA>;
     if (lds > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -528,11 +532,11 @@ static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, siz
     return VLGP_OK;
 }
 
-template <int RP>
+template <int RP, int RA>
 static int launch_fast_l(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t lds) {
-    if (A.L <= 3) return launch_fast_t<3, RP>(ctx, A, M, nthr, lds);
-    if (A.L <= 5) return launch_fast_t<5, RP>(ctx, A, M, nthr, lds);
-    return launch_fast_t<8, RP>(ctx, A, M, nthr, lds);
+    if (A.L <= 3) return launch_fast_t<3, RP, RA>(ctx, A, M, nthr, lds);
+    if (A.L <= 5) return launch_fast_t<5, RP, RA>(ctx, A, M, nthr, lds);
+    return launch_fast_t<8, RP, RA>(ctx, A, M, nthr, lds);
 }
 
 int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
@@ -560,7 +564,8 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : 8);
     const int nw = L < 4 ? 4 : L;  // L <= 8
     const int Tc = us.Tmax;
-    const int64_t PK = RP == 16 ? tri_packed_size(16) : tri_packed_size(32);
+    const int RA = rmax <= 16 ? 16 : (rmax <= 24 && !getenv("VLGP_ESTEP_NO_RA24") ? 24 : 32);
+    const int64_t PK = tri_packed_size(RA);
     int64_t scr = (int64_t)nw * Tc * L;                       // partial sums of the passes
     if (scr < (int64_t)nw * 256) scr = (int64_t)nw * 256;     // 16 x 16 MFMA staging tiles
     if (scr < (int64_t)nw * 128 + (int64_t)Tc * L) scr = (int64_t)nw * 128 + (int64_t)Tc * L;  // vec + u
@@ -578,6 +583,7 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     HIPCHK(ctx, hipGetLastError());
     *handled = 1;
     const int nthr = nw * 64;
-    if (RP == 16) return launch_fast_l<16>(ctx, A, us.M, nthr, (size_t)d * 8);
-    return launch_fast_l<32>(ctx, A, us.M, nthr, (size_t)d * 8);
+    if (RA == 16) return launch_fast_l<16, 16>(ctx, A, us.M, nthr, (size_t)d * 8);
+    if (RA == 24) return launch_fast_l<32, 24>(ctx, A, us.M, nthr, (size_t)d * 8);
+    return launch_fast_l<32, 32>(ctx, A, us.M, nthr, (size_t)d * 8);
 }
