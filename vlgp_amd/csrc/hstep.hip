@@ -871,6 +871,191 @@ __global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
     }
 }
 
+// The same round with the lean task layout (wave_tri.h): 10.2 KB of LDS per task and no
+// per-task vectors, so four blocks -- eight waves -- fit a CU instead of three.
+template <int T>
+__global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
+    constexpr int H = T / 2;
+    constexpr int PKU = (tri_off_u(T) + 1) & ~1;  // unpadded packed triangle; even, so that every task buffer is 16-byte aligned
+    constexpr int NW = 2;
+    static_assert(2 * NW * PKU >= hstep_prep_lds<T>() + 2 + 256, "K block scratch must fit");
+    __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PKU];
+    __shared__ double part[2 * NW][2];
+    __shared__ int s_last;
+    const HFastArgs& A = R.F;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if ((int)blockIdx.x < R.n_eval) {
+        const int e = blockIdx.x;
+        if (wid == 0) {
+            double* base = &Lp_all[0][0][0];
+            double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);  // kv64 | dkv64 | dk2 (128)
+            hstep_prep_body<T>(A, e, lane, base, extra, extra + 64);
+            tri_wave_sync();
+            hstep_prep_moments<T, false>(A, R.mom, R.qsum, e, lane, nullptr, extra + 128, extra + 64);
+        }
+    } else {
+        const int b = blockIdx.x - R.n_eval;
+        const int e = b / R.nb, bx = b - e * R.nb;
+        const int h = lane >> 5, q = lane & 31;
+        const int seg = (bx * NW + wid) * 2 + h;
+        double tr = 0.0, cacc = 0.0;
+        if ((bx * NW + wid) * 2 < A.M) {
+            const bool valid = seg < A.M;
+            const bool in = q < H && valid;
+            double* Lp = Lp_all[wid][h];
+            const int l = A.latent[e];
+            const int64_t r0row = A.off[valid ? seg : 0];
+            double w0 = 0.0, w1 = 0.0;
+            if (in) {
+                w0 = A.w[(r0row + q) * A.L + l];
+                w1 = A.w[(r0row + q + H) * A.L + l];
+            }
+            const double sw0 = sqrt(w0), sw1 = sqrt(w1);
+            // this lane's entries of the first columns of K and dK/dln omega (distances q and q + H)
+            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
+            const double d0 = q * A.dt, d1 = (q + H) * A.dt;
+            const double kk0 = sigmasq * exp(-omega * d0 * d0), kk1 = sigmasq * exp(-omega * d1 * d1);
+            const double kvw0 = kk0 + (q == 0 ? eps : 0.0), kvw1 = kk1;
+            double dkw0 = -kk0 * d0 * d0 * omega, dkw1 = -kk1 * d1 * d1 * omega;
+            if (q < H) {  // s_k waits in the diagonal slot of row k until step k replaces it by 1 / L[k][k]
+                Lp[tri_off_u(q) + q] = sw0;
+                Lp[tri_off_u(q + H) + q + H] = sw1;
+            }
+            tri_wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            bool ok;
+            {
+                double r0[H], r1[T];
+                ok = wave_chol_rows_duo_lean<T>(r0, r1, Lp, q, h, sw0, sw1, kvw0, kvw1);
+            }
+            {
+                double x0[T], x1[H];
+                wave_tri_inverse_cols_duo_lean<T>(Lp, x0, x1, q);
+#pragma unroll
+                for (int k = 0; k < T; ++k) tr = fma(x0[k], x0[k], tr);
+#pragma unroll
+                for (int k = 0; k < H; ++k) tr = fma(x1[k], x1[k], tr);
+                tri_wave_sync();
+                // X columns -> upper-packed rows of X' scaled by s (overwrites L)
+                if (q < H) {
+                    const int my0 = triu_off_u(q, T), my1 = triu_off_u(q + H, T);
+#pragma unroll
+                    for (int k = 0; k < T; ++k)
+                        if (k >= q) Lp[my0 + k - q] = sw0 * x0[k];
+#pragma unroll
+                    for (int k = H; k < T; ++k)
+                        if (k >= q + H) Lp[my1 + k - q - H] = sw1 * x1[k - H];
+                }
+                tri_wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                // strictly lower half of sum_jk s_j s_k dK_jk (X'X)_jk; dK[row - j] slides like kv did
+                double c0acc = 0.0, c1acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double* Xj = Lp + triu_off_u(j, T);
+                    const int st = triu_off_u(j, T) & 1;  // aligned pairs start at k = j + st
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                    if (st) {
+                        const double vx = Xj[0];
+                        a0 = fma(x0[j], vx, a0);
+                        if (j >= H) b0 = fma(x1[j - H < 0 ? 0 : j - H], vx, b0);
+                    }
+#pragma unroll
+                    for (int k = j + st; k + 1 < T; k += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
+                        a0 = fma(x0[k], v.x, a0);
+                        a1 = fma(x0[k + 1], v.y, a1);
+                        if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
+                        if (k + 1 >= H) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
+                        if (((k - j - st) & 14) == 14) {
+                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if ((T - j - st) & 1) {  // last column left over
+                        const double vx = Xj[T - 1 - j];
+                        a0 = fma(x0[T - 1], vx, a0);
+                        b0 = fma(x1[H - 1], vx, b0);
+                    }
+                    c0acc = fma(a0 + a1, dkw0, c0acc);
+                    c1acc = fma(b0 + b1, dkw1, c1acc);
+                    tri_windows_step<H>(dkw0, dkw1, q, h, 0.0);
+                    asm volatile("" : "+v"(c0acc), "+v"(c1acc), "+v"(dkw0), "+v"(dkw1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                cacc = 2.0 * (c0acc * sw0 + c1acc * sw1);
+            }
+            if (!ok) { tr = nan(""); cacc = nan(""); }  // failed factorisation: propagates into ll, dll
+            if (!in) { tr = 0.0; cacc = 0.0; }
+            for (int o = 16; o > 0; o >>= 1) {  // reduce within each 32-lane half
+                tr += __shfl_xor(tr, o, 64);
+                cacc += __shfl_xor(cacc, o, 64);
+            }
+        }
+        if ((lane & 31) == 0) {
+            part[wid * 2 + (lane >> 5)][0] = tr;
+            part[wid * 2 + (lane >> 5)][1] = cacc;
+        }
+    }
+    // ---- completion: one partial per block, then the last block reduces and publishes ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if ((int)blockIdx.x >= R.n_eval) {
+            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
+            o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+            o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+        }
+        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double* rs = &Lp_all[0][0][0];  // 2 x 128 partials
+    for (int e = 0; e < R.n_eval; ++e) {
+        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int m = threadIdx.x; m < R.nb; m += 128) {
+            const double2 v = in[m];
+            s0 += v.x;
+            s1 += v.y;
+        }
+        __syncthreads();
+        rs[threadIdx.x] = s0;
+        rs[128 + threadIdx.x] = s1;
+        __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                rs[threadIdx.x] += rs[threadIdx.x + o];
+                rs[128 + threadIdx.x] += rs[128 + threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double okf = A.scal[4 * e + 3];
+            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
+            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[128]);
+            R.red[2 * e + 0] = ll;
+            R.red[2 * e + 1] = dll;
+            R.red[2 * R.n_eval + e] = okf;
+            if (R.host) {
+                R.host[2 * e + 0] = ll;
+                R.host[2 * e + 1] = dll;
+                R.host[2 * R.n_eval + e] = okf;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        R.sync[16] = 0;  // next launch is stream-ordered after this one
+        if (R.host) {
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int T>
 static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
     hipLaunchKernelGGL((hstep_prep_fast<T>), dim3(n_eval), dim3(64), 0, ctx->stream, F);
@@ -956,10 +1141,13 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool mailbox = ctx->world == 1;  // multi-rank: the sums go through the all-reduce first
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
+            static const bool padded = getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
             if (one_wave)
                 hipLaunchKernelGGL((hstep_round_duo<50, 1>), dim3(n_eval + n_eval * R.nb), dim3(64), 0, ctx->stream, R);
-            else
+            else if (padded)
                 hipLaunchKernelGGL((hstep_round_duo<50, 2>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
+            else
+                hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
             HIPCHK(ctx, hipGetLastError());
             if (mailbox) {

@@ -318,6 +318,151 @@ __device__ __forceinline__ void wave_tri_inverse_cols_duo(const double* Lp, cons
     }
 }
 
+// ===========================================================================
+// "Lean" duo variants: the task's LDS footprint is the packed triangle and nothing else
+// (T (T + 1) / 2 doubles, rows NOT padded), so that four two-wave blocks -- eight waves --
+// share a CU's 160 KB at T = 50 (the padded layout plus per-task vectors stops at six;
+// measured: the factorisations are latency-bound and gain 18 % from the two extra waves).
+//   * A = I + S K S is never stored: column k of A is produced on the fly from the lane's
+//     s_row, the pivot's s_k (static-lane pick) and a sliding window of the Toeplitz first
+//     column kept in registers: lane q holds kv[q - k] (row q) and kv[q + T/2 - k]; after
+//     each step both windows move one lane up (DPP wave_shr:1, no LDS), row T/2's window
+//     taking over the value that falls off row T/2 - 1.
+//   * 1 / L[k][k] lives in the diagonal slot of the packed factor (the diagonal itself is
+//     never read back): no reciprocal-diagonal array.
+//   * the dK-weighted trace uses the symmetry of the double sum (2 x the strictly lower
+//     part), so its weights dK[row - j] are one more sliding window; X' is stored
+//     pre-scaled by s_j.
+// Unpadded rows are only 8-byte aligned: pivot-row pairs are read as two adjacent doubles
+// (one ds_read2_b64).
+// ===========================================================================
+__host__ __device__ constexpr int tri_off_u(int i) { return i * (i + 1) / 2; }
+__host__ __device__ constexpr int triu_off_u(int c, int T) { return c * T - (c * (c - 1)) / 2; }
+
+__device__ __forceinline__ double tri_wave_shr1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane i <- lane i - 1)
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Moves both sliding windows one step: w0 (row q) <- lane q - 1, w1 (row q + H) <- lane q - 1, and lane
+// q = 0 of each half takes row H's next value from row H - 1 (w0 of lane H - 1), `fill0` for row 0.
+template <int H>
+__device__ __forceinline__ void tri_windows_step(double& w0, double& w1, int q, int h, double fill0) {
+    const double carry = tri_pick_half(w0, H - 1, h);
+    w0 = tri_wave_shr1(w0);
+    w1 = tri_wave_shr1(w1);
+    if (q == 0) {
+        w0 = fill0;
+        w1 = carry;
+    }
+}
+
+// Factor A = I + S K S without ever storing A.  sw0/sw1: sqrt(w) of rows q, q + T/2; kvw0/kvw1:
+// first column of K at distances q and q + T/2 (kv[0] includes the jitter).  The diagonal slot of
+// row k holds s_k on entry (the caller puts it there) and 1 / L[k][k] on exit; L strictly below the
+// diagonal (unpadded packed).  Unpadded rows start at even or odd offsets: the pivot-row pairs are
+// formed from index 0 or 1 accordingly (static), so that every pair is one aligned ds_read_b128
+// with an immediate offset.
+template <int T>
+__device__ __forceinline__ bool wave_chol_rows_duo_lean(double (&r0)[T / 2], double (&r1)[T], double* Lp, int q, int h,
+                                                        double sw0, double sw1, double kvw0, double kvw1) {
+    constexpr int H = T / 2;
+    const bool in = q < H;
+    const int off0 = tri_off_u(in ? q : 0), off1 = tri_off_u(in ? q + H : H);
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const double* Lk = Lp + tri_off_u(k);
+        const int st = tri_off_u(k) & 1;  // first index of the aligned pairs
+        const double sk = Lk[k];          // s_k, parked in the diagonal slot
+        double s0 = 0.0, s0b = 0.0, s1b = 0.0;
+        if (k < H) s0 = fma(sw0 * sk, kvw0, q == k ? 1.0 : 0.0);                // A[q][k]
+        double s1 = fma(sw1 * sk, kvw1, q + H == k ? 1.0 : 0.0);                // A[q + H][k]
+        if (st && k > 0) {
+            const double lv = Lk[0];
+            if (k < H) s0 = fma(-r0[0], lv, s0);
+            s1 = fma(-r1[0], lv, s1);
+        }
+#pragma unroll
+        for (int i = st; i + 1 < k; i += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Lk + i);
+            if (k < H) {
+                s0 = fma(-r0[i < H ? i : 0], v.x, s0);
+                s0b = fma(-r0[i + 1 < H ? i + 1 : 0], v.y, s0b);
+            }
+            s1 = fma(-r1[i], v.x, s1);
+            s1b = fma(-r1[i + 1], v.y, s1b);
+            if (((i - st) & 14) == 14) {
+                asm volatile("" : "+v"(s0), "+v"(s0b), "+v"(s1), "+v"(s1b) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (k > st && ((k - st) & 1)) {
+            const double lv = Lk[k - 1];
+            if (k < H) s0 = fma(-r0[k - 1 < H ? k - 1 : 0], lv, s0);
+            s1 = fma(-r1[k - 1], lv, s1);
+        }
+        s0 += s0b;
+        s1 += s1b;
+        const double d = tri_pick_half(k < H ? s0 : s1, k < H ? k : k - H, h);
+        bad |= (!(d > 0.0) || !(d < 1e300)) ? 1 : 0;
+        asm volatile("" : "+v"(bad));
+        double inv, sd;
+        tri_rsqrt(d, &inv, &sd);
+        if (k < H) {
+            r0[k < H ? k : 0] = s0 * inv;
+            if (in && q >= k) Lp[off0 + k] = (q == k) ? inv : r0[k < H ? k : 0];
+        }
+        r1[k] = s1 * inv;
+        if (in && q + H >= k) Lp[off1 + k] = (q + H == k) ? inv : r1[k];
+        tri_windows_step<H>(kvw0, kvw1, q, h, 0.0);
+        asm volatile("" : "+v"(kvw0), "+v"(kvw1));
+        tri_wave_order();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return bad == 0;
+}
+
+// Columns q and q + T/2 of X = L^-1 from the lean factor (reciprocal diagonal in place).
+template <int T>
+__device__ __forceinline__ void wave_tri_inverse_cols_duo_lean(const double* Lp, double (&x0)[T], double (&x1)[T / 2],
+                                                               int q) {
+    constexpr int H = T / 2;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const double* Li = Lp + tri_off_u(i);
+        const int st = tri_off_u(i) & 1;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        if (st && i > 0) {
+            const double lv = Li[0];
+            a0 = fma(lv, x0[0], a0);
+        }
+#pragma unroll
+        for (int j = st; j + 1 < i; j += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Li + j);
+            a0 = fma(v.x, x0[j], a0);
+            a1 = fma(v.y, x0[j + 1], a1);
+            if (j >= H) b0 = fma(v.x, x1[j - H < 0 ? 0 : j - H], b0);
+            if (j + 1 >= H) b1 = fma(v.y, x1[j + 1 - H < 0 ? 0 : j + 1 - H], b1);
+            if (((j - st) & 14) == 14) {
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (i > st && ((i - st) & 1)) {
+            const double lv = Li[i - 1];
+            a0 = fma(lv, x0[i - 1], a0);
+            if (i - 1 >= H) b0 = fma(lv, x1[i - 1 - H < 0 ? 0 : i - 1 - H], b0);
+        }
+        const double di = Li[i];  // 1 / L[i][i]
+        x0[i] = ((q == i ? 1.0 : 0.0) - (a0 + a1)) * di;
+        if (i >= H) x1[i - H < 0 ? 0 : i - H] = ((q + H == i ? 1.0 : 0.0) - (b0 + b1)) * di;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // offset of row c in the upper-packed X' storage (rows padded to an even length), T even
 __host__ __device__ constexpr int triu_off_even(int c, int T) {
     return (c & 1) ? 2 * T * (c / 2) - 2 * (c / 2) * (c / 2 - 1) + (T - 2 * (c / 2))
