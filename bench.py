@@ -193,7 +193,7 @@ def main():
         kernels["estep_fast_kernel"] = {"launches": n_e, "avg_ms": ms_e / n_e, "total_ms": ms_e,
                                         "units_per_launch": u_e / n_e, "unit": "TFLOP/s", "bound": "mfma",
                                         "achieved": flops / (ms_e / n_e * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                        "pmc_key": "estep_fast_kernel<5, 16>"}
+                                        "pmc_key": "estep_fast_kernel<5, 16, 16>"}
     n_m, ms_m, u_m = prof["mstep"]
     if n_m:
         nbytes = work["mstep_bytes_per_row"] * u_m / n_m
@@ -204,10 +204,10 @@ def main():
     n_h, ms_h, u_h = prof["hstep"]
     if n_h:
         flops = work["hstep_flops_per_seg_eval"] * u_h / n_h
-        kernels["hstep_round_duo"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
+        kernels["hstep_round_lean"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
                                      "units_per_launch": u_h / n_h, "unit": "TFLOP/s", "bound": "mfma",
                                      "achieved": flops / (ms_h / n_h * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                     "pmc_key": "hstep_round_duo<50, 2>"}
+                                     "pmc_key": "hstep_round_lean<50>"}
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     roofline = None
     if dominant:

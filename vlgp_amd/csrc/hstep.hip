@@ -717,18 +717,18 @@ struct HRoundArgs {
     double* host;          // mapped pinned copy of `red` + sequence word at [48], or null
 };
 
-template <int T, int NW>
-__global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
+template <int T>
+__global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
+    constexpr int NW = 2;
     constexpr int H = T / 2;
     constexpr int PK = tri_packed_size(T);
-    // NW = 2: two waves, four tasks, 47 KB -> three blocks per CU (six waves).
-    // NW = 1: one wave, two tasks, 22.9 KB -> seven blocks per CU (seven waves): the per-task vectors
-    // shrink to T entries and the reciprocal diagonal of task 0 reuses kv, dead after A is built.
-    constexpr int VS = NW == 1 ? T : 64;
-    static_assert(2 * NW * PK >= hstep_prep_lds<T>() + 2 + (NW == 1 ? 256 : T * T), "K block scratch must fit");
+    // two waves, four tasks, 47 KB -> three blocks per CU (six waves); superseded by hstep_round_lean,
+    // kept as the reference implementation of the padded layout (VLGP_HSTEP_PADDED=1)
+    constexpr int VS = 64;
+    static_assert(2 * NW * PK >= hstep_prep_lds<T>() + 2 + T * T, "K block scratch must fit");
     __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PK];
     __shared__ double sw_all[NW][2][VS];
-    __shared__ double invd_all[NW == 1 ? 1 : 2 * NW][VS];
+    __shared__ double invd_all[2 * NW][VS];
     __shared__ double kv[VS], dkv[64];
     __shared__ double part[2 * NW][2];
     __shared__ int s_last;
@@ -739,16 +739,9 @@ __global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
         if (wid == 0) {
             double* base = &Lp_all[0][0][0];
             double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);
-            if constexpr (NW == 1) {
-                // kv / dkv of the K block need 64 entries each: carve them (and dk2) from the second task buffer
-                hstep_prep_body<T>(A, e, lane, base, extra, extra + 64);
-                tri_wave_sync();
-                hstep_prep_moments<T, false>(A, R.mom, R.qsum, e, lane, nullptr, extra + 128, extra + 64);
-            } else {
-                hstep_prep_body<T>(A, e, lane, base, extra + T * T, extra + T * T + 64);
-                tri_wave_sync();
-                hstep_prep_moments<T, true>(A, R.mom, R.qsum, e, lane, extra, extra + T * T + 128, extra + T * T + 64);
-            }
+            hstep_prep_body<T>(A, e, lane, base, extra + T * T, extra + T * T + 64);
+            tri_wave_sync();
+            hstep_prep_moments<T, true>(A, R.mom, R.qsum, e, lane, extra, extra + T * T + 128, extra + T * T + 64);
         }
     } else {
         const int b = blockIdx.x - R.n_eval;
@@ -759,7 +752,7 @@ __global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
             const double d = lane * A.dt, d2 = d * d;
             const double kk = sigmasq * exp(-omega * d2);
-            if (lane < VS) kv[lane] = kk + (lane == 0 ? eps : 0.0);
+            kv[lane] = kk + (lane == 0 ? eps : 0.0);
             dkv[lane] = -kk * d2 * omega;
         }
         __syncthreads();
@@ -769,9 +762,7 @@ __global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
             const bool in = q < H && valid;
             double* Lp = Lp_all[wid][h];
             double* sw = sw_all[wid][h];
-            // NW = 1: task 0 parks its reciprocal diagonal in kv (both halves finish reading kv -- the A
-            // build below -- before either writes invd in the factorisation: same wave, program order)
-            double* invd = NW == 1 ? (h == 0 ? kv : invd_all[0]) : invd_all[wid * 2 + h];
+            double* invd = invd_all[wid * 2 + h];
             const int l = A.latent[e];
             const int64_t r0row = A.off[valid ? seg : 0];
             double w0 = 0.0, w1 = 0.0;
@@ -811,13 +802,8 @@ __global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
     if (threadIdx.x == 0) {
         if ((int)blockIdx.x >= R.n_eval) {
             double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
-            if constexpr (NW == 1) {
-                o[0] = part[0][0] + part[1][0];
-                o[1] = part[0][1] + part[1][1];
-            } else {
-                o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-                o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
-            }
+            o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+            o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
         }
         const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         s_last = ticket == gridDim.x - 1;
@@ -825,7 +811,7 @@ __global__ void __launch_bounds__(64 * NW, 2) hstep_round_duo(HRoundArgs R) {
     __syncthreads();
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    constexpr int NT = 64 * NW;
+    constexpr int NT = 128;
     double* rs = &Lp_all[0][0][0];  // 2 x 128 partials
     for (int e = 0; e < R.n_eval; ++e) {
         const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
@@ -1132,20 +1118,15 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             }
             HRoundArgs R;
             R.F = F;
-            // single-wave blocks put a seventh wave on every CU but measured no faster (235 vs 260 us at three
-            // evaluations): the kernel is bound by the CU's LDS pipe, not by occupancy.  Kept for experiments.
-            static const bool one_wave = getenv("VLGP_HSTEP_NW1") != nullptr;
-            R.n_eval = n_eval; R.nb = one_wave ? (M + 1) / 2 : (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
+            R.n_eval = n_eval; R.nb = (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
             const bool mailbox = ctx->world == 1;  // multi-rank: the sums go through the all-reduce first
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
             static const bool padded = getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
-            if (one_wave)
-                hipLaunchKernelGGL((hstep_round_duo<50, 1>), dim3(n_eval + n_eval * R.nb), dim3(64), 0, ctx->stream, R);
-            else if (padded)
-                hipLaunchKernelGGL((hstep_round_duo<50, 2>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
+            if (padded)
+                hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else
                 hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
