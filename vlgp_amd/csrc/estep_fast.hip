@@ -525,6 +525,11 @@ static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, siz
     if (lds > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (getenv("VLGP_DEBUG_OCC")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, nthr, lds);
+        fprintf(stderr, "estep_fast<%d,%d,%d>: %d threads, %zu B LDS -> %d blocks per CU\n", LT, RP, RA, nthr, lds, nb);
+    }
     vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
     hipLaunchKernelGGL(fn, dim3(M), dim3(nthr), lds, ctx->stream, A, A.cols_g);
     vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)M * (A.n_iter > 0 ? A.n_iter : 1));
