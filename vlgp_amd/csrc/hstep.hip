@@ -934,23 +934,27 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
                 }
                 tri_wave_sync();
                 __builtin_amdgcn_sched_barrier(0);
-                // strictly lower half of sum_jk s_j s_k dK_jk (X'X)_jk; dK[row - j] slides like kv did
+                // strictly lower half of sum_jk s_j s_k dK_jk (X'X)_jk; dK[row - j] slides like kv did.
+                // Rows q < H only meet columns j < H - 1: their sums are skipped (statically) beyond that.
                 double c0acc = 0.0, c1acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < T; ++j) {
+                for (int j = 0; j < T - 1; ++j) {
                     const double* Xj = Lp + triu_off_u(j, T);
                     const int st = triu_off_u(j, T) & 1;  // aligned pairs start at k = j + st
+                    const bool lo = j < H - 1;              // rows of the first half still have weight
                     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
                     if (st) {
                         const double vx = Xj[0];
-                        a0 = fma(x0[j], vx, a0);
+                        if (lo) a0 = fma(x0[j], vx, a0);
                         if (j >= H) b0 = fma(x1[j - H < 0 ? 0 : j - H], vx, b0);
                     }
 #pragma unroll
                     for (int k = j + st; k + 1 < T; k += 2) {
                         const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-                        a0 = fma(x0[k], v.x, a0);
-                        a1 = fma(x0[k + 1], v.y, a1);
+                        if (lo) {
+                            a0 = fma(x0[k], v.x, a0);
+                            a1 = fma(x0[k + 1], v.y, a1);
+                        }
                         if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
                         if (k + 1 >= H) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
                         if (((k - j - st) & 14) == 14) {
@@ -960,10 +964,10 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
                     }
                     if ((T - j - st) & 1) {  // last column left over
                         const double vx = Xj[T - 1 - j];
-                        a0 = fma(x0[T - 1], vx, a0);
+                        if (lo) a0 = fma(x0[T - 1], vx, a0);
                         b0 = fma(x1[H - 1], vx, b0);
                     }
-                    c0acc = fma(a0 + a1, dkw0, c0acc);
+                    if (lo) c0acc = fma(a0 + a1, dkw0, c0acc);
                     c1acc = fma(b0 + b1, dkw1, c1acc);
                     tri_windows_step<H>(dkw0, dkw1, q, h, 0.0);
                     asm volatile("" : "+v"(c0acc), "+v"(c1acc), "+v"(dkw0), "+v"(dkw1));
