@@ -327,6 +327,39 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
         assert abs(moved[1][l, 1] - dll[1]) <= STAGE * max(abs(dll[1]), 1e-3 * abs(ll))
 
 
+def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
+    """The lean round kernel (no A in LDS, sliding register windows, eight waves per CU) against the padded
+    one and the three-launch form on 1203 segments (not a multiple of the four tasks of a block) and
+    curvatures spanning five decades: same (ll, dll) to rounding."""
+    rng = np.random.default_rng(8)
+    M, T, L = 1203, 50, 3
+    units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)),
+              "w": 10.0 ** rng.uniform(-3, 2, (T, L)), "v": np.zeros((T, L))} for _ in range(M)]
+    lat = np.array([0, 1, 2, 1, 0])
+    logp = np.log(np.array([[1.0, 2e-3, 1e-4], [0.8, 8e-3, 1e-4], [0.5, 4e-2, 1e-4], [1.0, 6e-4, 2e-4],
+                            [0.3, 1e-2, 5e-5]]))
+    with V.Engine(2, L, 1, 50) as eng:
+        eng.upload(0, units)
+        lean = eng.hstep_objective(0, T, 1.0, lat, logp)
+        monkeypatch.setenv("VLGP_HSTEP_PADDED", "1")
+    with V.Engine(2, L, 1, 50) as eng:
+        eng.upload(0, units)
+        padded = eng.hstep_objective(0, T, 1.0, lat, logp)
+        monkeypatch.setenv("VLGP_HSTEP_UNFUSED", "1")
+        unfused = eng.hstep_objective(0, T, 1.0, lat, logp)
+    for other in (padded, unfused):
+        assert relerr(other[0], lean[0]) < 1e-12
+        assert relerr(other[1][:, 1], lean[1][:, 1]) < 1e-10
+    t = np.arange(T) * 1.0
+    want = O.gp_objective(logp[2], t, np.stack([u["mu"][:, 2] for u in units[:40]], 1),
+                          np.stack([u["w"][:, 2] for u in units[:40]], 1))
+    with V.Engine(2, L, 1, 50) as eng:
+        eng.upload(0, units[:40])
+        got = eng.hstep_objective(0, T, 1.0, lat[2:3], logp[2:3])
+    assert abs(got[0][0] - want[0]) <= STAGE * abs(want[0])
+    assert abs(got[1][0, 1] - want[1][1]) <= STAGE * max(abs(want[1][1]), 1e-3 * abs(want[0]))
+
+
 @pytest.mark.parametrize("T", [25, 64, 100, 128])
 def test_hstep_objective_other_windows_vs_oracle(V, T):
     """Windows other than 50 take the generic kernels (one T x T matrix per wave in LDS, lane-strided rows

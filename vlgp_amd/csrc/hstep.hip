@@ -1128,7 +1128,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool mailbox = ctx->world == 1;  // multi-rank: the sums go through the all-reduce first
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-            static const bool padded = getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
+            const bool padded = getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
             if (padded)
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else
