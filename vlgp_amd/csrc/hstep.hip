@@ -901,7 +901,8 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
             const double d0 = q * A.dt, d1 = (q + H) * A.dt;
             const double kk0 = sigmasq * exp(-omega * d0 * d0), kk1 = sigmasq * exp(-omega * d1 * d1);
-            const double kvw0 = kk0 + (q == 0 ? eps : 0.0), kvw1 = kk1;
+            const double odt2 = omega * A.dt * A.dt;
+            const double g0 = exp(odt2 * (2 * q - 1)), g1 = exp(odt2 * (2 * (q + H) - 1)), gc = exp(-2.0 * odt2);
             double dkw0 = -kk0 * d0 * d0 * omega, dkw1 = -kk1 * d1 * d1 * omega;
             if (q < H) {  // s_k waits in the diagonal slot of row k until step k replaces it by 1 / L[k][k]
                 Lp[tri_off_u(q) + q] = sw0;
@@ -912,7 +913,7 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
             bool ok;
             {
                 double r0[H], r1[T];
-                ok = wave_chol_rows_duo_lean<T>(r0, r1, Lp, q, h, sw0, sw1, kvw0, kvw1);
+                ok = wave_chol_rows_duo_lean<T>(r0, r1, Lp, q, h, sw0, sw1, kk0, kk1, g0, g1, gc, eps);
             }
             {
                 double x0[T], x1[H];

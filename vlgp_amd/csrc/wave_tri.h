@@ -360,14 +360,19 @@ __device__ __forceinline__ void tri_windows_step(double& w0, double& w1, int q, 
 }
 
 // Factor A = I + S K S without ever storing A.  sw0/sw1: sqrt(w) of rows q, q + T/2; kvw0/kvw1:
-// first column of K at distances q and q + T/2 (kv[0] includes the jitter).  The diagonal slot of
+// jitter-free first column of K, sigma^2 exp(-omega (d dt)^2), at distances d = q and q + T/2;
+// g0/g1 = exp(omega dt^2 (2 d - 1)) at those distances, gc = exp(-2 omega dt^2): the column obeys
+// kv0[d-1] = kv0[d] g_d with g_{d-1} = g_d gc, so every lane walks its own two values down to
+// distance zero (and symmetrically beyond) with two multiplies a step -- fifty steps cost ~1e-14
+// relative, far inside the parity tolerance; eps = the jitter on the diagonal of K.  The diagonal slot of
 // row k holds s_k on entry (the caller puts it there) and 1 / L[k][k] on exit; L strictly below the
 // diagonal (unpadded packed).  Unpadded rows start at even or odd offsets: the pivot-row pairs are
 // formed from index 0 or 1 accordingly (static), so that every pair is one aligned ds_read_b128
 // with an immediate offset.
 template <int T>
 __device__ __forceinline__ bool wave_chol_rows_duo_lean(double (&r0)[T / 2], double (&r1)[T], double* Lp, int q, int h,
-                                                        double sw0, double sw1, double kvw0, double kvw1) {
+                                                        double sw0, double sw1, double kvw0, double kvw1,
+                                                        double g0, double g1, double gc, double eps) {
     constexpr int H = T / 2;
     const bool in = q < H;
     const int off0 = tri_off_u(in ? q : 0), off1 = tri_off_u(in ? q + H : H);
@@ -378,8 +383,9 @@ __device__ __forceinline__ bool wave_chol_rows_duo_lean(double (&r0)[T / 2], dou
         const int st = tri_off_u(k) & 1;  // first index of the aligned pairs
         const double sk = Lk[k];          // s_k, parked in the diagonal slot
         double s0 = 0.0, s0b = 0.0, s1b = 0.0;
-        if (k < H) s0 = fma(sw0 * sk, kvw0, q == k ? 1.0 : 0.0);                // A[q][k]
-        double s1 = fma(sw1 * sk, kvw1, q + H == k ? 1.0 : 0.0);                // A[q + H][k]
+        // A[row][k] = s_row s_k kv0[row - k] + (row == k) (1 + s_k^2 eps)
+        if (k < H) s0 = fma(sw0 * sk, kvw0, q == k ? fma(sw0 * sk, eps, 1.0) : 0.0);
+        double s1 = fma(sw1 * sk, kvw1, q + H == k ? fma(sw1 * sk, eps, 1.0) : 0.0);
         if (st && k > 0) {
             const double lv = Lk[0];
             if (k < H) s0 = fma(-r0[0], lv, s0);
@@ -417,8 +423,15 @@ __device__ __forceinline__ bool wave_chol_rows_duo_lean(double (&r0)[T / 2], dou
         }
         r1[k] = s1 * inv;
         if (in && q + H >= k) Lp[off1 + k] = (q + H == k) ? inv : r1[k];
-        tri_windows_step<H>(kvw0, kvw1, q, h, 0.0);
-        asm volatile("" : "+v"(kvw0), "+v"(kvw1));
+        // next distance: kv0[d - 1] = kv0[d] g_d, g_{d-1} = g_d e^{-2 omega dt^2} (each lane advances its own
+        // two window values; no cross-lane traffic)
+        if (k < H) {
+            kvw0 *= g0;
+            g0 *= gc;
+        }
+        kvw1 *= g1;
+        g1 *= gc;
+        asm volatile("" : "+v"(kvw0), "+v"(kvw1), "+v"(g0), "+v"(g1));
         tri_wave_order();
         __builtin_amdgcn_sched_barrier(0);
     }
