@@ -208,6 +208,15 @@ def main():
                                      "units_per_launch": u_h / n_h, "unit": "TFLOP/s", "bound": "mfma",
                                      "achieved": flops / (ms_h / n_h * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
                                      "pmc_key": "hstep_round_lean<50>"}
+    # north_star also asks for the HBM side of the factorisation kernels: measured bytes (PMC passes on
+    # file) over the live launch time, against the 8 TB/s peak -- expected far below 1 % for these
+    # compute-bound kernels
+    for kd in kernels.values():
+        tb = pmc_traffic(kd["pmc_key"])
+        if tb:
+            kd["hbm_bytes_per_launch_pmc"] = tb
+            kd["hbm_gbs"] = tb / (kd["avg_ms"] * 1e-3) / 1e9
+            kd["hbm_frac"] = kd["hbm_gbs"] / HBM_PEAK_GBS
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     roofline = None
     if dominant:
@@ -215,6 +224,7 @@ def main():
         roofline = {"kernel": dominant, "bound": kd["bound"], "achieved": kd["achieved"], "peak": kd["peak"],
                     "unit": kd["unit"], "frac": kd["achieved"] / kd["peak"],
                     "traffic": pmc_traffic(kd["pmc_key"]),
+                    "hbm_gbs": kd.get("hbm_gbs"), "hbm_frac": kd.get("hbm_frac"),
                     "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"],
                     "units_per_launch": kd["units_per_launch"]}
 
