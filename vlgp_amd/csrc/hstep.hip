@@ -11,6 +11,7 @@
 // tr(K^-1 dK), log det.  Per segment (one wavefront each, factor in LDS):
 // Cholesky of K^-1 + W, its triangular inverse X, and the two Frobenius
 // products <X'X, K^-1>, <X'X, Q> accumulated without materialising S.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1168,6 +1169,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
         }
         // K did not factor for some evaluation: fall through to the generic path,
         // which implements the reference's omega bump
+        if (getenv("VLGP_DEBUG_OCC")) fprintf(stderr, "hstep: K failed to factor in a round of %d evaluations -> generic kernels\n", n_eval);
     }
     for (int i = 0; i < 3 * n_eval; ++i) hp[i] = logp[i];
     int* hlat = reinterpret_cast<int*>(hp + 3 * n_eval);

@@ -55,7 +55,9 @@ static inline int nstat_rt(int L, int P, int kind) {
 }
 
 template <int LT, int PT, int KIND>
-__global__ void __launch_bounds__(512, 4) mstep_accum(MArgs A) {
+// four waves per SIMD (128 VGPRs) up to five latents; the 2 L + L (L + 1) / 2 accumulators of more latents
+// need the registers more than the occupancy
+__global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_accum(MArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NA = nacc<LT, PT, KIND>();
     const int N = A.N, L = A.L, P = A.P, CT = A.CT, S = A.S;
