@@ -47,8 +47,8 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) estep_kernel(EstepArgs A) 
 
     // ---- carve LDS ------------------------------------------------------
     double* p = smem;
-    double* a_s = p;      p += L * N;
-    double* asq_s = p;    p += L * N;
+    double* a_s = p;      p += LT * N;   // rows l >= L are zero: the (T x N) passes need no l < L tests
+    double* asq_s = p;    p += LT * N;
     double* bvec = p;     p += N;
     double* cn = p;       p += N;
     double* wconst = p;   p += (L + 1) & ~1;
@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) estep_kernel(EstepArgs A) 
     int* fail_s = ip;   ip += L;
 
     // ---- stage parameters and the unit state -----------------------------
-    for (int i = tid; i < L * N; i += nthr) {
-        const double av = A.a[i];
+    for (int i = tid; i < LT * N; i += nthr) {
+        const double av = i < L * N ? A.a[i] : 0.0;
         a_s[i] = av;
         asq_s[i] = av * av;
     }
@@ -148,49 +148,55 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) estep_kernel(EstepArgs A) 
     const int sub = tid & (RG - 1), rgid = tid / RG, nrg = nthr / RG;
 
     // ---- (T x N) passes: lanes of a row group stride over channels --------
+    // Branch-free body: the loadings are zero-padded to LT rows, Poisson / Gaussian is a select, the
+    // regressor term comes from one of two uniform sources (a per-latent `l < L` branch or a
+    // global-vs-LDS pointer select costs a wait per load; see estep_long.hip).
+    const bool has_xb = A.xb != nullptr;
     auto tn_pass = [&](auto kind_c) {
         constexpr int KIND = decltype(kind_c)::value;
         for (int row = rgid; row < T; row += nrg) {
             double mr[LT], vr[LT], acc[LT];
 #pragma unroll
             for (int l = 0; l < LT; ++l) {
-                const bool in = l < L;
-                mr[l] = (KIND != PASS_YA && in) ? mu_s[row * L + l] : 0.0;
-                vr[l] = (KIND != PASS_YA && in) ? v_s[row * L + l] : 0.0;
+                const int lc = l < L ? l : 0;
+                const double mv = KIND != PASS_YA ? mu_s[row * L + lc] : 0.0;
+                const double vv = KIND != PASS_YA ? v_s[row * L + lc] : 0.0;
+                mr[l] = l < L ? mv : 0.0;
+                vr[l] = l < L ? vv : 0.0;
                 acc[l] = 0.0;
             }
             const double* yrow = A.y + (r0 + row) * N;
-            const double* xbrow = A.xb ? A.xb + (r0 + row) * N : nullptr;
+            const double* xbrow = A.xb + (has_xb ? (r0 + row) * N : 0);
             for (int n = sub; n < N; n += RG) {
-                if constexpr (KIND == PASS_YA) {
-                    const double yc = yrow[n] * cn[n];
+                double al[LT], aq[LT];
 #pragma unroll
-                    for (int l = 0; l < LT; ++l)
-                        if (l < L) acc[l] = fma(yc, a_s[l * N + n], acc[l]);
+                for (int l = 0; l < LT; ++l) {
+                    al[l] = a_s[l * N + n];
+                    aq[l] = asq_s[l * N + n];
+                }
+                const double cnn = cn[n];
+                const int g = gauss_s[n];
+                if constexpr (KIND == PASS_YA) {
+                    const double yc = yrow[n] * cnn;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) acc[l] = fma(yc, al[l], acc[l]);
                 } else {
-                    double eta = xbrow ? xbrow[n] : bvec[n];
+                    double eta = has_xb ? xbrow[n] : bvec[n];
                     double lin = 0.0;
 #pragma unroll
-                    for (int l = 0; l < LT; ++l)
-                        if (l < L) {
-                            eta = fma(mr[l], a_s[l * N + n], eta);
-                            lin = fma(vr[l], asq_s[l * N + n], lin);
-                        }
-                    const int g = gauss_s[n];
+                    for (int l = 0; l < LT; ++l) {
+                        eta = fma(mr[l], al[l], eta);
+                        lin = fma(vr[l], aq[l], lin);
+                    }
+                    const double pois = exp(fmin(fma(0.5, lin, eta), 10.0));
                     if constexpr (KIND == PASS_RES) {
-                        double mval;
-                        if (g) mval = eta * cn[n];
-                        else mval = exp(fmin(fma(0.5, lin, eta), 10.0));
+                        const double mval = g ? eta * cnn : pois;
 #pragma unroll
-                        for (int l = 0; l < LT; ++l)
-                            if (l < L) acc[l] = fma(mval, a_s[l * N + n], acc[l]);
+                        for (int l = 0; l < LT; ++l) acc[l] = fma(mval, al[l], acc[l]);
                     } else {
-                        if (!g) {
-                            const double rate = exp(fmin(fma(0.5, lin, eta), 10.0));
+                        const double rate = g ? 0.0 : pois;
 #pragma unroll
-                            for (int l = 0; l < LT; ++l)
-                                if (l < L) acc[l] = fma(rate, asq_s[l * N + n], acc[l]);
-                        }
+                        for (int l = 0; l < LT; ++l) acc[l] = fma(rate, aq[l], acc[l]);
                     }
                 }
             }
@@ -436,7 +442,8 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     lcsz = (lcsz + 1) & ~1LL;
 
     const int64_t LDS_MAX = 160 * 1024;
-    const int64_t common = 2LL * L * N + 2LL * N + ((L + 1) & ~1);
+    const int LTl = L <= 2 ? 2 : (L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : (L <= 10 ? 10 : 16))));  // as launch_l dispatches
+    const int64_t common = 2LL * LTl * N + 2LL * N + ((L + 1) & ~1);
     const int64_t ints = ((int64_t)N + 4 * L + 1) / 2 + 1;
 
     EstepArgs A;
