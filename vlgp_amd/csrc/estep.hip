@@ -486,6 +486,13 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
         return rc;
     }
 
+    // too big for LDS residency (many latents at high rank): the long-unit kernel streams G from L2
+    {
+        int handled = 0;
+        CHK(launch_estep_long(ctx, us, A, &handled));
+        if (handled) return VLGP_OK;
+    }
+
     // LONG: unit state in HBM/L2, factors in LDS when they fit
     const int nthr = 1024, nw = nthr / 64;
     int64_t long_d = common + 2LL * nw * 64 + ints;
