@@ -32,7 +32,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // the unrolled factor / solve loops (RA = 24 serves ranks 17..24 with 3/4 of the registers of RA = 32,
 // which is what lets two workgroups share a CU).
 template <int LT, int RP, int RA = RP>
-__global__ void __launch_bounds__(512, (RP <= 16 ? 4 : (RA <= 24 ? 3 : 1)))
+__global__ void __launch_bounds__((LT > 8 ? 640 : 512), (LT > 8 ? 3 : (RP <= 16 ? 4 : (RA <= 24 ? 3 : 1))))
 estep_fast_kernel(EstepArgs A, const double* __restrict__ cols_g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int REC = 2 * LT + 2;          // a[LT], a^2[LT], b, c  (even -> 16-byte records)
@@ -541,14 +541,16 @@ template <int RP, int RA>
 static int launch_fast_l(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t lds) {
     if (A.L <= 3) return launch_fast_t<3, RP, RA>(ctx, A, M, nthr, lds);
     if (A.L <= 5) return launch_fast_t<5, RP, RA>(ctx, A, M, nthr, lds);
-    return launch_fast_t<8, RP, RA>(ctx, A, M, nthr, lds);
+    if (A.L <= 8) return launch_fast_t<8, RP, RA>(ctx, A, M, nthr, lds);
+    if constexpr (RA == 16) return launch_fast_t<10, RP, RA>(ctx, A, M, nthr, lds);  // ten waves, one workgroup per CU
+    return vlgp_fail(ctx, VLGP_ERR_STATE, "no fast E-step instantiation for %d latents at this rank", A.L);
 }
 
 int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     *handled = 0;
     const int N = ctx->N, L = ctx->L;
     if (getenv("VLGP_ESTEP_GENERIC")) return VLGP_OK;
-    if (us.Tmax > 64 || L > 8) return VLGP_OK;
+    if (us.Tmax > 64 || L > 10) return VLGP_OK;
     const bool need_prior = (A.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
     int rmax = 0;
     int64_t gsz = 0;
@@ -564,9 +566,9 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
             gsz = g > gsz ? g : gsz;
         }
     }
-    if (rmax > 32) return VLGP_OK;
+    if (rmax > 32 || (L > 8 && rmax > 16)) return VLGP_OK;  // nine or ten latents: only the rank <= 16 instantiation
     const int RP = rmax <= 16 ? 16 : 32;
-    const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : 8);
+    const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : 10));
     const int nw = L < 4 ? 4 : L;  // L <= 8
     const int Tc = us.Tmax;
     const int RA = rmax <= 16 ? 16 : (rmax <= 24 && !getenv("VLGP_ESTEP_NO_RA24") ? 24 : 32);
