@@ -107,6 +107,7 @@ struct vlgp_ctx {
     void* comm = nullptr;         // ncclComm_t
     void* shm = nullptr;          // shared-memory test transport (VLGP_COMM_TRANSPORT=shm), main lane
     void* shm_m = nullptr;        // ... M-step lane
+    void* hx = nullptr;           // host-side exchange segment for the H-step round sums (single node)
     int rank = 0, world = 1;
 
     std::string err;
@@ -130,6 +131,7 @@ int vlgp_fail(vlgp_ctx* ctx, int code, const char* fmt, ...);
 int vlgp_ensure_work(vlgp_ctx* ctx, int64_t n_doubles);
 int vlgp_ensure_pinned(vlgp_ctx* ctx, int64_t n_doubles);
 int vlgp_allreduce(vlgp_ctx* ctx, double* d_buf, int64_t n);  // in place, sum, on ctx->stream
+int vlgp_hx_allreduce(vlgp_ctx* ctx, double* h_vals, int n);   // host values, n <= 64, rank-order sum; needs ctx->hx
 int vlgp_allreduce_m(vlgp_ctx* ctx, double* d_buf, int64_t n);  // same on the M-step lane (comm_m, mstream)
 int vlgp_ensure_work_m(vlgp_ctx* ctx, int64_t n_doubles);
 int vlgp_join_m(vlgp_ctx* ctx);  // wait for a pending asynchronous M-step

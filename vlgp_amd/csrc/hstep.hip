@@ -1127,7 +1127,10 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             R.n_eval = n_eval; R.nb = (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
-            const bool mailbox = ctx->world == 1;  // multi-rank: the sums go through the all-reduce first
+            // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
+            // their sums on the host (vlgp_hx_allreduce); without the exchange segment the sums go through the
+            // device all-reduce and a copy instead
+            const bool mailbox = ctx->world == 1 || ctx->hx != nullptr;
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
             const bool padded = getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
@@ -1150,6 +1153,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                 }
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 for (int i = 0; i < 3 * n_eval; ++i) hres[i] = ctx->h_hres[i];
+                if (ctx->world > 1) CHK(vlgp_hx_allreduce(ctx, hres, 2 * n_eval));
             } else {
                 CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
                 HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
