@@ -181,6 +181,10 @@ int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES], int rank,
  * all-reduces may overlap the H-step's; without it a multi-rank M-step runs
  * its collectives un-overlapped on the first communicator's stream order. */
 int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]);
+/* 1 when the ranks share the host-side exchange segment for the H-step round sums (single node,
+ * world > 1): the H-step then issues no RCCL collective, so the M-step lane may run concurrently with
+ * it across ranks (its communicator is the only one in flight). */
+int vlgp_comm_host_exchange(vlgp_ctx* ctx);
 /* In-place sum over ranks of n host doubles (staged through the device, on the
  * handle's stream, synchronous).  With no communicator attached it is a no-op.
  * n == 0 is a pure barrier. */

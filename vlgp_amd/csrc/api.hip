@@ -385,6 +385,8 @@ extern "C" int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BY
     return VLGP_OK;
 }
 
+extern "C" int vlgp_comm_host_exchange(vlgp_ctx* ctx) { return ctx && ctx->hx ? 1 : 0; }
+
 extern "C" int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n) {
     NEED_CTX(ctx);
     if (n < 0 || (n > 0 && !buf)) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad allreduce arguments");

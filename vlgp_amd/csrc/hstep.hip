@@ -1175,6 +1175,9 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
         // which implements the reference's omega bump
         if (getenv("VLGP_DEBUG_OCC")) fprintf(stderr, "hstep: K failed to factor in a round of %d evaluations -> generic kernels\n", n_eval);
     }
+    // generic path: its sums go through the main communicator; with several ranks the M-step lane's
+    // collectives must not be in flight at the same time (two communicators, no common order)
+    if (ctx->world > 1) CHK(vlgp_join_m(ctx));
     for (int i = 0; i < 3 * n_eval; ++i) hp[i] = logp[i];
     int* hlat = reinterpret_cast<int*>(hp + 3 * n_eval);
     for (int i = 0; i < n_eval; ++i) hlat[i] = latent[i];

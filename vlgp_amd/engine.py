@@ -61,6 +61,7 @@ class Engine:
         self.h = h
         self.sets = {}  # set id -> (M, rows, offsets)
         self.rank, self.world = 0, 1
+        self.host_exchange = False
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -266,6 +267,7 @@ class Engine:
         if uid_aux is not None:
             self._ck(self.lib.vlgp_comm_init_aux(self.h, uid_aux))
         self.rank, self.world = int(rank), int(world)
+        self.host_exchange = bool(self.lib.vlgp_comm_host_exchange(self.h))
 
     def allreduce_host(self, arr):
         """In-place sum over ranks of a float64 host array (no-op on one GPU)."""
@@ -618,10 +620,11 @@ def em_iteration(trials, params, config, runtime, echo=None):
         _pull_params(eng, params)
         return ms
 
-    # With several ranks the two lanes' RCCL collectives would be in flight at once on two
-    # communicators; ranks could enqueue them in different orders, so the overlap is a
-    # single-GPU optimisation and multi-rank runs finish M before starting H.
-    if m_async and (eng.world > 1 or os.environ.get("VLGP_M_SEQUENTIAL")):
+    # With several ranks the M-step lane issues RCCL all-reduces on its own communicator.  That is safe
+    # under the H-step only when the H-step issues none itself, i.e. when its round sums are exchanged on
+    # the host (Engine.host_exchange); otherwise two communicators would be in flight with no common
+    # order across ranks, and the M-step is finished first.
+    if m_async and ((eng.world > 1 and not eng.host_exchange) or os.environ.get("VLGP_M_SEQUENTIAL")):
         m_ms = finish_m()
         m_async = False
     t2 = time.perf_counter()
