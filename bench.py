@@ -236,7 +236,8 @@ def main():
         "config": {"workload": "%s: %d trials x %d bins x %d Poisson channels, %d latents, window %d -> %d segments; "
                                "Eniter=Mniter=25, rank 50, VB, Hstep on" % (args.workload, n_trials, n_bins, N, L,
                                                                              cfg["window"], n_seg),
-                   "parallelism": "trials sharded over %d rank(s), RCCL all-reduce of M/H-step statistics" % world},
+                   "parallelism": "trials sharded over %d rank(s); RCCL all-reduce of the M-step statistics and norms, "
+                                  "H-step round sums added on the host (shared memory)" % world},
         "ms_per_e_step": phase_ms["e"], "ms_per_m_step": phase_ms["m"], "ms_per_h_step": phase_ms["h"],
         "roofline": roofline, "kernels": kernels,
         "effective_rank": ranks_used, "omega_final": omega,

@@ -1,11 +1,12 @@
 """Multi-GPU plumbing: one process per GPU, units block-partitioned over ranks,
 parameters replicated.
 
-The data path has exactly one kind of exchange: RCCL ``allReduce(sum, fp64)``
-over xGMI of small fused buffers -- the M-step sufficient statistics (once per
-Newton iteration), the H-step (ll, dll) pairs (once per objective evaluation)
-and the convergence norms -- all issued by ``libvlgp_hip.so`` on the engine's
-own stream.  E-step, update_w/v and the final inference need no communication.
+The data path has two exchanges, both issued by ``libvlgp_hip.so``: RCCL
+``allReduce(sum, fp64)`` over xGMI of small fused buffers -- the M-step
+sufficient statistics (once per Newton iteration) and the convergence norms
+-- and a host-side rank-order sum of the H-step (ll, dll) pairs (once per
+round; every rank's round kernel already publishes them to its host).  E-step,
+update_w/v and the final inference need no communication.
 
 This module only (a) splits the trial list, (b) gets the 128-byte RCCL unique
 id from rank 0 to the other ranks of the node, (c) attaches the communicator.
