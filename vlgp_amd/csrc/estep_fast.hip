@@ -407,20 +407,32 @@ estep_fast_kernel(EstepArgs A, const double* __restrict__ cols_g) {
             tri_wave_sync();
             // z = X rhs, sol = X' z   (lane = row, then lane = column)
             double z = 0.0;
-            if (lane < RA) {
+            if (lane < RA) {  // four partial sums: the dependent FMA chain is RA / 4 long instead of RA
                 const double* Xi = Xl + tri_row_off(lane);
+                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
 #pragma unroll
-                for (int q = 0; q < RA; ++q)
-                    if (q <= lane) z = fma(Xi[q], vec2[q], z);
+                for (int q = 0; q < RA; q += 4) {
+                    if (q <= lane) z0 = fma(Xi[q], vec2[q], z0);
+                    if (q + 1 <= lane) z1 = fma(Xi[q + 1], vec2[q + 1], z1);
+                    if (q + 2 <= lane) z2 = fma(Xi[q + 2], vec2[q + 2], z2);
+                    if (q + 3 <= lane) z3 = fma(Xi[q + 3], vec2[q + 3], z3);
+                }
+                z = (z0 + z1) + (z2 + z3);
             }
             tri_wave_sync();
             if (lane < RA) vec[lane] = z;
             tri_wave_sync();
             double sol = 0.0;
             if (lane < RA) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                for (int q = 0; q < RA; ++q)
-                    if (q >= lane) sol = fma(Xl[tri_row_off(q) + lane], vec[q], sol);
+                for (int q = 0; q < RA; q += 4) {
+                    if (q >= lane) s0 = fma(Xl[tri_row_off(q) + lane], vec[q], s0);
+                    if (q + 1 >= lane) s1 = fma(Xl[tri_row_off(q + 1) + lane], vec[q + 1], s1);
+                    if (q + 2 >= lane) s2 = fma(Xl[tri_row_off(q + 2) + lane], vec[q + 2], s2);
+                    if (q + 3 >= lane) s3 = fma(Xl[tri_row_off(q + 3) + lane], vec[q + 3], s3);
+                }
+                sol = (s0 + s1) + (s2 + s3);
             }
             tri_wave_sync();
             if (lane < RA) vec2[lane] = sol;
