@@ -142,7 +142,7 @@ int vlgp_mstep_end(vlgp_ctx* ctx, int* n_failed, double* device_ms);
  * latent[e] and log-parameters logp[3e..3e+2] = log(sigma^2, omega, eps).
  * Outputs the UN-negated ll[e] and dll[3e..3e+2] summed over all units of the
  * set (and over ranks).  Every unit must have exactly `window` rows, window <= 128
- * (50, the reference's default, has a dedicated kernel). */
+ * (windows <= 50 -- 50 is the reference's default -- share a dedicated kernel). */
 int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_eval,
                          const int* latent, const double* logp, double* ll,
                          double* dll);

@@ -1,0 +1,14 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, "/root/repo")
+import bench
+from vlgp_amd.api import FitSession
+trials, a0, b0, dims = bench.build_inputs("C3")
+for window in (40, 50, 100):
+    tr = [{"ID": t["ID"], "y": t["y"], "mu": t["mu"].copy()} for t in trials]
+    sess = FitSession(tr, dims[3], verbose=False, a=a0.copy(), b=b0.copy(), max_iter=8, min_iter=8, window=window)
+    for _ in range(6):
+        sess.em_iteration()
+    rt = sess.runtime
+    print("window %3d: E %.1f M %.1f H %.1f ms (iteration 6), segments %d" % (window, 1e3 * rt["e_elapsed"][-1], 1e3 * rt["m_elapsed"][-1], 1e3 * rt["h_elapsed"][-1], len(sess.segs)))
+    sess.close()

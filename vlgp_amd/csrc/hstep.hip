@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* 
 // ===========================================================================
 struct HFastArgs {
     int L, M;
+    int Tr;              // rows actually present per segment (<= the compiled window T): rows Tr..T-1 are
+                         // identity padding (K block-diagonal with I, w = mu = 0), which leaves every term but
+                         // tr(A^-1) unchanged; that one is corrected by T - Tr
     double dt;
     const int64_t* off;
     const double* mu;
@@ -319,8 +322,9 @@ __device__ __forceinline__ void hstep_prep_body(const HFastArgs& A, int e, int l
     tri_wave_sync();
     if (lane < T) {
         const int my_off = tri_row_off(lane);
+        const bool real = lane < A.Tr;  // padding rows are unit vectors
 #pragma nounroll
-        for (int i = 0; i <= lane; ++i) Lp[my_off + i] = kv[lane - i];
+        for (int i = 0; i <= lane; ++i) Lp[my_off + i] = real ? kv[lane - i] : (i == lane ? 1.0 : 0.0);
     }
     tri_wave_sync();
     __builtin_amdgcn_sched_barrier(0);
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(128, 2) hstep_seg_duo(HFastArgs A) {
 // H-step (vlgp_hstep_begin) and every evaluation's K block reduces it in ~10 us.
 // ---------------------------------------------------------------------------
 template <int T>
-__global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, const int64_t* off, const double* mu,
+__global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, int Tr, const int64_t* off, const double* mu,
                                                            int nchunk, double* part) {
     constexpr int NE = (T * T + 255) / 256;
     __shared__ double s[4][64];
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, const i
         __syncthreads();
         {
             const int sg = tid >> 6, t = tid & 63;
-            s[sg][t] = (m + sg < m1 && t < T) ? mu[(off[m + sg] + t) * L + l] : 0.0;
+            s[sg][t] = (m + sg < m1 && t < Tr) ? mu[(off[m + sg] + t) * L + l] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -893,9 +897,9 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
             const int l = A.latent[e];
             const int64_t r0row = A.off[valid ? seg : 0];
             double w0 = 0.0, w1 = 0.0;
-            if (in) {
-                w0 = A.w[(r0row + q) * A.L + l];
-                w1 = A.w[(r0row + q + H) * A.L + l];
+            if (in) {  // rows >= Tr are identity padding: zero curvature
+                if (q < A.Tr) w0 = A.w[(r0row + q) * A.L + l];
+                if (q + H < A.Tr) w1 = A.w[(r0row + q + H) * A.L + l];
             }
             const double sw0 = sqrt(w0), sw1 = sqrt(w1);
             // this lane's entries of the first columns of K and dK/dln omega (distances q and q + H)
@@ -983,6 +987,7 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
                 tr += __shfl_xor(tr, o, 64);
                 cacc += __shfl_xor(cacc, o, 64);
             }
+            if (valid) tr -= (double)(T - A.Tr);  // the identity padding's share of tr(A^-1)
         }
         if ((lane & 31) == 0) {
             part[wid * 2 + (lane >> 5)][0] = tr;
@@ -1065,12 +1070,13 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     if (T > HS_MAXT) return vlgp_fail(ctx, VLGP_ERR_ARG, "H-step kernel supports window <= %d, got %d", HS_MAXT, T);
     if (us.Tmin != T || us.Tmax != T)
         return vlgp_fail(ctx, VLGP_ERR_STATE, "H-step needs every unit to have exactly window=%d rows", T);
-    const int64_t TT = (int64_t)T * T;
+    const bool fast = T <= 50 && !getenv("VLGP_HSTEP_GENERIC");  // the T = 50 kernels, identity-padded
+    const int64_t TT = fast ? 2500 : (int64_t)T * T;
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
     const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
     const int64_t o_lat = o_logp + 3 * n_eval, o_qsum = o_lat + n_eval + 8, o_mpart = o_qsum + 2 * n_eval + 2;
-    const int64_t o_tm = o_mpart + (T == 50 ? (int64_t)L * 64 * TT : 0);
+    const int64_t o_tm = o_mpart + (fast ? (int64_t)L * 64 * TT : 0);
     const int64_t total = o_tm + (T > 64 ? n_eval * TT : 0);
     CHK(vlgp_ensure_work(ctx, total));
     CHK(vlgp_ensure_pinned(ctx, 12 * n_eval + 32));
@@ -1080,14 +1086,14 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     for (int i = 0; i < n_eval; ++i)
         if (latent[i] < 0 || latent[i] >= L) return vlgp_fail(ctx, VLGP_ERR_ARG, "latent index out of range");
 
-    if (T == 50 && !getenv("VLGP_HSTEP_GENERIC")) {
+    if (fast) {
         HFastArgs F;
-        F.L = L; F.M = M; F.dt = dt; F.off = us.d_off; F.mu = us.mu; F.w = us.w;
+        F.L = L; F.M = M; F.Tr = T; F.dt = dt; F.off = us.d_off; F.mu = us.mu; F.w = us.w;
         for (int i = 0; i < n_eval; ++i) F.latent[i] = latent[i];
         for (int i = 0; i < 3 * n_eval; ++i) F.logp[i] = logp[i];
         F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
         double* hres = hp + 4 * n_eval + 8;
-        if (getenv("VLGP_HSTEP_UNFUSED")) {
+        if (T == 50 && getenv("VLGP_HSTEP_UNFUSED")) {
             CHK(launch_fast<50>(ctx, F, n_eval, M));
             // red: [2 n_eval] (ll, dll) pairs, then [n_eval] "K factored" flags -> one device->host copy
             hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red,
@@ -1114,7 +1120,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             }
             if (!ctx->hmom_bracket || ctx->hmom_us != &us || ctx->hmom_T != T) {
                 // second moments of mu: once per vlgp_hstep_begin bracket, else per call
-                hipLaunchKernelGGL((hstep_moment_kernel<HT>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, us.d_off,
+                hipLaunchKernelGGL((hstep_moment_kernel<HT>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T, us.d_off,
                                    us.mu, NCH, W + o_mpart);
                 hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, ctx->stream, NCH,
                                    HT * HT, W + o_mpart, ctx->d_hmom);
@@ -1133,7 +1139,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool mailbox = ctx->world == 1 || ctx->hx != nullptr;
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-            const bool padded = getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
+            const bool padded = T == 50 && getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
             if (padded)
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else
