@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 import bench
 from vlgp_amd.api import FitSession
 trials, a0, b0, dims = bench.build_inputs("C3")
-for window in (40, 50, 100):
+for window in [int(w) for w in os.environ.get("WINDOWS", "40,50,100").split(",")]:
     tr = [{"ID": t["ID"], "y": t["y"], "mu": t["mu"].copy()} for t in trials]
     sess = FitSession(tr, dims[3], verbose=False, a=a0.copy(), b=b0.copy(), max_iter=8, min_iter=8, window=window)
     for _ in range(6):
