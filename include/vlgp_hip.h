@@ -210,6 +210,10 @@ int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, double* total_m
  * factor, 2 residual pass, 3 mean update, 4 curvature pass, 5 factor + variance).
  * `out` may be NULL; on != 0 also zeroes the counters. */
 int vlgp_debug_phase_clock(vlgp_ctx* ctx, int on, uint64_t out[8]);
+/* Element-wise probe of the device arithmetic the prior kernel relies on being bit-identical to the
+ * reference's NumPy (vlgp/math.py:113-119): kind 0 out = exp(a) as np.exp computes it, 1 out = sqrt(a),
+ * 2 out = a / b, 3 out = fma(a, b, out).  Host arrays of n doubles; b may be NULL for kinds 0, 1. */
+int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const double* b, double* out);
 
 #ifdef __cplusplus
 }

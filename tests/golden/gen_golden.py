@@ -307,6 +307,30 @@ def gen_fit():
          dmu=np.stack([t["dmu"] for t in res["trials"]]))
 
 
+def gen_fit_h1():
+    """fit end to end with the H-step ON (the default) and with every default left alone."""
+    trials0, a0, b0, mu0 = c1_inputs()
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy()} for t, m in zip(trials0, mu0)]
+    np.random.seed(3)
+    res = ref_api.fit(trials, 3, a=a0.copy(), b=b0.copy(), max_iter=5, min_iter=5)
+    p = res["params"]
+    out = dict(a0=a0, b0=b0, mu0=np.stack(mu0), y=np.stack([t["y"] for t in trials0]).astype(np.uint8),
+               a=p["a"], b=p["b"], noise=p["noise"], omega=p["omega"], sigma=p["sigma"],
+               G200=p["cholesky"][200], it=res["config"]["runtime"]["it"])
+    for k in ("mu", "v", "w", "dmu"):
+        out[k] = np.stack([t[k] for t in res["trials"]])
+    # nothing injected: FactorAnalysis initialisation on the seeded subsample, default iteration counts
+    trials = [{"ID": t["ID"], "y": t["y"].copy()} for t in trials0]
+    np.random.seed(5)
+    res = ref_api.fit(trials, 3, max_iter=8)
+    p = res["params"]
+    out.update(d_a=p["a"], d_b=p["b"], d_noise=p["noise"], d_omega=p["omega"], d_sigma=p["sigma"],
+               d_G200=p["cholesky"][200], d_it=res["config"]["runtime"]["it"])
+    for k in ("mu", "v", "w"):
+        out["d_" + k] = np.stack([t[k] for t in res["trials"]])
+    save("fit_c1_h1", **out)
+
+
 def gen_init():
     """preprocess.initialize on C1 (FactorAnalysis on the seeded 10 % subsample)."""
     from vlgp.preprocess import initialize
@@ -324,10 +348,6 @@ def gen_init():
 if __name__ == "__main__":
     os.chdir("/tmp")  # the reference writes vlgp.log into the cwd at import
     check_generator()
-    gen_ichol()
-    gen_estep()
-    gen_mstep()
-    gen_hstep()
-    gen_vem()
-    gen_fit()
-    gen_init()
+    todo = sys.argv[1:] or ["ichol", "estep", "mstep", "hstep", "vem", "fit", "init", "fit_h1"]
+    for name in todo:  # `gen_golden.py fit_h1` regenerates one fixture
+        globals()["gen_" + name]()

@@ -40,47 +40,89 @@ def _units(g, keys=("y", "x", "mu", "v", "w")):
 
 
 # ------------------------------------------------------------------ prior
-def test_ichol_device_vs_oracle(V):
-    for T, omegas in ((50, [5e-2, 5e-3, 5e-4]), (64, [2e-2, 1e-3, 3e-2]), (37, [7e-3, 1e-2, 2e-3])):
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_device_arithmetic_is_numpys(V):
+    """The prior kernel's claim to the reference's pivots rests on the device doing NumPy's arithmetic
+    bit for bit: exp as np.exp computes it (SVML restated), correctly rounded sqrt, division and fma."""
+    import ctypes as C
+    from vlgp_amd._lib import dptr
+
+    rng = np.random.default_rng(0)
+    parts = [-rng.uniform(0, 50, 300_000), -rng.uniform(0, 760, 300_000), rng.uniform(-1e-3, 1e-3, 50_000),
+             rng.uniform(0, 709.9, 50_000), -np.exp(rng.uniform(-40, 7, 100_000)),
+             np.array([0.0, -0.0, -745.2, -745.13, -746.0, -1e4, -np.inf, 1e-300, -1e-300, -708.396, -708.4, -707.7])]
+    for om in (5e-2, 5e-3, 5e-4, 1.0, 0.0123456789):
+        parts.append(-om * np.arange(2000.0) ** 2)
+    x = np.concatenate(parts)
+    a = rng.uniform(0, 4, 200_000) * np.exp(rng.uniform(-30, 30, 200_000))
+    b = rng.standard_normal(200_000) * np.exp(rng.uniform(-30, 30, 200_000))
+    c = rng.standard_normal(200_000)
+    with V.Engine(4, 2, 1, 50) as eng:
+        def probe(kind, p, q, out):
+            eng._ck(eng.lib.vlgp_debug_npx(eng.h, kind, C.c_int64(p.size), dptr(p), dptr(q), dptr(out)))
+            return out
+        with np.errstate(over="ignore"):
+            assert np.array_equal(_bits(probe(0, x, None, np.zeros_like(x))), _bits(np.exp(x)))
+        assert np.array_equal(_bits(probe(1, a, None, np.zeros_like(a))), _bits(np.sqrt(a)))
+        assert np.array_equal(_bits(probe(2, a, b, np.zeros_like(a))), _bits(a / b))
+        # fma against exact rational arithmetic on a sample
+        from fractions import Fraction as Fr
+        got = probe(3, a[:2000], b[:2000], c[:2000].copy())
+        want = np.array([float(Fr(float(p)) * Fr(float(q)) + Fr(float(r))) for p, q, r in zip(a[:2000], b[:2000], c[:2000])])
+        assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_ichol_golden_bitwise(V, golden):
+    """math.ichol_gauss (vlgp/math.py:76-126) on the device: the golden factors of the reference,
+    rank-exhausted 1000-bin cases included, bit for bit -- i.e. the same pivot sequence."""
+    g = golden("ichol")
+    for i, (n, om, r) in enumerate(g["cases"]):
+        n, r = int(n), int(r)
+        with V.Engine(4, 1, 1, r) as eng:
+            eng.build_prior([n], np.array([om]), np.ones(1))
+            G, rk = eng.get_prior(n, with_rank=True)
+        G = G[0]
+        if n > 200:
+            assert np.array_equal(G[::8], g["G%d_rows" % i])
+            assert np.array_equal(G.sum(axis=0), g["G%d_colsum" % i])
+        else:
+            assert np.array_equal(G, g["G%d" % i])
+        assert rk[0] == int((np.abs(G).sum(0) > 0).sum())
+
+
+def test_ichol_device_vs_oracle_bitwise(V):
+    """Several latents and lengths per call, sigma != 1, ranks, the compact copy's consumers (update_v)."""
+    rng = np.random.default_rng(3)
+    cases = [(50, [5e-2, 5e-3, 5e-4]), (64, [2e-2, 1e-3, 3e-2]), (37, [7e-3, 1e-2, 2e-3]), (400, [3e-2, 4e-3, 6e-4]),
+             (1000, [5e-4, 2e-3, 5e-2]), (1503, [3e-3, 7e-4, 1e-2]), (50, [1.0, 5.0, 0.3]), (5, [1e-2, 1.0, 1e-4])]
+    for T, omegas in cases:
         omegas = np.array(omegas)
         sigma = np.array([1.0, 0.9, 1.1])
         with V.Engine(4, 3, 1, 50) as eng:
             eng.build_prior([T], omegas, sigma)
             G, rk = eng.get_prior(T, with_rank=True)
+            # rebuild in place with other hyper-parameters (the per-EM-iteration path), then back
+            eng.build_prior([T], omegas[::-1].copy(), sigma)
+            eng.build_prior([T], omegas, sigma)
+            G2, rk2 = eng.get_prior(T, with_rank=True)
+        assert np.array_equal(G, G2) and np.array_equal(rk, rk2)
         for l in range(3):
             Go = O.ichol_gauss(T, omegas[l], 50) * sigma[l]
-            r_o = int((np.abs(Go).sum(0) > 0).sum())
-            assert rk[l] == r_o, (T, l, rk[l], r_o)
-            # converged before the rank budget: both factors reproduce K up to the
-            # stopping tolerance (residual diagonal mass <= 1e-6 T, math.py:105); the
-            # O(1e-6) remainder depends on how arg-max ties between mirror-image rows
-            # fall, so device and NumPy agree to that level, not to rounding
-            t = np.arange(T)
-            K = sigma[l] ** 2 * np.exp(-omegas[l] * (t[:, None] - t[None, :]) ** 2)
-            resid = np.diag(K - G[l] @ G[l].T)
-            assert resid.min() > -1e-12 and resid.sum() <= 1e-6 * T * sigma[l] ** 2 * (1 + 1e-9)
-            assert np.abs(G[l] @ G[l].T - K).max() < 2e-5
-            assert relerr(G[l] @ G[l].T, Go @ Go.T) < 2e-5
-            assert np.all(G[l][:, rk[l]:] == 0)
-
-
-def test_ichol_device_rank_exhausted_is_valid(V):
-    # truncated regime: pivots may legitimately differ from NumPy's in the last
-    # bit; the factor must still be a valid incomplete Cholesky.
-    T, om = 400, np.array([3e-2, 4e-3])
-    with V.Engine(4, 2, 1, 50) as eng:
-        eng.build_prior([T], om, np.ones(2))
-        G = eng.get_prior(T)
-    t = np.arange(T)
-    for l in range(2):
-        K = np.exp(-om[l] * (t[:, None] - t[None, :]) ** 2)
-        Go = O.ichol_gauss(T, om[l], 50)
-        resid = np.diag(K - G[l] @ G[l].T)
-        assert resid.min() > -1e-12
-        # same approximation quality as the reference factor
-        assert abs(resid.sum() - np.diag(K - Go @ Go.T).sum()) < 0.05 * max(np.diag(K - Go @ Go.T).sum(), 1e-9)
-        # K - GG' is positive semi-definite for an incomplete Cholesky
-        assert np.linalg.eigvalsh(K - G[l] @ G[l].T).min() > -1e-9
+            assert np.array_equal(G[l], Go), (T, l)
+            assert rk[l] == int((np.abs(Go).sum(0) > 0).sum())
+    # random lengths / timescales, several lengths in one call
+    for _ in range(6):
+        Ts = sorted({int(t) for t in rng.integers(2, 300, 3)})
+        om = np.exp(rng.uniform(np.log(1e-5), np.log(3.0), 2))
+        with V.Engine(4, 2, 1, 50) as eng:
+            eng.build_prior(Ts, om, np.ones(2))
+            for T in Ts:
+                G = eng.get_prior(T)
+                for l in range(2):
+                    assert np.array_equal(G[l], O.ichol_gauss(T, om[l], 50)), (T, om[l])
 
 
 # ------------------------------------------------------------------ E-step
@@ -394,7 +436,10 @@ def test_hstep_optimize_golden(V, golden):
         assert relerr(params["omega"], g["omega_opt"]) < 1e-6
         assert relerr(params["sigma"], g["sigma_opt"]) < 1e-9
         Gd = dev.engine.get_prior(T)
-        # the rebuilt factor reproduces K to the ichol stopping tolerance (see test_ichol_device_vs_oracle)
+        # the rebuilt factor: the device ichol of the device's omega (bitwise the oracle's), and the
+        # reference's K at its omega to the 1e-6 the optimiser is held to
+        for l in range(L):
+            assert np.array_equal(Gd[l], O.ichol_gauss(T, params["omega"][l], 50) * params["sigma"][l])
         assert relerr(np.einsum("ltr,lsr->lts", Gd, Gd),
                       np.einsum("ltr,lsr->lts", g["G_opt"], g["G_opt"])) < 2e-5
     finally:
@@ -413,11 +458,8 @@ def _c1(g):
 def test_vem_trajectory_golden(V, golden, tag, hs, ichol):
     """Six EM iterations at C1 against the reference's trajectory.
 
-    ichol="host": the prior factor has the reference's pivots -> 1e-6.
-    ichol="device" (the default): the HIP factor reproduces K to the same
-    stopping tolerance (residual mass <= 1e-6 T) but arg-max ties between
-    mirror-image rows may fall the other way, so G G' differs from NumPy's by
-    the O(1e-6) truncation remainder and the trajectory follows at ~1e-5.
+    Both prior-factor producers -- the device kernel (default) and the host NumPy restatement --
+    have the reference's pivots bit for bit, so both follow the trajectory at 1e-6.
     """
     g = golden("vem_c1")
     trials = _c1(g)
@@ -430,26 +472,26 @@ def test_vem_trajectory_golden(V, golden, tag, hs, ichol):
     np.random.seed(3)
     res = V.fit(trials, 3, a=g["a0"].copy(), b=g["b0"].copy(), Hstep=hs, max_iter=6, min_iter=6,
                 callbacks=[spy], verbose=False, ichol=ichol)
-    tol = TRAJ if ichol == "host" else 1e-4
+    tol = TRAJ
     assert res["config"]["runtime"]["it"] == int(g["it_" + tag])
     assert relerr([t[0] for t in traj], g["norm_mu_" + tag]) < tol
     assert relerr([t[1] for t in traj], g["norm_a_" + tag]) < tol
     assert relerr([t[2] for t in traj], g["norm_b_" + tag]) < tol
-    assert relerr(np.array([t[3] for t in traj]), g["omega_" + tag]) < (tol if ichol == "host" else 1e-3)
+    assert relerr(np.array([t[3] for t in traj]), g["omega_" + tag]) < tol
     assert relerr(res["params"]["a"], g["a_" + tag]) < tol
     assert relerr(res["params"]["b"], g["b_" + tag]) < tol
     assert relerr(res["params"]["noise"], g["noise_" + tag]) < tol
 
 
 def test_fit_end_to_end_golden(V, golden):
-    # full-length posterior is only well-posed with identical pivots (T = 200 at
-    # omega = 5e-2 exhausts the rank budget): host ichol + Hstep off, SURVEY 8c item 7
+    # H-step off: omega stays at 5e-2, where T = 200 exhausts the rank budget -- the full-length posterior
+    # is only well-posed with the reference's pivots, which the device factor has (G200 compared bitwise)
     g = golden("fit_c1")
     trials = _c1(g)
     mu_ids = [id(t["mu"]) for t in trials]
     np.random.seed(3)
     res = V.fit(trials, 3, a=g["a0"].copy(), b=g["b0"].copy(), Hstep=False, max_iter=5, min_iter=5,
-                ichol="host", verbose=False)
+                verbose=False)
     assert res["trials"] is trials
     assert [id(t["mu"]) for t in trials] == mu_ids
     assert set(res) == {"trials", "params", "config"}
@@ -459,6 +501,35 @@ def test_fit_end_to_end_golden(V, golden):
     assert relerr(res["params"]["b"], g["b"]) < TRAJ
     assert np.array_equal(res["params"]["cholesky"][200], g["G200"])
     assert res["config"]["runtime"]["it"] == int(g["it"])
+
+
+def test_fit_default_arguments_golden(V, golden):
+    """fit with the H-step on and every default left alone (vlgp/api.py:18-76) against the reference's result:
+    (1) a, b, mu injected -- 5 iterations, full-length mu, v, w at 1e-6; (2) nothing injected -- factor-analysis
+    initialisation from the seeded subsample, 8 iterations; the 1e-10 difference of the initialisation
+    (own FactorAnalysis vs scikit-learn's) grows to ~1e-6 through the EM iterations, held to 1e-5."""
+    g = golden("fit_c1_h1")
+    y = g["y"].astype(float)
+    trials = [{"ID": i, "y": y[i].copy(), "mu": g["mu0"][i].copy()} for i in range(y.shape[0])]
+    np.random.seed(3)
+    res = V.fit(trials, 3, a=g["a0"].copy(), b=g["b0"].copy(), max_iter=5, min_iter=5, verbose=False)
+    p = res["params"]
+    assert res["config"]["runtime"]["it"] == int(g["it"])
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert relerr(p[k], g[k]) < TRAJ, k
+    for k in ("mu", "v", "w", "dmu"):
+        assert relerr(np.stack([t[k] for t in trials]), g[k]) < TRAJ, k
+    for l in range(3):  # the returned factor is the reference's ichol_gauss of the returned omega, bit for bit
+        assert np.array_equal(p["cholesky"][200][l], O.ichol_gauss(200, p["omega"][l], 50) * p["sigma"][l])
+    trials = [{"ID": i, "y": y[i].copy()} for i in range(y.shape[0])]
+    np.random.seed(5)
+    res = V.fit(trials, 3, max_iter=8, verbose=False)
+    p = res["params"]
+    assert res["config"]["runtime"]["it"] == int(g["d_it"])
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert relerr(p[k], g["d_" + k]) < 1e-5, k
+    for k in ("mu", "v", "w"):
+        assert relerr(np.stack([t[k] for t in trials]), g["d_" + k]) < 1e-5, k
 
 
 def test_reference_smoke_test_fit_then_transform(V):
@@ -562,7 +633,7 @@ def test_c5_like_ragged_mixed_ten_latents(V):
     """BASELINE.json configs[4] in miniature: unequal trial lengths (multiples of the window), Poisson +
     Gaussian channels, ten latents.  Exercises the generic E-step kernels (L > 8), long units whose ten
     rank-50 factors do not fit LDS, the mixed-likelihood M-step and a ten-latent H-step, against the oracle
-    run on the same inputs with the same (host-made) prior factors."""
+    run on the same inputs."""
     from vlgp_amd import synth
 
     lengths = [250, 400, 300, 350]
@@ -580,7 +651,16 @@ def test_c5_like_ragged_mixed_ten_latents(V):
         return [{"ID": i, "y": t["y"].copy(), "mu": m.copy()} for i, (t, m) in enumerate(zip(trials, mu0))]
 
     kw = dict(a=a0.copy(), b=b0.copy(), lik=lik, max_iter=3, min_iter=3, Eniter=5, Mniter=5)
-    got = V.fit(fresh(), L, ichol="host", verbose=False, **kw)
+    from vlgp_amd.api import SET_SEGMENTS, FitSession
+
+    mine = fresh()
+    sess = FitSession(mine, L, verbose=False, **kw)
+    sess.run()
+    # state the final stage of fit starts from (api.py:66: the trials after vem, before make_cholesky/infer)
+    sess.eng.merge(SET_SEGMENTS)
+    sess.dev_trials.pull(("mu", "v", "w"))
+    after_vem = [{k: t[k].copy() for k in ("mu", "v", "w")} for t in mine]
+    got = sess.finish()
 
     ref_trials = fresh()
     for t in ref_trials:
@@ -592,19 +672,39 @@ def test_c5_like_ragged_mixed_ten_latents(V):
     params = O.make_params(ref_trials, L, a=a0.copy(), b=b0.copy(), lik=lik)
     O.fit_given_init(ref_trials, params, cfg)
 
-    assert relerr(got["params"]["omega"], params["omega"]) < 1e-5
-    assert relerr(got["params"]["a"], params["a"]) < 1e-5
-    assert relerr(got["params"]["b"], params["b"]) < 1e-5
-    assert relerr(got["params"]["noise"], params["noise"]) < 1e-5
-    # full-length posterior: only comparable where the factor has identical pivots; omega differs at
-    # ~1e-9 after three H-steps, which can flip pivots of a rank-exhausted factor,
-    # so compare the trials whose factors did agree
+    # (1) the EM phase, through what it leaves in the parameters
+    gp_ = got["params"]
+    assert relerr(gp_["omega"], params["omega"]) < 1e-5
+    assert relerr(gp_["a"], params["a"]) < 1e-5
+    assert relerr(gp_["b"], params["b"]) < 1e-5
+    assert relerr(gp_["noise"], params["noise"]) < 1e-5
+    # (2) the returned factors are the reference's ichol_gauss of the returned omega, bit for bit, every length
+    for T, Gg in gp_["cholesky"].items():
+        for l in range(L):
+            assert np.array_equal(Gg[l], O.ichol_gauss(T, gp_["omega"][l], 50) * gp_["sigma"][l])
+    # (3) the full-length posterior of EVERY trial.  The two runs' omega differ at ~1e-9 after three L-BFGS-B
+    # runs, and the rank-exhausted factor of a 250...600-bin trial is a discontinuous function of omega (pivot
+    # chaos, SURVEY section 7: the reference against itself with a different LAPACK driver moves mu by 5 %), so
+    # the final stage (api.py:66-71) is checked under the parameters the device run returned: oracle
+    # make_cholesky / update_w / update_v / infer from the device's post-EM state, every trial, 1e-6
+    stage = [{"y": t["y"], "x": np.ones((t["y"].shape[0], 1, N)), "dmu": np.zeros_like(s["mu"]),
+              **{k: s[k].copy() for k in ("mu", "v", "w")}} for t, s in zip(mine, after_vem)]
+    p2 = dict(params)
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        p2[k] = np.array(gp_[k])
+    O.make_cholesky(stage, p2, cfg)
+    O.update_w(stage, p2, cfg)
+    O.update_v(stage, p2, cfg)
+    O.infer(stage, p2, cfg)
+    for tg, tr in zip(got["trials"], stage):
+        for k in ("mu", "v", "w"):
+            assert relerr(tg[k], tr[k]) < TRAJ, (k, tr["y"].shape[0])
+    # and where the two runs' factors happen to coincide, the end-to-end posterior agrees too
+    same = [t["y"].shape[0] for t in ref_trials
+            if np.array_equal(gp_["cholesky"][t["y"].shape[0]], params["cholesky"][t["y"].shape[0]])]
     for tg, tr in zip(got["trials"], ref_trials):
-        T = tr["y"].shape[0]
-        Gg, Gr = got["params"]["cholesky"][T], params["cholesky"][T]
-        if relerr(np.einsum("ltr,lsr->lts", Gg, Gg), np.einsum("ltr,lsr->lts", Gr, Gr)) < 1e-9:
-            assert relerr(tg["mu"], tr["mu"]) < 1e-4, T
-            assert relerr(tg["v"], tr["v"]) < 1e-4, T
+        if tr["y"].shape[0] in same:
+            assert relerr(tg["mu"], tr["mu"]) < 1e-4
 
 
 # ------------------------------------------------------------------ other windows / likelihoods through fit
@@ -628,7 +728,7 @@ def test_fit_other_windows_and_all_gaussian(V, window, lik_gauss):
     mu0 = [0.2 * rng.standard_normal((n_bins, L)) for _ in trials]
     fresh = lambda: [{"ID": i, "y": t["y"].copy(), "mu": m.copy()} for i, (t, m) in enumerate(zip(trials, mu0))]
     kw = dict(a=a0.copy(), b=b0.copy(), lik=lik, max_iter=3, min_iter=3, window=window)
-    got = V.fit(fresh(), L, ichol="host", verbose=False, **kw)
+    got = V.fit(fresh(), L, verbose=False, **kw)
 
     ref = fresh()
     for t in ref:

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "vlgp_profile_reset": (C.c_int, [_h]),
     "vlgp_profile_get": (C.c_int, [_h, C.c_int, _i64p, _dp, _dp]),
     "vlgp_debug_phase_clock": (C.c_int, [_h, C.c_int, C.POINTER(C.c_uint64)]),
+    "vlgp_debug_npx": (C.c_int, [_h, C.c_int, C.c_int64, _dp, _dp, _dp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -211,15 +211,26 @@ static int shm_allreduce(vlgp_ctx* ctx, ShmComm* c, hipStream_t st, double* d_bu
     if (n > SHM_SLOT_DOUBLES) return vlgp_fail(ctx, VLGP_ERR_COMM, "shm transport: buffer of %lld doubles too large", (long long)n);
     const long long s = ++c->seq;
     ShmRegion* R = c->reg;
+    // a rank that died must not hang the others: every wait gives up after VLGP_SHM_TIMEOUT_S (default 60 s)
+    const char* tmo_s = getenv("VLGP_SHM_TIMEOUT_S");
+    const double tmo = tmo_s ? atof(tmo_s) : 60.0;
+    auto wait_ge = [&](volatile long long* p, long long want) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*p < want) {
+            usleep(20);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > tmo) return false;
+        }
+        return true;
+    };
     // nobody may still be reading my slot from the previous round
     for (int k = 0; k < c->world; ++k)
-        while (R->done[k] < s - 1) usleep(20);
+        if (!wait_ge(&R->done[k], s - 1)) return vlgp_fail(ctx, VLGP_ERR_COMM, "shm transport: rank %d is not responding", k);
     HIPCHK(ctx, hipMemcpyAsync((void*)R->slot[c->rank], d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     __sync_synchronize();
     R->ready[c->rank] = s;
     for (int k = 0; k < c->world; ++k)
-        while (R->ready[k] < s) usleep(20);
+        if (!wait_ge(&R->ready[k], s)) return vlgp_fail(ctx, VLGP_ERR_COMM, "shm transport: rank %d is not responding", k);
     __sync_synchronize();
     std::vector<double> sum((size_t)n, 0.0);
     for (int k = 0; k < c->world; ++k)  // fixed rank order: every rank gets the same bits
@@ -530,6 +541,8 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     if (ctx->mstream) (void)hipStreamDestroy(ctx->mstream); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_hres) (void)hipHostFree(ctx->h_hres);
+    if (ctx->h_prior_mb) (void)hipHostFree(ctx->h_prior_mb);
+    fr(ctx->d_prior_mb);
     fr(ctx->d_hsync); fr(ctx->d_hmom);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -753,6 +766,12 @@ static int new_prior(vlgp_ctx* ctx, int T, Prior** out) {
     const int64_t n = (int64_t)ctx->L * T * ctx->R;
     HIPCHK(ctx, hipMalloc(&pr.d_full, (size_t)n * sizeof(double)));
     HIPCHK(ctx, hipMalloc(&pr.d_compact, (size_t)n * sizeof(double)));
+    // capacity layout of the compact copy: latent l at l*T*R whatever the ranks turn out to be, so that the
+    // factorisation kernel can write it (and the table never needs the ranks of the other latents)
+    pr.goff.resize(ctx->L);
+    for (int l = 0; l < ctx->L; ++l) pr.goff[l] = (int64_t)l * T * ctx->R;
+    pr.compact_len = n;
+    pr.rl.assign(ctx->L, 1);
     auto res = ctx->priors.emplace(T, pr);
     *out = &res.first->second;
     return VLGP_OK;
@@ -770,36 +789,33 @@ extern "C" int vlgp_build_prior(vlgp_ctx* ctx, int n_lengths, const int* lengths
     NEED_CTX(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     if (n_lengths < 1 || !lengths || !omega || !sigma) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad build_prior arguments");
-    const int L = ctx->L;
-    // the reference replaces the whole dict on every call (gp.py:158); keep
-    // buffers of lengths that are rebuilt, drop the others
-    for (auto it = ctx->priors.begin(); it != ctx->priors.end();) {
-        if (std::find(lengths, lengths + n_lengths, it->first) == lengths + n_lengths) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (it->second.d_full) (void)hipFree(it->second.d_full);
-            if (it->second.d_compact) (void)hipFree(it->second.d_compact);
-            it = ctx->priors.erase(it);
-        } else {
-            ++it;
+    // the reference replaces the whole dict on every call (gp.py:158).  Same set of lengths as the table holds
+    // (every H-step): the factors are rebuilt in place and the kernel refreshes the ranks of the table rows --
+    // no allocation, no copy.  Otherwise: drop the lengths not listed, add the new ones, rebuild the table.
+    bool same = (int)ctx->priors.size() > 0 && ctx->d_prior_rl != nullptr;
+    for (int i = 0; same && i < n_lengths; ++i) same = ctx->priors.count(lengths[i]) > 0;
+    for (auto it = ctx->priors.begin(); same && it != ctx->priors.end(); ++it)
+        same = std::find(lengths, lengths + n_lengths, it->first) != lengths + n_lengths;
+    if (!same) {
+        for (auto it = ctx->priors.begin(); it != ctx->priors.end();) {
+            if (std::find(lengths, lengths + n_lengths, it->first) == lengths + n_lengths) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                if (it->second.d_full) (void)hipFree(it->second.d_full);
+                if (it->second.d_compact) (void)hipFree(it->second.d_compact);
+                it = ctx->priors.erase(it);
+            } else {
+                ++it;
+            }
         }
     }
-    int Tmax = 0;
-    for (int i = 0; i < n_lengths; ++i) Tmax = std::max(Tmax, lengths[i]);
-    CHK(vlgp_ensure_pinned(ctx, 2 * L + 8 * L + 64));
-    // hyper-parameters live at the tail of the workspace the ichol kernel sizes
-    const int64_t per = (int64_t)Tmax * ctx->R + Tmax;
-    const int64_t n_d = per * L + ((int64_t)L * Tmax + L + 1) / 2 + 1;
-    CHK(vlgp_ensure_work(ctx, n_d + 2 * L + 8));
-    double* d_hyp = ctx->d_work + n_d;
-    double* hp = ctx->h_pinned + 8 * L + 32;
-    for (int l = 0; l < L; ++l) { hp[l] = omega[l]; hp[L + l] = sigma[l]; }
-    HIPCHK(ctx, hipMemcpyAsync(d_hyp, hp, sizeof(double) * 2 * L, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<Prior*> prs;
     for (int i = 0; i < n_lengths; ++i) {
         Prior* pr = nullptr;
         CHK(new_prior(ctx, lengths[i], &pr));
-        CHK(launch_ichol(ctx, *pr, d_hyp, d_hyp + L));
+        if (std::find(prs.begin(), prs.end(), pr) == prs.end()) prs.push_back(pr);
     }
-    return rebuild_prior_table(ctx);
+    CHK(launch_ichol_all(ctx, prs, omega, sigma, same));
+    return same ? VLGP_OK : rebuild_prior_table(ctx);
 }
 
 extern "C" int vlgp_set_prior(vlgp_ctx* ctx, int T, const double* G) {
@@ -1001,7 +1017,7 @@ static int moments_host(vlgp_ctx* ctx, UnitSet& us, std::vector<double>& out) {
     const int L = ctx->L;
     const int K = L * (L + 1) / 2 + 3 * L + 1;
     CHK(vlgp_ensure_pinned(ctx, K + 8));
-    CHK(launch_moments(ctx, us, ctx->d_work));
+    CHK(launch_moments(ctx, us));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_work, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     out.assign(ctx->h_pinned, ctx->h_pinned + K);
@@ -1077,6 +1093,21 @@ extern "C" int vlgp_project_units(vlgp_ctx* ctx, int set, const double* proj, co
 }
 
 // ---- measurement -------------------------------------------------------------
+extern "C" int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const double* b, double* out) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    if (n < 1 || !a || !out || kind < 0 || kind > 3 || (kind >= 2 && !b)) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad probe arguments");
+    CHK(vlgp_ensure_work(ctx, 3 * n));
+    double* W = ctx->d_work;
+    HIPCHK(ctx, hipMemcpyAsync(W, a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (b) HIPCHK(ctx, hipMemcpyAsync(W + n, b, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(W + 2 * n, out, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_npx_probe(ctx, kind, n, W, W + n, W + 2 * n));
+    HIPCHK(ctx, hipMemcpyAsync(out, W + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_debug_phase_clock(vlgp_ctx* ctx, int on, uint64_t out[8]) {
     NEED_CTX(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

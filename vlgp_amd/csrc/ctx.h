@@ -10,6 +10,7 @@
 #include "../../include/vlgp_hip.h"
 
 #define VLGP_WAVE 64
+#define VLGP_PRIOR_SLOTS 64   // prior lengths factored per mailbox round
 
 // One low-rank prior factor per distinct unit length (gp.make_cholesky).
 struct Prior {
@@ -65,6 +66,11 @@ struct vlgp_ctx {
     int* d_prior_rl = nullptr;              // (rows, L)
     int64_t* d_prior_goff = nullptr;        // (rows, L)
     int prior_rows = 0;
+    // mailbox of the prior kernel: per launch slot the L ranks, then a sequence word (mapped host memory)
+    int* h_prior_mb = nullptr;
+    int* d_prior_mb_host = nullptr;         // device view of h_prior_mb
+    int* d_prior_mb = nullptr;              // device slots + arrival counter
+    unsigned long long prior_seq = 0;
 
     UnitSet sets[VLGP_MAX_SETS];
 
@@ -155,11 +161,14 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
                  double da_bound, double db_bound);
 int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
                  const double* logp, double* ll, double* dll);
-int launch_ichol(vlgp_ctx* ctx, Prior& pr, const double* d_omega, const double* d_sigma);
-int launch_compact_prior(vlgp_ctx* ctx, Prior& pr);  // d_full -> rl, d_compact
+// factor the listed priors (bit-exact ichol_gauss), ranks and compact copies included; returns with pr.rl set
+int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
+                     bool in_table);
+int launch_compact_prior(vlgp_ctx* ctx, Prior& pr);  // host-injected d_full -> rl, d_compact
+int launch_npx_probe(vlgp_ctx* ctx, int kind, int64_t n, const double* d_a, const double* d_b, double* d_out);
 int launch_xb(vlgp_ctx* ctx, UnitSet& us);
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
-int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out /* 2L+2: sum1, sum2, |mu|^2, |dmu|^2 */);
+int launch_moments(vlgp_ctx* ctx, UnitSet& us);  // tri(L) gram | sum mu | sum v | sum mu^2 | |dmu|^2 at ctx->d_work
 int launch_project(vlgp_ctx* ctx, UnitSet& us, const double* d_proj, const double* d_shift, double* d_part,
                    double* d_out);  // mu = y proj - shift; d_out = column sums of y
 int launch_gather(vlgp_ctx* ctx, UnitSet& src, UnitSet& dst, int window);

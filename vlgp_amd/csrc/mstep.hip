@@ -545,16 +545,14 @@ static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double*
     return mlane ? vlgp_allreduce_m(ctx, d_out, K) : vlgp_allreduce(ctx, d_out, K);
 }
 
-int launch_moments(vlgp_ctx* ctx, UnitSet& us, double* d_out) {
+// result (K doubles, all-reduced) is left at the head of ctx->d_work; the partials use its tail.  The
+// workspace may be reallocated in here: take ctx->d_work AFTER the call, never before.
+int launch_moments(vlgp_ctx* ctx, UnitSet& us) {
     const int L = ctx->L;
     const int K = tri(L) + 3 * L + 1;
     CHK(vlgp_ensure_work(ctx, 256LL * K + K + 64));
-    // caller's d_out may live inside d_work: use the tail of the workspace for partials
     double* d_partial = ctx->d_work + K + 64;
-    CHK(latent_moments(ctx, us, d_partial, ctx->d_work, false));
-    if (d_out != ctx->d_work)
-        HIPCHK(ctx, hipMemcpyAsync(d_out, ctx->d_work, sizeof(double) * K, hipMemcpyDeviceToDevice, ctx->stream));
-    return VLGP_OK;
+    return latent_moments(ctx, us, d_partial, ctx->d_work, false);
 }
 
 int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double eps, double lr,

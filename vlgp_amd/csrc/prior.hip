@@ -1,120 +1,217 @@
-// Prior factor on the device: pivoted incomplete Cholesky of the squared-
-// exponential kernel (math.ichol_gauss, vlgp/math.py:76-126) for every latent
-// of one unit length, plus the compaction that drops the trailing zero columns.
+// Prior factor on the device: pivoted incomplete Cholesky of the squared-exponential kernel
+// (math.ichol_gauss, vlgp/math.py:76-126) for every latent of one unit length, its rank and the
+// compact copy (trailing zero columns dropped) the E-step kernels read -- one launch, no copies.
 //
-// One workgroup per latent.  Each of the (at most R) steps needs the arg-max
-// of the residual diagonal and its sum (two block reductions), then one new
-// column; the residual diagonal is recomputed from scratch each step exactly as
-// the reference does (math.py:119).  Ties in the arg-max go to the lowest row,
-// as numpy.argmax does; the last bit of the residuals may differ from NumPy's
-// (different exp/summation order), see DESIGN.md "pivot chaos".
+// The factor reproduces the reference's pivot sequence and its G BIT FOR BIT: every residual,
+// every new column entry and the stopping sum are computed with the operation order NumPy /
+// OpenBLAS use on the reference's side (np_exact.h: np.exp, np.dot, np.sum restated), the arg-max
+// takes the first maximum in permuted order like numpy.argmax, and nothing is contracted.
+//
+// One workgroup per latent.  Rows stay at their ORIGINAL index in G (the reference swaps rows and
+// un-permutes at the end, math.py:110,126: same thing); `piv` maps permuted position -> row.
+// Per step: (1) np.sum(d[i:]) -- the leaves of NumPy's pairwise recursion are summed by groups of
+// eight lanes (one lane per accumulator), thread 0 walks the recursion tree over the leaf sums;
+// (2) first arg-max of d[i:]; (3) every remaining row gets its new column entry and residual
+// (npx_ichol_row), one row per thread.
 #include "ctx.h"
+#include "np_exact.h"
 
-#define ICH_THREADS 256
+struct IcholArgs {
+    int T, R, L;
+    double omega[16], sigma[16];
+    double* full;        // (L, T, R) as the reference lays it out
+    double* compact;     // latent l at l*T*R, (T, rank_l) row-major
+    int* rl_table;       // (L) row of the device prior table, or null
+    int* rank_dev;       // (L) device slot of this launch
+    int* rank_host;      // (L) mapped host slot of this launch
+    unsigned long long* flag_host;  // mapped host sequence word
+    unsigned long long seq;
+    unsigned* ticket;    // device arrival counter (zero between launches)
+    double* gwork;       // global scratch for d, kv (2T per latent) when they do not fit LDS, else null
+    int* giwork;         // ... piv (T per latent)
+};
 
-// work: per latent [ Gp (T*R) | d (T) ] doubles, piv: per latent T ints
-__global__ void __launch_bounds__(ICH_THREADS)
-ichol_kernel(int T, int R, const double* omega, const double* sigma, double* work, int* piv,
-             double* G_out, int* rank_out) {
-    __shared__ double red_v[ICH_THREADS];
-    __shared__ int red_i[ICH_THREADS];
-    __shared__ double s_piv;
-    __shared__ int s_jast;
-    const int l = blockIdx.x, tid = threadIdx.x;
-    double* Gp = work + (int64_t)l * ((int64_t)T * R + T);
-    double* d = Gp + (int64_t)T * R;
-    int* pv = piv + (int64_t)l * T;
-    const double om = omega[l];
-    const double tol_n = 1e-6 * T;
+#define ICH_LEAVES(T) ((T) / 64 + 2)
 
-    for (int j = tid; j < T; j += ICH_THREADS) {
-        d[j] = 1.0;
-        pv[j] = j;
-        for (int c = 0; c < R; ++c) Gp[(int64_t)j * R + c] = 0.0;
+// one leaf (n <= 128 contiguous elements) of NumPy's pairwise sum, by the 8 lanes [base, base+8) of a wave;
+// k = lane - base is the accumulator this lane owns.  Result valid on every lane of the group.
+__device__ static inline double ich_leaf8(const double* a, int n, int k, int base) {
+    if (n < 8) {
+        double res = -0.0;
+        for (int i = 0; i < n; ++i) res = res + a[i];
+        return res;
     }
-    __syncthreads();
-
-    int k = 0;
-    for (; k < R; ++k) {
-        // sum and arg-max of d[k:]
-        double s = 0.0, best = -1.0;
-        int bi = 0x7fffffff;
-        for (int j = k + tid; j < T; j += ICH_THREADS) {
-            const double dj = d[j];
-            s += dj;
-            if (dj > best) { best = dj; bi = j; }
-        }
-        red_v[tid] = s;
-        __syncthreads();
-        for (int o = ICH_THREADS / 2; o > 0; o >>= 1) {
-            if (tid < o) red_v[tid] += red_v[tid + o];
-            __syncthreads();
-        }
-        const double total = red_v[0];
-        __syncthreads();
-        if (!(total > tol_n)) break;
-        red_v[tid] = best;
-        red_i[tid] = bi;
-        __syncthreads();
-        for (int o = ICH_THREADS / 2; o > 0; o >>= 1) {
-            if (tid < o) {
-                const double ov = red_v[tid + o];
-                const int oi = red_i[tid + o];
-                if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) {
-                    red_v[tid] = ov;
-                    red_i[tid] = oi;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const int jast = (k == 0) ? 0 : red_i[0];  // first pivot is row 0 (math.py:112)
-            s_jast = jast;
-            s_piv = sqrt(d[jast]);
-        }
-        __syncthreads();
-        const int jast = s_jast;
-        const double pivot = s_piv;
-        if (jast != k) {  // swap rows k <-> jast (columns 0..k-1) and the pivot vector
-            for (int c = tid; c < k; c += ICH_THREADS) {
-                const double tmp = Gp[(int64_t)k * R + c];
-                Gp[(int64_t)k * R + c] = Gp[(int64_t)jast * R + c];
-                Gp[(int64_t)jast * R + c] = tmp;
-            }
-            if (tid == 0) {
-                const int tmp = pv[k];
-                pv[k] = pv[jast];
-                pv[jast] = tmp;
-            }
-        }
-        __syncthreads();
-        const double xk = (double)pv[k];
-        if (tid == 0) Gp[(int64_t)k * R + k] = pivot;
-        for (int j = k + 1 + tid; j < T; j += ICH_THREADS) {
-            double* row = Gp + (int64_t)j * R;
-            const double* rk = Gp + (int64_t)k * R;
-            const double dx = (double)pv[j] - xk;
-            double dot = 0.0;
-            for (int c = 0; c < k; ++c) dot += row[c] * rk[c];
-            const double g = (exp(-om * (dx * dx)) - dot) / pivot;
-            row[k] = g;
-            double ss = 0.0;
-            for (int c = 0; c < k; ++c) ss += row[c] * row[c];
-            ss += g * g;
-            d[j] = 1.0 - ss;
-        }
-        __syncthreads();
-    }
-    // un-pivot, scale by sigma: G[l, pv[j], :] = Gp[j, :] * sigma_l
-    const double sg = sigma[l];
-    for (int i = tid; i < T * R; i += ICH_THREADS) {
-        const int j = i / R, c = i - j * R;
-        G_out[((int64_t)l * T + pv[j]) * R + c] = Gp[i] * sg;
-    }
-    if (tid == 0) rank_out[l] = k;
+    double r = a[k];
+    const int nm = n - (n % 8);
+    for (int i = 8; i < nm; i += 8) r = r + a[i + k];
+    const double r0 = __shfl(r, base + 0), r1 = __shfl(r, base + 1), r2 = __shfl(r, base + 2), r3 = __shfl(r, base + 3);
+    const double r4 = __shfl(r, base + 4), r5 = __shfl(r, base + 5), r6 = __shfl(r, base + 6), r7 = __shfl(r, base + 7);
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (int i = nm; i < n; ++i) res = res + a[i];
+    return res;
 }
 
-// number of leading columns up to the last non-zero one, per latent
+template <int NT>
+__global__ void __launch_bounds__(NT) ichol_exact_kernel(IcholArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char ich_smem[];
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = A.T, R = A.R, NL = ICH_LEAVES(T);
+    constexpr int NW = NT / 64;
+    // LDS: [red_v 16 | leafsum NL | (d T | kv T)] doubles, [red_i 16 | misc 8 | leaf_start NL | leaf_len NL | (piv T)] ints
+    double* red_v = reinterpret_cast<double*>(ich_smem);
+    double* leafsum = red_v + 16;
+    double* dbig = leafsum + NL;
+    const bool in_lds = A.gwork == nullptr;
+    double* d = in_lds ? dbig : A.gwork + (int64_t)l * 2 * T;
+    double* kv = d + T;
+    int* ibase = reinterpret_cast<int*>(in_lds ? dbig + 2 * (int64_t)T : dbig);
+    int* red_i = ibase;
+    int* misc = red_i + 16;        // 0: leaf count, 1: jast, 2: row of the pivot
+    int* leaf_start = misc + 8;
+    int* leaf_len = leaf_start + NL;
+    int* piv = in_lds ? leaf_len + NL : A.giwork + (int64_t)l * T;
+    __shared__ double s_pivot, s_total;
+
+    double* G = A.full + (int64_t)l * T * R;
+    const double om = A.omega[l];
+    const double tol_n = 1e-6 * (double)T;
+
+    for (int j = tid; j < T; j += NT) {
+        d[j] = 1.0;
+        piv[j] = j;
+        const double dx = (double)j;
+        kv[j] = npx_exp(-om * (dx * dx));  // exp(-omega (x_j - x_p)^2), a function of |j - p| only (dt = 1, math.py:101)
+    }
+    for (int64_t e = tid; e < (int64_t)T * R; e += NT) G[e] = 0.0;
+    __syncthreads();
+
+    int i = 0;
+    for (; i < R; ++i) {
+        const int n = T - i;
+        // ---- np.sum(d[i:]) > tol * n ? (math.py:105) ----
+        if (tid == 0) {  // leaves of the pairwise recursion, left to right
+            int ss[32], sl[32], sp = 0, nl = 0;
+            ss[0] = i; sl[0] = n;
+            while (sp >= 0) {
+                const int s = ss[sp], len = sl[sp];
+                --sp;
+                if (len <= 128) {
+                    leaf_start[nl] = s; leaf_len[nl] = len; ++nl;
+                } else {
+                    int n2 = len / 2;
+                    n2 -= n2 % 8;
+                    ++sp; ss[sp] = s + n2; sl[sp] = len - n2;
+                    ++sp; ss[sp] = s; sl[sp] = n2;
+                }
+            }
+            misc[0] = nl;
+        }
+        __syncthreads();
+        {
+            const int nl = misc[0];
+            const int base = lane & ~7, k = lane & 7;
+            for (int lf = tid >> 3; lf < nl; lf += NT / 8) {
+                const double s = ich_leaf8(d + leaf_start[lf], leaf_len[lf], k, base);
+                if (k == 0) leafsum[lf] = s;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int next = 0;
+            // same traversal as npx_pairwise, leaves taken from leafsum in order
+            int sl[32], st[32], sp = 0;
+            double left[32], ret = 0.0;
+            sl[0] = n; st[0] = 0;
+            while (sp >= 0) {
+                const int len = sl[sp];
+                if (len <= 128) { ret = leafsum[next++]; --sp; continue; }
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                if (st[sp] == 0) { st[sp] = 1; ++sp; sl[sp] = n2; st[sp] = 0; }
+                else if (st[sp] == 1) { left[sp] = ret; st[sp] = 2; ++sp; sl[sp] = len - n2; st[sp] = 0; }
+                else { ret = left[sp] + ret; --sp; }
+            }
+            s_total = 0.0 + ret;
+        }
+        __syncthreads();
+        if (!(s_total > tol_n)) break;
+
+        // ---- jast = i + argmax(d[i:]) (first maximum), 0 at the first step (math.py:106-112) ----
+        if (i > 0) {
+            double best = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int p = i + tid; p < T; p += NT) {
+                const double dp = d[p];
+                if (dp > best) { best = dp; bi = p; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; ++w)
+                    if (red_v[w] > best || (red_v[w] == best && red_i[w] < bi)) { best = red_v[w]; bi = red_i[w]; }
+                misc[1] = bi;
+            }
+        } else if (tid == 0) {
+            misc[1] = 0;
+        }
+        __syncthreads();  // (the barrier inside the i > 0 branch is block-uniform)
+        if (tid == 0) {
+            const int jast = misc[1];
+            const double pivot = sqrt(d[jast]);
+            const int t = piv[i]; piv[i] = piv[jast]; piv[jast] = t;
+            misc[2] = piv[i];
+            s_pivot = pivot;
+            G[(int64_t)piv[i] * R + i] = pivot;
+        }
+        __syncthreads();
+        // ---- new column and residuals of the remaining rows (math.py:114-119) ----
+        {
+            const int rowi = misc[2], mo = n - 1;
+            const double pivot = s_pivot;
+            const double* prow = G + (int64_t)rowi * R;
+            for (int jj = tid; jj < mo; jj += NT) {
+                const int p = i + 1 + jj, row = piv[p];
+                const int dist = row > rowi ? row - rowi : rowi - row;
+                d[p] = npx_ichol_row(G + (int64_t)row * R, prow, i, jj, mo, kv[dist], pivot);
+            }
+        }
+        __syncthreads();
+    }
+    const int rank = i;
+    // ---- G * sigma (gp.py:161), compact copy, rank ----
+    {
+        const double sg = A.sigma[l];
+        double* C = A.compact + (int64_t)l * T * R;
+        for (int64_t e = tid; e < (int64_t)T * R; e += NT) {
+            const int row = (int)(e / R), c = (int)(e - (int64_t)row * R);
+            const double v = G[e] * sg;
+            G[e] = v;
+            if (c < rank) C[(int64_t)row * rank + c] = v;
+        }
+    }
+    if (tid == 0) {
+        if (A.rl_table) A.rl_table[l] = rank;
+        __hip_atomic_store(A.rank_dev + l, rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)A.L - 1) {  // last latent of this launch: publish every rank to the host mailbox
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int q = 0; q < A.L; ++q)
+                A.rank_host[q] = __hip_atomic_load(A.rank_dev + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(A.flag_host, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// number of leading columns up to the last non-zero one, per latent (host-injected factors)
 __global__ void __launch_bounds__(256) prior_rank_kernel(int T, int R, const double* G, int* rank_out) {
     __shared__ int s_r;
     const int l = blockIdx.x;
@@ -133,63 +230,136 @@ __global__ void __launch_bounds__(256) prior_rank_kernel(int T, int R, const dou
     if (threadIdx.x == 0) rank_out[l] = s_r < 1 ? 1 : s_r;
 }
 
+// compact[l*T*R + t*r_l + c] = G[l, t, c], c < r_l
 __global__ void __launch_bounds__(256)
-prior_compact_kernel(int T, int R, int L, const double* G, const int* rl, const int64_t* goff,
-                     double* out) {
+prior_compact_kernel(int T, int R, const double* G, const int* rl, double* out) {
     const int l = blockIdx.y;
     const int r = rl[l];
     const int64_t n = (int64_t)T * r;
+    const int64_t base = (int64_t)l * T * R;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t t = i / r;
         const int c = (int)(i - t * r);
-        out[goff[l] + i] = G[((int64_t)l * T + t) * R + c];
+        out[base + i] = G[base + t * R + c];
     }
 }
 
-int launch_ichol(vlgp_ctx* ctx, Prior& pr, const double* d_omega, const double* d_sigma) {
-    const int L = ctx->L, R = ctx->R, T = pr.T;
-    const int64_t per = (int64_t)T * R + T;
-    // workspace: doubles for (Gp, d) per latent, then ints for pivots and ranks
-    const int64_t n_d = per * L + ((int64_t)L * T + L + 1) / 2 + 1;
-    CHK(vlgp_ensure_work(ctx, n_d));
-    double* work = ctx->d_work;
-    int* piv = reinterpret_cast<int*>(work + per * L);
-    int* rank = piv + (int64_t)L * T;
-    vlgp_prof_begin(ctx, VLGP_PROF_PRIOR);
-    hipLaunchKernelGGL(ichol_kernel, dim3(L), dim3(ICH_THREADS), 0, ctx->stream, T, R, d_omega,
-                       d_sigma, work, piv, pr.d_full, rank);
-    vlgp_prof_end(ctx, VLGP_PROF_PRIOR, (double)L);
-    HIPCHK(ctx, hipGetLastError());
-    return launch_compact_prior(ctx, pr);
+static int ensure_mailbox(vlgp_ctx* ctx) {
+    if (ctx->h_prior_mb) return VLGP_OK;
+    const size_t bytes = sizeof(int) * VLGP_PRIOR_SLOTS * 16 + 64;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prior_mb), bytes, hipHostMallocMapped));
+    memset(ctx->h_prior_mb, 0, bytes);
+    HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_prior_mb_host), ctx->h_prior_mb, 0));
+    HIPCHK(ctx, hipMalloc(&ctx->d_prior_mb, sizeof(int) * VLGP_PRIOR_SLOTS * 16 + 64));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_prior_mb, 0, sizeof(int) * VLGP_PRIOR_SLOTS * 16 + 64, ctx->stream));
+    return VLGP_OK;
 }
 
+template <int NT>
+static int launch_ichol_t(vlgp_ctx* ctx, const IcholArgs& A, size_t lds) {
+    auto fn = ichol_exact_kernel<NT>;
+    if (lds > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    hipLaunchKernelGGL(fn, dim3(A.L), dim3(NT), lds, ctx->stream, A);
+    return VLGP_OK;
+}
+
+// Factor every listed prior (all already present in ctx->priors) with the given hyper-parameters and wait for
+// the ranks.  in_table: the priors' rows of the device table are current, the kernel refreshes their ranks.
+int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
+                     bool in_table) {
+    const int L = ctx->L, R = ctx->R;
+    if (L > 16) return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 latents");
+    CHK(ensure_mailbox(ctx));
+    int* flag_words = ctx->h_prior_mb + VLGP_PRIOR_SLOTS * 16;
+    volatile unsigned long long* h_flag = reinterpret_cast<volatile unsigned long long*>(flag_words);
+    unsigned long long* d_flag = reinterpret_cast<unsigned long long*>(ctx->d_prior_mb_host + VLGP_PRIOR_SLOTS * 16);
+    unsigned* d_ticket = reinterpret_cast<unsigned*>(ctx->d_prior_mb + VLGP_PRIOR_SLOTS * 16);
+    // global scratch for the lengths whose residuals / pivots do not fit LDS
+    int64_t gw = 0;
+    for (Prior* pr : prs)
+        if (pr->T > 4096) gw = std::max<int64_t>(gw, (int64_t)L * (2 * (int64_t)pr->T + (pr->T + 1) / 2 + 1));
+    if (gw) CHK(vlgp_ensure_work(ctx, gw));
+    for (size_t base = 0; base < prs.size(); base += VLGP_PRIOR_SLOTS) {
+        const size_t cnt = std::min<size_t>(VLGP_PRIOR_SLOTS, prs.size() - base);
+        unsigned long long last = 0;
+        for (size_t j = 0; j < cnt; ++j) {
+            Prior& pr = *prs[base + j];
+            IcholArgs A;
+            A.T = pr.T; A.R = R; A.L = L;
+            for (int l = 0; l < L; ++l) { A.omega[l] = omega[l]; A.sigma[l] = sigma[l]; }
+            A.full = pr.d_full; A.compact = pr.d_compact;
+            A.rl_table = (in_table && ctx->d_prior_rl && pr.index >= 0) ? ctx->d_prior_rl + (int64_t)pr.index * L : nullptr;
+            A.rank_dev = ctx->d_prior_mb + j * 16;
+            A.rank_host = ctx->d_prior_mb_host + j * 16;
+            A.flag_host = d_flag;
+            A.seq = last = ++ctx->prior_seq;
+            A.ticket = d_ticket;
+            const bool in_lds = pr.T <= 4096;
+            A.gwork = in_lds ? nullptr : ctx->d_work;
+            A.giwork = in_lds ? nullptr : reinterpret_cast<int*>(ctx->d_work + (int64_t)L * 2 * pr.T);
+            const int NL = ICH_LEAVES(pr.T);
+            const size_t lds = 8 * (size_t)(16 + NL + (in_lds ? 2 * pr.T : 0)) + 4 * (size_t)(24 + 2 * NL + (in_lds ? pr.T : 0)) + 16;
+            vlgp_prof_begin(ctx, VLGP_PROF_PRIOR);
+            if (pr.T <= 64) CHK(launch_ichol_t<64>(ctx, A, lds));
+            else if (pr.T <= 512) CHK(launch_ichol_t<256>(ctx, A, lds));
+            else CHK(launch_ichol_t<1024>(ctx, A, lds));
+            vlgp_prof_end(ctx, VLGP_PROF_PRIOR, (double)L);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        unsigned spins = 0;
+        while (*h_flag != last) {
+            if ((++spins & 0xfff) == 0) {  // a faulted kernel must not hang the host
+                const hipError_t qe = hipStreamQuery(ctx->stream);
+                if (qe == hipSuccess) {
+                    if (*h_flag == last) break;
+                    if ((spins >> 12) > 64) return vlgp_fail(ctx, VLGP_ERR_HIP, "prior kernel finished without publishing its ranks");
+                } else if (qe != hipErrorNotReady) {
+                    return vlgp_fail(ctx, VLGP_ERR_HIP, "prior kernel failed: %s", hipGetErrorString(qe));
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (size_t j = 0; j < cnt; ++j) {
+            Prior& pr = *prs[base + j];
+            pr.rl.assign(ctx->h_prior_mb + j * 16, ctx->h_prior_mb + j * 16 + L);
+        }
+    }
+    return VLGP_OK;
+}
+
+// host-injected factor (vlgp_set_prior): rank per latent and the compact copy
 int launch_compact_prior(vlgp_ctx* ctx, Prior& pr) {
     const int L = ctx->L, R = ctx->R, T = pr.T;
-    CHK(vlgp_ensure_work(ctx, 4 * L + 8));
-    CHK(vlgp_ensure_pinned(ctx, 4 * L + 8));
+    CHK(vlgp_ensure_work(ctx, L + 8));
+    CHK(vlgp_ensure_pinned(ctx, L + 8));
     int* d_rank = reinterpret_cast<int*>(ctx->d_work);
     hipLaunchKernelGGL(prior_rank_kernel, dim3(L), dim3(256), 0, ctx->stream, T, R, pr.d_full, d_rank);
+    HIPCHK(ctx, hipGetLastError());
+    const int gx = (int)((((int64_t)T * R) + 255) / 256);
+    hipLaunchKernelGGL(prior_compact_kernel, dim3(gx > 64 ? 64 : gx, L), dim3(256), 0, ctx->stream, T, R, pr.d_full,
+                       d_rank, pr.d_compact);
     HIPCHK(ctx, hipGetLastError());
     int* h_rank = reinterpret_cast<int*>(ctx->h_pinned);
     HIPCHK(ctx, hipMemcpyAsync(h_rank, d_rank, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     pr.rl.assign(h_rank, h_rank + L);
-    pr.goff.resize(L);
-    int64_t off = 0;
-    for (int l = 0; l < L; ++l) {
-        pr.goff[l] = off;
-        off += (int64_t)T * pr.rl[l];
-    }
-    pr.compact_len = off;  // d_compact was allocated at full (L, T, R) capacity
-    // device copies of rl / goff for the compaction kernel (reuse workspace)
-    int64_t* h_goff = reinterpret_cast<int64_t*>(ctx->h_pinned) + L;  // after the ints
-    for (int l = 0; l < L; ++l) h_goff[l] = pr.goff[l];
-    int64_t* d_goff = reinterpret_cast<int64_t*>(ctx->d_work) + L;
-    HIPCHK(ctx, hipMemcpyAsync(d_goff, h_goff, sizeof(int64_t) * L, hipMemcpyHostToDevice, ctx->stream));
-    const int gx = (int)((((int64_t)T * R) + 255) / 256);
-    hipLaunchKernelGGL(prior_compact_kernel, dim3(gx > 64 ? 64 : gx, L), dim3(256), 0, ctx->stream, T, R, L,
-                       pr.d_full, d_rank, d_goff, pr.d_compact);
+    return VLGP_OK;
+}
+
+// ---- debug: the device build of np_exact.h, element-wise (tests compare it with the host NumPy) ----
+__global__ void npx_probe_kernel(int kind, int64_t n, const double* a, const double* b, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (kind == 0) out[i] = npx_exp(a[i]);
+    else if (kind == 1) out[i] = sqrt(a[i]);
+    else if (kind == 2) out[i] = a[i] / b[i];
+    else out[i] = fma(a[i], b[i], out[i]);
+}
+int launch_npx_probe(vlgp_ctx* ctx, int kind, int64_t n, const double* d_a, const double* d_b, double* d_out) {
+    hipLaunchKernelGGL(npx_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, kind, n, d_a, d_b,
+                       d_out);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return VLGP_OK;
 }
