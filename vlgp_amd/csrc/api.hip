@@ -938,8 +938,9 @@ extern "C" int vlgp_mstep_begin(vlgp_ctx* ctx, int set, int n_iter, int use_hess
     if (n_iter >= 1)  // core.py:131-133
         CHK(launch_mstep(ctx, *us, n_iter, use_hessian, eps, lr, da_bound, db_bound));
     HIPCHK(ctx, hipEventRecord(ctx->ev_m_done, ctx->mstream));
-    // join (device side): later work on the main stream sees the new a, b
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_m_done, 0));
+    // NO device-side join here: the H-step rounds and the prior rebuild queued on the main stream meanwhile
+    // touch neither a, b nor anything the M-step writes, and every entry point that does joins on the host
+    // first (vlgp_join_m waits for ev_m_done) -- a stream wait here would serialise the H-step behind the M-step
     ctx->m_pending = true;
     return VLGP_OK;
 }
