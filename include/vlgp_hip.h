@@ -185,6 +185,9 @@ int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]);
  * world > 1): the H-step then issues no RCCL collective, so the M-step lane may run concurrently with
  * it across ranks (its communicator is the only one in flight). */
 int vlgp_comm_host_exchange(vlgp_ctx* ctx);
+/* Transport behind the handle's all-reduces: 0 none (single rank), 1 RCCL, 2 host shared memory
+ * (VLGP_COMM_TRANSPORT=shm, a test vehicle: several ranks on one GPU). */
+int vlgp_comm_transport(vlgp_ctx* ctx);
 /* In-place sum over ranks of n host doubles (staged through the device, on the
  * handle's stream, synchronous).  With no communicator attached it is a no-op.
  * n == 0 is a pure barrier. */

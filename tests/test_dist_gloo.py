@@ -70,3 +70,68 @@ def test_two_rank_mstep_protocol_and_rendezvous():
     for rank, err, same, _ in res:
         assert err < 1e-9, (rank, err)
         assert same
+
+
+def _init_worker(rank, world, port, q):
+    """preprocess.initialize on a shard with the pooled factor analysis, sums through gloo."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as td
+
+    from vlgp_amd import synth
+    from vlgp_amd.dist import shard
+    from vlgp_amd.preprocess import get_config, get_params, initialize
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Pool:  # what an attached Engine offers: in-place sum over ranks of a float64 array
+            def __init__(self):
+                self.rank, self.world = rank, world
+
+            def allreduce_host(self, arr):
+                t = torch.from_numpy(arr.reshape(-1))
+                td.all_reduce(t)
+                return arr
+
+        trials = synth.make_trials(7, 150, 12, 3, seed=2)  # 7 trials over 2 ranks: uneven shards
+        mine = shard(trials, rank, world)
+        cfg = get_config()
+        params = get_params(mine, 3, omega_bound=cfg["omega_bound"])
+        np.random.seed(11 + 5 * rank)  # ranks do NOT share an RNG state: rank 0's draw must be the one used
+        initialize(mine, params, cfg, pool=Pool() if world > 1 else None)
+        q.put((rank, params["a"], params["b"], params["noise"], np.concatenate([t["mu"] for t in mine])))
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_pooled_initialisation_matches_single_process():
+    """A sharded fit must start from the initialisation of the unsharded one (every rank used to
+    run its own factor analysis and keep its own latents)."""
+    import torch.multiprocessing as mp
+
+    from vlgp_amd import synth
+    from vlgp_amd.preprocess import get_config, get_params, initialize
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_init_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    trials = synth.make_trials(7, 150, 12, 3, seed=2)
+    cfg = get_config()
+    params = get_params(trials, 3, omega_bound=cfg["omega_bound"])
+    np.random.seed(11)  # rank 0's stream
+    initialize(trials, params, cfg)
+    for k, i in (("a", 1), ("b", 2), ("noise", 3)):
+        assert np.array_equal(res[0][i], res[1][i])  # replicated bit for bit
+        assert np.abs(res[0][i] - params[k]).max() < 1e-9 * max(np.abs(params[k]).max(), 1.0), k
+    mu = np.concatenate([res[0][4], res[1][4]])
+    want = np.concatenate([t["mu"] for t in trials])
+    assert np.abs(mu - want).max() < 1e-9 * np.abs(want).max()

@@ -18,19 +18,26 @@ from conftest import ROOT, relerr
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, tmp, q):
+def _worker(rank, world, tmp, q, inject):
     os.environ.update({"VLGP_COMM_TRANSPORT": "shm", "RANK": str(rank), "WORLD_SIZE": str(world),
                        "LOCAL_RANK": "0", "MASTER_PORT": "29999", "VLGP_RENDEZVOUS_DIR": tmp})
     sys.path.insert(0, ROOT)
     import bench
+    from vlgp_amd import synth
     from vlgp_amd.api import FitSession
     from vlgp_amd.dist import Comm
 
-    trials, a0, b0, dims = bench.build_inputs("C1")
     comm = Comm.from_env() if world > 1 else None
+    if inject:
+        trials, a0, b0, dims = bench.build_inputs("C1")
+        kw = dict(a=a0.copy(), b=b0.copy())
+    else:  # nothing injected: the pooled factor-analysis initialisation (ranks seed differently on purpose)
+        trials = synth.make_trials(10, 200, 20, 3, seed=0)
+        dims, kw = (10, 200, 20, 3), {}
+        np.random.seed(4 + 3 * rank)
     mine = comm.shard(trials) if comm else trials
-    sess = FitSession(mine, dims[3], device=0, comm=comm, verbose=False, a=a0.copy(), b=b0.copy(),
-                      max_iter=3, min_iter=3)
+    sess = FitSession(mine, dims[3], device=0, comm=comm, verbose=False, max_iter=3, min_iter=3, **kw)
+    assert sess.eng.transport == ("shm" if world > 1 else "none")
     sess.run()
     res = sess.finish()
     p = res["params"]
@@ -57,15 +64,15 @@ def _collect(q, procs, limit=600.0):
     return got
 
 
-def test_two_ranks_one_gpu_match_single_process():
+def _run_worlds(worlds, inject):
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = {}
-    for world in (1, 2):
+    for world in worlds:
         q = ctx.Queue()
         with tempfile.TemporaryDirectory() as tmp:
-            procs = [ctx.Process(target=_worker, args=(r, world, tmp, q)) for r in range(world)]
+            procs = [ctx.Process(target=_worker, args=(r, world, tmp, q, inject)) for r in range(world)]
             for p in procs:
                 p.start()
             res = sorted(_collect(q, procs), key=lambda r: r[0])
@@ -73,17 +80,37 @@ def test_two_ranks_one_gpu_match_single_process():
                 p.join(timeout=120)
                 assert p.exitcode == 0
         out[world] = res
+    return out
+
+
+def test_ranks_on_one_gpu_match_single_process():
+    """2 and 4 ranks (uneven shards of the 10 trials at 4) against the single-process fit."""
+    out = _run_worlds((1, 2, 4), inject=True)
     one = out[1][0]
-    r0, r1 = out[2]
-    # parameters are replicated: bit-identical on both ranks
+    for world in (2, 4):
+        rs = out[world]
+        # parameters are replicated: bit-identical on every rank
+        for r in rs[1:]:
+            for i in (1, 2, 3, 4):
+                assert np.array_equal(rs[0][i], r[i])
+        # and equal to the single-process fit up to the order of the row sums (the prior factor is a bit-exact
+        # function of omega, so nothing amplifies the last-bit differences of the M/H-step sums)
+        for i in (1, 2, 3, 4):
+            assert relerr(rs[0][i], one[i]) < 1e-6, (world, i)
+        assert sum((r[5] for r in rs), []) == one[5]  # contiguous shards cover the trials in order
+        assert relerr(np.concatenate([r[6] for r in rs]), one[6]) < 1e-6  # full-length posterior means
+        assert all(r[7] == 3 for r in rs) and one[7] == 3
+
+
+def test_two_ranks_default_initialisation_matches_single_process():
+    """No a, b, mu handed in: the factor-analysis initialisation is pooled over the ranks (rank 0's subsample
+    draw, pooled second moments, global channel means), so the sharded fit starts where the unsharded one does."""
+    out = _run_worlds((1, 2), inject=False)
+    one, (r0, r1) = out[1][0], out[2]
     for i in (1, 2, 3, 4):
         assert np.array_equal(r0[i], r1[i])
-    # and equal to the single-process fit up to the order of the row sums (the prior factor is a bit-exact
-    # function of omega, so nothing amplifies the last-bit differences of the M/H-step sums)
-    assert relerr(r0[1], one[1]) < 1e-6 and relerr(r0[2], one[2]) < 1e-6
-    assert relerr(r0[3], one[3]) < 1e-6 and relerr(r0[4], one[4]) < 1e-6
-    assert r0[5] + r1[5] == one[5]  # contiguous shards cover the trials in order
-    assert r0[7] == r1[7] == one[7] == 3
+        assert relerr(r0[i], one[i]) < 1e-6, i
+    assert relerr(np.concatenate([r0[6], r1[6]]), one[6]) < 1e-6
 
 
 def test_bench_launch_line_two_ranks_one_gpu():
@@ -99,16 +126,16 @@ def test_bench_launch_line_two_ranks_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
 
 
-def test_rccl_failure_falls_back_to_shared_memory():
-    """Two ranks on ONE device make ncclCommInitRank fail on both ranks ("duplicate GPU"): the job must
-    carry on through the shared-memory all-reduce (Comm.attach) and say so, not abort."""
+def test_rccl_failure_is_loud():
+    """Two ranks on ONE device make ncclCommInitRank fail ("duplicate GPU"): the job must stop with the
+    reason on every rank -- a silent move to the host shared-memory transport would make a multi-GPU number
+    meaningless.  The shared-memory transport is opt-in (VLGP_COMM_TRANSPORT=shm, the tests above)."""
     env = {k: v for k, v in os.environ.items() if k != "VLGP_COMM_TRANSPORT"}
     env["VLGP_DEVICE"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C1"]
     done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert done.returncode == 0, done.stderr[-2000:]
-    assert "using the shared-memory all-reduce" in done.stderr
-    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    assert done.returncode != 0
+    assert "communicator initialisation failed" in done.stderr and "VLGP_COMM_TRANSPORT=shm" in done.stderr
+    assert not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]  # no result line

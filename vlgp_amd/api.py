@@ -70,26 +70,30 @@ class FitSession:
 
         if echo:
             echo("Initializing")
-        plan = initialize(trials, params, config, defer_latent=True)
-        fill_trials(trials)
-
         eng = E.Engine(params["ydim"], params["zdim"], params["xdim"], params["rank"],
                        np.asarray(params["likelihood"]) == "gaussian", device=device)
         self.eng = eng
         try:
+            multi = comm is not None and comm.world > 1
+            if multi:
+                comm.attach(eng)
+            # sharded fit: the subsample, the factor analysis and b = log mean y are pooled over the ranks
+            plan = initialize(trials, params, config, defer_latent=True, pool=eng if multi else None)
+            fill_trials(trials)
             eng.upload(SET_TRIALS, trials)
             if plan is not None:
                 # the two full passes over y of preprocess.initialize, on the device: mu = transform(y), b = log mean y
                 colsum = eng.project_latent(SET_TRIALS, plan["proj"], plan["shift"])
                 if plan["need_b"]:
+                    if multi:
+                        eng.allreduce_host(colsum)
                     params["b"] = np.log(np.maximum(colsum[None, :] / plan["rows"], config["eps"]))
             if echo:
                 echo("Initialized")
             fill_params(params)
             for key in ("a", "b", "noise", "omega", "sigma"):
                 params[key] = np.array(params[key], dtype=float)
-            if comm is not None and comm.world > 1:
-                comm.attach(eng)
+            if multi:
                 self._replicate_params()
             eng.set_params(params["a"], params["b"], params["noise"])
             self.dev_trials = E.DeviceTrials(trials, eng, SET_TRIALS)

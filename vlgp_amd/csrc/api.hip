@@ -397,6 +397,7 @@ extern "C" int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BY
 }
 
 extern "C" int vlgp_comm_host_exchange(vlgp_ctx* ctx) { return ctx && ctx->hx ? 1 : 0; }
+extern "C" int vlgp_comm_transport(vlgp_ctx* ctx) { return !ctx ? 0 : (ctx->comm ? 1 : (ctx->shm ? 2 : 0)); }
 
 extern "C" int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n) {
     NEED_CTX(ctx);

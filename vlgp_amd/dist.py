@@ -32,10 +32,29 @@ def shard(items, rank, world):
 
 
 def _rendezvous_path():
-    # every rank of one torchrun launch shares the agent as parent process and
-    # the master port; together they name the launch on this node
-    tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-    return os.path.join(os.environ.get("VLGP_RENDEZVOUS_DIR", "/tmp"), "vlgp_rccl_%s.id" % tag)
+    """Where rank 0 leaves the communicator ids for the other ranks of this launch (single node).
+
+    Every rank of one torchrun launch shares the agent as parent process and the master port; the
+    parent's start time (``/proc/<ppid>/stat``) tells a recycled pid from the original, so a file left
+    behind by a crashed earlier launch is never mistaken for this one's.  The files live in a per-user
+    directory of mode 0700 (nobody else can pre-create them)."""
+    ppid = os.getppid()
+    born = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            born = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    tag = "%s_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), ppid, born, os.environ.get("TORCHELASTIC_RUN_ID", "x"))
+    base = os.environ.get("VLGP_RENDEZVOUS_DIR")
+    if not base:
+        base = os.path.join("/tmp", "vlgp_%d" % os.getuid())
+        os.makedirs(base, mode=0o700, exist_ok=True)
+        try:
+            os.chmod(base, 0o700)
+        except OSError:
+            pass
+    return os.path.join(base, "vlgp_rccl_%s.id" % tag)
 
 
 def exchange_unique_id(rank, world, make_id, path=None, timeout=120.0):
@@ -84,17 +103,16 @@ class Comm:
     def attach(self, engine):
         """Bind ``engine`` to this launch's communicators (main lane + M-step lane).
 
-        RCCL is the transport.  If it cannot be used on this node -- ``librccl.so`` missing on some
-        rank, or ``ncclCommInitRank`` failing (on this pool e.g. ``hipIpcGetMemHandle: invalid
-        argument`` when ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is not exported) -- every rank switches to the
-        host shared-memory all-reduce of ``libvlgp_hip.so`` (``VLGP_COMM_TRANSPORT=shm``: same call
-        sites, same deterministic rank-order sum) and says so on stderr, instead of aborting the job.
-        The ranks agree on the first case through per-rank status files before anyone enters
+        RCCL is the transport.  If it cannot be used -- ``librccl.so`` missing on some rank, or
+        ``ncclCommInitRank`` failing (on this pool e.g. ``hipIpcGetMemHandle: invalid argument`` when
+        ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is not exported) -- the job FAILS, on every rank, with the
+        reason: a multi-GPU run that silently moved its collectives to host memory would report
+        numbers that say nothing about xGMI.  The host shared-memory all-reduce exists for tests that
+        put several ranks on one GPU and is strictly opt-in: ``VLGP_COMM_TRANSPORT=shm``.
+        The ranks agree on "RCCL loads everywhere" through per-rank status files before anyone enters
         ``ncclCommInitRank`` (a rank that went ahead alone would block forever)."""
         if self.world == 1 and not os.environ.get("VLGP_FORCE_RCCL"):
             return
-        import sys
-
         from .engine import VlgpError, unique_id
 
         base = self.path or _rendezvous_path()
@@ -102,46 +120,34 @@ class Comm:
             try:
                 unique_id()  # probes dlopen(librccl) + ncclGetUniqueId on this rank
                 mine = b"ok"
-            except VlgpError:
-                mine = b"no"
+            except VlgpError as err:
+                mine = ("no: %s" % err).encode()
             votes = [exchange_unique_id(0 if r == self.rank else 1, 2, lambda: mine, "%s.vote%d" % (base, r))
                      for r in range(self.world)]
-            if any(v != b"ok" for v in votes):
-                if self.rank == 0:
-                    print("vlgp_amd: RCCL unavailable on some rank, using the shared-memory all-reduce",
-                          file=sys.stderr, flush=True)
-                os.environ["VLGP_COMM_TRANSPORT"] = "shm"
-
-        def connect(tag):
-            uid = exchange_unique_id(self.rank, self.world, unique_id, base + tag)
-            uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + tag + ".aux")
-            engine.comm_init(uid, self.rank, self.world, uid_aux)
-            return uid, uid_aux
-
-        tags = [""]
+            bad = [(r, v) for r, v in enumerate(votes) if v != b"ok"]
+            if bad:
+                raise VlgpError("RCCL is unavailable on rank(s) %s (%s); set VLGP_COMM_TRANSPORT=shm to run the "
+                                "ranks over the host shared-memory test transport instead"
+                                % ([r for r, _ in bad], bad[0][1].decode(errors="replace")))
+        if self.uid is not None:  # ids handed in by the caller
+            if getattr(self, "uid_aux", None) is None:
+                self.uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + ".aux")
+        else:
+            self.uid = exchange_unique_id(self.rank, self.world, unique_id, base)
+            self.uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + ".aux")
         try:
-            if self.uid is not None:  # ids handed in by the caller
-                if getattr(self, "uid_aux", None) is None:
-                    self.uid_aux = exchange_unique_id(self.rank, self.world, unique_id, base + ".aux")
-                engine.comm_init(self.uid, self.rank, self.world, self.uid_aux)
-            else:
-                self.uid, self.uid_aux = connect("")
+            engine.comm_init(self.uid, self.rank, self.world, self.uid_aux)
         except VlgpError as err:
-            if os.environ.get("VLGP_COMM_TRANSPORT") == "shm":
-                raise
-            print("vlgp_amd: rank %d: RCCL initialisation failed (%s); using the shared-memory all-reduce"
-                  % (self.rank, err), file=sys.stderr, flush=True)
-            os.environ["VLGP_COMM_TRANSPORT"] = "shm"
-            tags.append(".shm")
-            self.uid, self.uid_aux = connect(".shm")
+            raise VlgpError("rank %d: communicator initialisation failed (%s); no fallback is taken -- "
+                            "VLGP_COMM_TRANSPORT=shm selects the host shared-memory test transport explicitly"
+                            % (self.rank, err)) from err
         engine.barrier()
         if self.rank == 0:
-            for tag in tags:
-                for path in (base + tag, base + tag + ".aux"):
-                    try:
-                        os.remove(path)
-                    except OSError:
-                        pass
+            for path in (base, base + ".aux"):
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
         try:
             os.remove("%s.vote%d" % (base, self.rank))
         except OSError:

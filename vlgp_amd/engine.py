@@ -269,6 +269,11 @@ class Engine:
         self.rank, self.world = int(rank), int(world)
         self.host_exchange = bool(self.lib.vlgp_comm_host_exchange(self.h))
 
+    @property
+    def transport(self):
+        """"none" (single rank), "rccl" or "shm" (the opt-in host shared-memory test transport)."""
+        return ("none", "rccl", "shm")[int(self.lib.vlgp_comm_transport(self.h))]
+
     def allreduce_host(self, arr):
         """In-place sum over ranks of a float64 host array (no-op on one GPU)."""
         assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
@@ -376,7 +381,8 @@ class _Bound:
             _push_params(eng, p)
             eng.upload(0, tr)
             if self.need_prior:
-                chol = p.get("cholesky") or {}
+                chol = p.get("cholesky")  # may be a _LazyPrior: an empty-looking dict that answers __contains__
+                chol = {} if chol is None else chol
                 for T in sorted({t["y"].shape[0] for t in tr}):
                     if T not in chol:
                         raise KeyError("params['cholesky'] has no factor for length %d "

@@ -106,15 +106,29 @@ def _projected_svd(C, omega):
     return s, Vt, basis
 
 
-def fit_factor_analysis(X, n_components, seed=0, tol=1e-2, max_iter=1000):
-    """EM factor analysis of the rows of X; the randomized-SVD variant with ``RandomState(seed)``."""
+def fit_factor_analysis(X, n_components, seed=0, tol=1e-2, max_iter=1000, allreduce=None, rank=0, world=1):
+    """EM factor analysis of the rows of X; the randomized-SVD variant with ``RandomState(seed)``.
+
+    With ``allreduce`` (in-place sum over ranks of a float64 array) X holds only THIS rank's rows of the
+    sample: the estimator needs the rows through their count, sum and second-moment matrix alone (plus one
+    arg-max for the sign convention), so every rank obtains the fit of the pooled sample."""
     X = np.asarray(X, dtype=float)
     n, p = X.shape
     k = int(n_components)
-    mean = X.mean(axis=0)
-    Xc = X - mean
-    var = Xc.var(axis=0)
-    S = (Xc.T @ Xc) / n
+    if allreduce is None:
+        mean = X.mean(axis=0)
+        Xc = X - mean
+        var = Xc.var(axis=0)
+        S = (Xc.T @ Xc) / n
+    else:
+        mom = np.concatenate([[float(n)], X.sum(axis=0), (X.T @ X).ravel()])
+        allreduce(mom)
+        n = int(round(mom[0]))
+        mean = mom[1:1 + p] / n
+        S = mom[1 + p:].reshape(p, p) / n - np.outer(mean, mean)
+        S = 0.5 * (S + S.T)
+        var = np.diag(S).copy()
+        Xc = X - mean
     rng = np.random.RandomState(seed)
     size = k + _OVERSAMPLES
     llconst = p * math.log(2.0 * math.pi) + k
@@ -140,7 +154,16 @@ def fit_factor_analysis(X, n_components, seed=0, tol=1e-2, max_iter=1000):
         psi = np.maximum(var - (W ** 2).sum(axis=0), _SMALL)
     # sign convention of the final iterate: largest |entry| of each left singular vector positive
     U = Xc @ ((basis[:, :k] / sqrt_psi[:, None]) / math.sqrt(n))
-    rows = np.argmax(np.abs(U), axis=0)
-    signs = np.sign(U[rows, np.arange(k)])
+    if allreduce is None:
+        rows = np.argmax(np.abs(U), axis=0)
+        signs = np.sign(U[rows, np.arange(k)])
+    else:  # the arg-max runs over the rows of every rank: each rank posts its own candidate, lowest rank wins ties
+        slots = np.zeros((world, k, 2))
+        if U.shape[0]:
+            rows = np.argmax(np.abs(U), axis=0)
+            slots[rank, :, 0] = np.abs(U[rows, np.arange(k)])
+            slots[rank, :, 1] = np.sign(U[rows, np.arange(k)])
+        allreduce(slots)
+        signs = slots[np.argmax(slots[:, :, 0], axis=0), np.arange(k), 1]
     signs[signs == 0] = 1.0
     return FactorModel(W * signs[:, None], psi, mean, loglike)

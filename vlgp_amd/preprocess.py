@@ -58,18 +58,36 @@ def _gather_rows(trials, pick):
     return out
 
 
-def initialize(trials, params, config, defer_latent=False):
+def initialize(trials, params, config, defer_latent=False, pool=None):
     """vlgp/preprocess.py:4-46.
 
     With ``defer_latent`` (used by ``fit``, which uploads y anyway) the two operations that touch
     every row of y -- the initial latents ``mu = transform(y)`` and ``b = log mean y`` -- are left
     to the device: the function then returns ``{"proj", "shift", "need_b"}`` for
     ``Engine.project_latent`` and gives every trial a zero ``mu`` placeholder.  It falls back to the
-    host path (and returns None) when the caller supplied a transform or any ``mu``."""
+    host path (and returns None) when the caller supplied a transform or any ``mu``.
+
+    ``pool`` (an attached :class:`Engine` of a multi-rank fit: ``allreduce_host``, ``rank``, ``world``):
+    ``trials`` is this rank's shard.  The subsample is then drawn over the rows of ALL ranks (rank 0's
+    draw), the factor analysis is fitted to the pooled sample (every rank gets the same loading, noise
+    and latent map) and ``b`` is the log of the global channel means -- the same initialisation the
+    single-process fit of the concatenated trials computes, whatever the sharding."""
     zdim, xdim = params["zdim"], params["xdim"]
-    rows = int(sum(tr["y"].shape[0] for tr in trials))
+    rows_local = int(sum(tr["y"].shape[0] for tr in trials))
     ydim = trials[0]["y"].shape[-1]
+    pooled = pool is not None and getattr(pool, "world", 1) > 1
+    row0, rows = 0, rows_local
+    if pooled:
+        counts = np.zeros(pool.world)
+        counts[pool.rank] = rows_local
+        pool.allreduce_host(counts)
+        row0, rows = int(counts[:pool.rank].sum()), int(counts.sum())
     pick = np.random.choice(rows, max(rows // 10, 50))
+    if pooled:
+        buf = pick.astype(np.float64) if pool.rank == 0 else np.zeros(pick.size)
+        pool.allreduce_host(buf)
+        pick = buf.astype(np.int64)
+        pick = pick[(pick >= row0) & (pick < row0 + rows_local)] - row0
     defer = bool(defer_latent) and params.get("transform") is None and \
         not any(tr.get("mu") is not None for tr in trials)
     y = None if defer else np.concatenate([tr["y"] for tr in trials], axis=0)
@@ -80,7 +98,11 @@ def initialize(trials, params, config, defer_latent=False):
         from .fa import fit_factor_analysis
 
         sample = _gather_rows(trials, pick) if defer else y[pick, :]
-        fa = fit_factor_analysis(sample, zdim, seed=0)
+        if pooled:
+            fa = fit_factor_analysis(sample, zdim, seed=0, allreduce=pool.allreduce_host, rank=pool.rank,
+                                     world=pool.world)
+        else:
+            fa = fit_factor_analysis(sample, zdim, seed=0)
         z = fa.transform(sample)
         a = fa.components
         params["transform"] = fa.transform
@@ -88,9 +110,20 @@ def initialize(trials, params, config, defer_latent=False):
             params["a"] = a
         need_b = params.get("b") is None
         if need_b and not defer:
-            params["b"] = np.log(np.maximum(np.mean(y, axis=0, keepdims=True), config["eps"]))
+            colsum = np.sum(y, axis=0, keepdims=True)
+            if pooled:
+                pool.allreduce_host(colsum)
+            params["b"] = np.log(np.maximum(colsum / rows, config["eps"])) if pooled else \
+                np.log(np.maximum(np.mean(y, axis=0, keepdims=True), config["eps"]))
         if params.get("noise") is None:
-            params["noise"] = np.var(sample - z @ a, ddof=0, axis=0)
+            res = sample - z @ a
+            if pooled:
+                mom = np.concatenate([[float(res.shape[0])], res.sum(axis=0), (res * res).sum(axis=0)])
+                pool.allreduce_host(mom)
+                m1 = mom[1:1 + ydim] / mom[0]
+                params["noise"] = mom[1 + ydim:] / mom[0] - m1 * m1
+            else:
+                params["noise"] = np.var(res, ddof=0, axis=0)
         if defer:
             plan = {"proj": fa.projection, "shift": fa.shift, "need_b": need_b, "rows": rows}
     to_latent = params["transform"]
