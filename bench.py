@@ -53,75 +53,107 @@ def build_inputs(name):
     return trials, params["a"], params["b"], (n_trials, n_bins, N, L)
 
 
-def algorithmic_work(T, N, L, P, r):
-    """SURVEY.md section 8(d) minimal-algorithm counts (nominal r = 50), per work unit."""
+def estep_flops(T, N, L, ranks):
+    """SURVEY.md section 8(d) count for one unit x one inner sweep of the E-step: the (T x N) passes plus, per
+    latent of rank r, the build of I + G'WG, its factorisation and the mean / variance updates."""
+    return 12.0 * T * L * N + sum(5.0 * T * r * r + 2.0 / 3.0 * r ** 3 + 8.0 * T * r for r in ranks)
+
+
+def algorithmic_work(T, N, L, P):
+    """SURVEY.md section 8(d) minimal-algorithm counts per work unit (the E-step one is estep_flops)."""
     return {
-        # one unit (segment) x one inner sweep of the E-step
-        "estep_flops_per_unit_sweep": 12.0 * T * L * N + L * (5.0 * T * r * r + 2.0 / 3.0 * r ** 3 + 8.0 * T * r),
         # one row of one Newton iteration of the M-step
         "mstep_flops_per_row": 4.0 * L * N + N * (2.0 * L * L + 9.0 * L + 4.0 * P * P),
-        "mstep_bytes_per_row": 8.0 * (N * (1 + P) + 2 * L),
+        "mstep_bytes_per_row_survey": 8.0 * (N * (1 + P) + 2 * L),   # SURVEY's count: y and x re-read every iteration
+        "mstep_bytes_per_row_kernel": 8.0 * 2 * L,                   # what the kernel streams: mu, v (y hoisted, x == 1)
         # one segment of one H-step objective evaluation
         "hstep_flops_per_seg_eval": T ** 3 + 4.0 * T * T,
         "hstep_bytes_per_seg_eval": 16.0 * T,
     }
 
 
+_PMC_CACHE = {}
+
+
 def pmc_traffic(kernel_key):
-    """Per-launch HBM bytes of a kernel from the committed rocprofv3 --pmc passes
-    (profiles/r1/pmc_summary.json: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM,
-    plus WRITE_SIZE; separate passes).  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+    """Per-launch HBM bytes of a kernel from the committed rocprofv3 --pmc passes (profiles/r2/pmc_summary.json,
+    else profiles/r1: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, plus WRITE_SIZE; separate
+    passes).  None when no measurement is on file for that exact kernel name."""
+    if not _PMC_CACHE:
+        for rnd in ("r1", "r2"):  # later rounds override
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
+                    _PMC_CACHE.update(json.load(f))
+            except Exception:
+                pass
+        _PMC_CACHE.setdefault("_", {})
+    return _PMC_CACHE.get(kernel_key, {}).get("hbm_bytes_per_launch")
+
+
+def host_info():
+    model = "unknown"
     try:
-        with open(path) as f:
-            return json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def _oracle_em_iteration(name, budget_trials, threads):
+    """One timed EM iteration (the 2nd of two) of the oracle on the first ``budget_trials`` trials."""
+    from oracle import vlgp_oracle as O
+
+    from threadpoolctl import threadpool_limits
+
+    with threadpool_limits(limits=threads):
+        trials, a0, b0, (n_trials, n_bins, N, L) = build_inputs(name)
+        trials = trials[:budget_trials]
+        for tr in trials:
+            tr["x"] = np.ones((n_bins, 1, N))
+            tr["w"] = np.zeros((n_bins, L))
+            tr["v"] = np.zeros((n_bins, L))
+        cfg = O.make_config(max_iter=2, min_iter=2)
+        params = O.make_params(trials, L, a=a0.copy(), b=b0.copy())
+        params["da"], params["db"] = np.zeros_like(a0), np.zeros_like(b0)
+        O.fill_trials(trials)
+        O.make_cholesky(trials, params)
+        O.update_w(trials, params)
+        O.update_v(trials, params, cfg)
+        segs = O.cut_trials(trials, cfg["window"])
+        O.make_cholesky(segs, params)
+        O.fill_trials(segs)
+        t0 = time.perf_counter()
+        O.vem(segs, params, cfg)
+        wall = time.perf_counter() - t0
+    rt = cfg["runtime"]
+    return rt["em_elapsed"][-1], (rt["e_elapsed"][-1], rt["m_elapsed"][-1], rt["h_elapsed"][-1]), wall, len(segs), n_trials
 
 
 def cpu_baseline(name, budget_trials):
-    """Time the oracle's EM iteration on the first ``budget_trials`` trials of the
-    same workload (one BLAS thread: the reference is effectively single-core,
-    BASELINE.md section 2) and scale to the full trial count."""
-    from oracle import vlgp_oracle as O
-
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
-    except Exception:  # pragma: no cover
-        limiter = None
-    trials, a0, b0, (n_trials, n_bins, N, L) = build_inputs(name)
-    trials = trials[:budget_trials]
-    for tr in trials:
-        tr["x"] = np.ones((n_bins, 1, N))
-        tr["w"] = np.zeros((n_bins, L))
-        tr["v"] = np.zeros((n_bins, L))
-    cfg = O.make_config(max_iter=2, min_iter=2)
-    params = O.make_params(trials, L, a=a0.copy(), b=b0.copy())
-    params["da"], params["db"] = np.zeros_like(a0), np.zeros_like(b0)
-    O.fill_trials(trials)
-    O.make_cholesky(trials, params)
-    O.update_w(trials, params)
-    O.update_v(trials, params, cfg)
-    segs = O.cut_trials(trials, cfg["window"])
-    O.make_cholesky(segs, params)
-    O.fill_trials(segs)
-    t0 = time.perf_counter()
-    O.vem(segs, params, cfg)
-    wall = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
-    rt = cfg["runtime"]
-    per_iter = rt["em_elapsed"][-1]          # second iteration (first dropped)
+    """The oracle's EM iteration on a bounded sample of the same workload, on this host, scaled to the full
+    trial count: with one BLAS thread (the reference is effectively single-core) and
+    with OPENBLAS threads = nproc (50x50 matrices do not thread -- reported, not the baseline)."""
+    model, nproc = host_info()
+    per1, (e1, m1, h1), wall1, nseg, n_trials = _oracle_em_iteration(name, budget_trials, 1)
     scale = n_trials / float(budget_trials)
-    return {
-        "value": 1.0 / (per_iter * scale), "unit": "EM it/s", "cores": 1, "kind": "port",
+    out = {
+        "value": 1.0 / (per1 * scale), "unit": "EM it/s", "cores": 1, "kind": "port",
+        "cpu_model": model, "nproc": nproc,
         "sample": "oracle/vlgp_oracle.py vem on the first %d of %d trials (%d segments), 2 EM iterations, "
                   "2nd timed (E %.1fs, M %.1fs, H %.1fs), scaled x%g to the full workload; %.0fs wall"
-                  % (budget_trials, n_trials, len(segs), rt["e_elapsed"][-1], rt["m_elapsed"][-1],
-                     rt["h_elapsed"][-1], scale, wall),
-        "e_step_ms_full": 1e3 * rt["e_elapsed"][-1] * scale,
+                  % (budget_trials, n_trials, nseg, e1, m1, h1, scale, wall1),
+        "e_step_ms_full": 1e3 * e1 * scale,
     }
+    if nproc > 1:
+        half = max(budget_trials // 2, 1)
+        pern, _, walln, _, _ = _oracle_em_iteration(name, half, nproc)
+        out["all_threads"] = {"value": 1.0 / (pern * n_trials / float(half)), "unit": "EM it/s", "cores": nproc,
+                              "sample": "same on the first %d trials with %d BLAS threads; %.0fs wall" % (half, nproc, walln)}
+    return out
 
 
 def main():
@@ -162,7 +194,9 @@ def main():
     eng.profile_reset()
     eng.barrier()
     t0 = time.perf_counter()
+    ranks_per_step = []
     for _ in range(args.steps):
+        ranks_per_step.append([int(r) for r in eng.prior_ranks(cfg["window"])])  # the factor this E-step uses
         sess.em_iteration()
     eng.barrier()
     elapsed = time.perf_counter() - t0
@@ -171,62 +205,99 @@ def main():
     eng.allreduce_host(times)
     elapsed = float(times.max())
 
-    prof = {k: eng.profile_get(i) for k, i in
-            (("estep", _lib.PROF_ESTEP), ("mstep", _lib.PROF_MSTEP), ("hstep", _lib.PROF_HSTEP),
-             ("prior", _lib.PROF_PRIOR))}
+    kinds = (("estep", _lib.PROF_ESTEP), ("mstep", _lib.PROF_MSTEP), ("hstep", _lib.PROF_HSTEP),
+             ("prior", _lib.PROF_PRIOR), ("estep_ra16", _lib.PROF_ESTEP_RA16), ("estep_ra24", _lib.PROF_ESTEP_RA24),
+             ("estep_ra32", _lib.PROF_ESTEP_RA32), ("estep_long", _lib.PROF_ESTEP_LONG),
+             ("estep_generic", _lib.PROF_ESTEP_GENERIC))
+    prof = {k: eng.profile_get(i) for k, i in kinds}
     eng.profile(False)
     rt = sess.runtime
     timed = slice(args.warmup, args.warmup + args.steps)
     phase_ms = {k: 1e3 * float(np.mean(rt[k + "_elapsed"][timed])) for k in ("e", "m", "h", "em")}
     omega = np.array(sess.params["omega"]).tolist()
-    ranks_used = [int(r) for r in eng.get_prior(cfg["window"], with_rank=True)[1]]
+    ranks_used = [int(r) for r in eng.prior_ranks(cfg["window"])]
+    transport = eng.transport
     sess.close()
 
     if rank != 0:
         return
 
-    work = algorithmic_work(cfg["window"], N, L, 1, 50)
+    T = cfg["window"]
+    work = algorithmic_work(T, N, L, 1)
+    LT = 3 if L <= 3 else (5 if L <= 5 else (8 if L <= 8 else 10))
+
+    def entry(n, ms, per_launch, unit, bound, peak, **extra):
+        d = {"launches": n, "avg_ms": ms / n, "total_ms": ms, "unit": unit, "bound": bound,
+             "achieved": per_launch / (ms / n * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9), "peak": peak}
+        d["frac"] = d["achieved"] / peak
+        d.update(extra)
+        return d
+
     kernels = {}
-    n_e, ms_e, u_e = prof["estep"]
-    if n_e:
-        flops = work["estep_flops_per_unit_sweep"] * u_e / n_e
-        kernels["estep_fast_kernel"] = {"launches": n_e, "avg_ms": ms_e / n_e, "total_ms": ms_e,
-                                        "units_per_launch": u_e / n_e, "unit": "TFLOP/s", "bound": "mfma",
-                                        "achieved": flops / (ms_e / n_e * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                        "pmc_key": "estep_fast_kernel<5, 16, 16>"}
+    # E-step: one entry per instantiation that ran.  "achieved" charges what the kernel executed -- the SURVEY
+    # count at the EFFECTIVE ranks of the factor each launch used; "nominal" is the same count at the
+    # reference's fixed rank 50 (what a dense rank-50 implementation would have to do).
+    seg_local = n_seg_local
+    by_ra = {16: [], 24: [], 32: []}
+    for rk in ranks_per_step:
+        rmax = max(rk)
+        by_ra[16 if rmax <= 16 else (24 if rmax <= 24 else 32)].append(rk)
+    for ra, key in ((16, "estep_ra16"), (24, "estep_ra24"), (32, "estep_ra32")):
+        n_e, ms_e, u_e = prof[key]
+        if not n_e:
+            continue
+        rks = by_ra[ra] or ranks_per_step
+        exe = float(np.mean([estep_flops(T, N, L, rk) for rk in rks])) * u_e / n_e
+        nom = estep_flops(T, N, L, [50] * L) * u_e / n_e
+        name = "estep_fast_kernel<%d, %d, %d>" % (LT, 16 if ra == 16 else 32, ra)
+        kernels[name] = entry(n_e, ms_e, exe, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_e / n_e,
+                              flops_per_launch_executed=exe, flops_per_launch_nominal_rank50=nom,
+                              achieved_nominal_rank50=nom / (ms_e / n_e * 1e-3) / 1e12,
+                              frac_nominal_rank50=nom / (ms_e / n_e * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                              mean_effective_ranks=np.mean(np.array(rks, dtype=float), axis=0).round(2).tolist(),
+                              pmc_key=name)
     n_m, ms_m, u_m = prof["mstep"]
     if n_m:
-        nbytes = work["mstep_bytes_per_row"] * u_m / n_m
-        kernels["mstep_accum<NEWTON>"] = {"launches": n_m, "avg_ms": ms_m / n_m, "total_ms": ms_m,
-                                          "units_per_launch": u_m / n_m, "unit": "GB/s", "bound": "hbm",
-                                          "achieved": nbytes / (ms_m / n_m * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                          "pmc_key": "mstep_accum<5, 1, 1>"}
+        fl = work["mstep_flops_per_row"] * u_m / n_m
+        kernels["mstep_accum<NEWTON>"] = entry(
+            n_m, ms_m, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_m / n_m,
+            flops_per_launch_executed=fl,
+            bytes_per_launch_streamed=work["mstep_bytes_per_row_kernel"] * u_m / n_m,
+            bytes_per_launch_survey_count=work["mstep_bytes_per_row_survey"] * u_m / n_m,
+            pmc_key="mstep_accum<%d, 1, 1>" % LT,
+            note="compute-bound (exp + FMA per (row, channel)); y is read once per M-step by the PREP pass, "
+                 "each Newton launch streams only mu, v")
     n_h, ms_h, u_h = prof["hstep"]
     if n_h:
-        flops = work["hstep_flops_per_seg_eval"] * u_h / n_h
-        kernels["hstep_round_lean"] = {"launches": n_h, "avg_ms": ms_h / n_h, "total_ms": ms_h,
-                                     "units_per_launch": u_h / n_h, "unit": "TFLOP/s", "bound": "mfma",
-                                     "achieved": flops / (ms_h / n_h * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                     "pmc_key": "hstep_round_lean<50>"}
+        fl = work["hstep_flops_per_seg_eval"] * u_h / n_h
+        kernels["hstep_round_lean<50>"] = entry(
+            n_h, ms_h, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_h / n_h,
+            flops_per_launch_executed=fl, bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_h / n_h,
+            pmc_key="hstep_round_lean<50>")
+    n_p, ms_p, u_p = prof["prior"]
+    if n_p:
+        kernels["ichol_exact_kernel"] = {"launches": n_p, "avg_ms": ms_p / n_p, "total_ms": ms_p,
+                                         "note": "bit-exact math.ichol_gauss, one launch per H-step"}
     # north_star also asks for the HBM side of the factorisation kernels: measured bytes (PMC passes on
-    # file) over the live launch time, against the 8 TB/s peak -- expected far below 1 % for these
-    # compute-bound kernels
+    # file, keyed by the exact kernel name) over the live launch time, against the 8 TB/s peak
     for kd in kernels.values():
-        tb = pmc_traffic(kd["pmc_key"])
+        tb = pmc_traffic(kd.get("pmc_key", ""))
         if tb:
             kd["hbm_bytes_per_launch_pmc"] = tb
             kd["hbm_gbs"] = tb / (kd["avg_ms"] * 1e-3) / 1e9
             kd["hbm_frac"] = kd["hbm_gbs"] / HBM_PEAK_GBS
-    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    timed_kernels = {k: v for k, v in kernels.items() if "achieved" in v}
+    dominant = max(timed_kernels, key=lambda k: timed_kernels[k]["total_ms"]) if timed_kernels else None
     roofline = None
     if dominant:
         kd = kernels[dominant]
-        roofline = {"kernel": dominant, "bound": kd["bound"], "achieved": kd["achieved"], "peak": kd["peak"],
-                    "unit": kd["unit"], "frac": kd["achieved"] / kd["peak"],
-                    "traffic": pmc_traffic(kd["pmc_key"]),
+        # the contract's "mfma" = the compute roof: on CDNA4 the fp64 matrix and vector peaks coincide (78.6 TFLOP/s)
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": kd["achieved"], "peak": kd["peak"],
+                    "unit": kd["unit"], "frac": kd["frac"], "traffic": kd.get("hbm_bytes_per_launch_pmc"),
                     "hbm_gbs": kd.get("hbm_gbs"), "hbm_frac": kd.get("hbm_frac"),
                     "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"],
-                    "units_per_launch": kd["units_per_launch"]}
+                    "units_per_launch": kd["units_per_launch"],
+                    "algorithmic_flops_per_launch": kd["flops_per_launch_executed"]}
 
     out = {
         "metric": "EM iterations/sec", "value": args.steps / elapsed, "unit": "EM it/s",
@@ -236,11 +307,13 @@ def main():
         "config": {"workload": "%s: %d trials x %d bins x %d Poisson channels, %d latents, window %d -> %d segments; "
                                "Eniter=Mniter=25, rank 50, VB, Hstep on" % (args.workload, n_trials, n_bins, N, L,
                                                                              cfg["window"], n_seg),
-                   "parallelism": "trials sharded over %d rank(s); RCCL all-reduce of the M-step statistics and norms, "
-                                  "H-step round sums added on the host (shared memory)" % world},
+                   "parallelism": "trials sharded over %d rank(s)%s" % (
+                       world, "" if world == 1 else "; all-reduce of the M-step statistics and norms over " + transport +
+                       ", H-step round sums added on the host (shared memory)"),
+                   "transport": transport, "rccl_ranks": world if transport == "rccl" else 0},
         "ms_per_e_step": phase_ms["e"], "ms_per_m_step": phase_ms["m"], "ms_per_h_step": phase_ms["h"],
         "roofline": roofline, "kernels": kernels,
-        "effective_rank": ranks_used, "omega_final": omega,
+        "effective_rank": ranks_used, "effective_rank_per_step": ranks_per_step, "omega_final": omega,
     }
     if not args.no_cpu_baseline and world == 1:
         cb = cpu_baseline(args.workload, min(args.cpu_trials, n_trials))

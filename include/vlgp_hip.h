@@ -83,6 +83,11 @@ int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst,
 /* Write mu and v of a cut set back into its source set (no-op when aliased;
  * with overlapping segments later segments win, in order). */
 int vlgp_merge_units(vlgp_ctx* ctx, int cut_set);
+/* restore == 0: keep a device-side copy of the set's mu; restore != 0: write it back.  For the one place where
+ * the reference DETACHES segments from their trials: constrain_loading == "svd" rebinds every segment's mu
+ * (vlgp/core.py:407-408, `trial["mu"] = trial["mu"] @ us`), after which the parent trials keep the values they
+ * had at that moment -- the final inference of fit starts from those. */
+int vlgp_stash_mu(vlgp_ctx* ctx, int set, int restore);
 /* Any of the output pointers may be NULL. */
 int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v, double* w,
                         double* dmu);
@@ -201,7 +206,14 @@ int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n);
 #define VLGP_PROF_MSTEP 1
 #define VLGP_PROF_HSTEP 2
 #define VLGP_PROF_PRIOR 3
-#define VLGP_PROF_KINDS 4
+/* the fast E-step kernel by instantiation (register-array size 16 / 24 / 32), the long-unit kernel and the
+ * generic kernel; kind 0 reports the sum of all E-step kernels */
+#define VLGP_PROF_ESTEP_RA16 4
+#define VLGP_PROF_ESTEP_RA24 5
+#define VLGP_PROF_ESTEP_RA32 6
+#define VLGP_PROF_ESTEP_LONG 7
+#define VLGP_PROF_ESTEP_GENERIC 8
+#define VLGP_PROF_KINDS 9
 int vlgp_profile_enable(vlgp_ctx* ctx, int on);
 int vlgp_profile_reset(vlgp_ctx* ctx);
 /* launches, total milliseconds and work units recorded for `kind` since the last

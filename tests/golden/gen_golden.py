@@ -331,6 +331,48 @@ def gen_fit_h1():
     save("fit_c1_h1", **out)
 
 
+def gen_vem_c2():
+    """BASELINE.json configs[1] at full size: 50 trials x 500 bins x 50 channels, 3 latents -> 500 segments;
+    three EM iterations of the real reference with every default (H-step on), from injected a, b, mu."""
+    n_trials, n_bins, N, L = synth.CONFIGS["C2"]
+    trials0 = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    rng = np.random.default_rng(21)
+    a0 = 0.3 * rng.standard_normal((L, N))
+    b0 = np.log(np.maximum(np.mean(np.concatenate([t["y"] for t in trials0]), axis=0, keepdims=True), 1e-8))
+    mu0 = [0.2 * rng.standard_normal((n_bins, L)) for _ in trials0]
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy()} for t, m in zip(trials0, mu0)]
+    cfg = get_config(max_iter=3, min_iter=3)
+    params = get_params(trials, L, a=a0.copy(), b=b0.copy(), omega_bound=cfg["omega_bound"])
+    for tr in trials:
+        tr["x"] = np.ones((n_bins, 1, N))
+        tr["w"] = np.zeros((n_bins, L))
+        tr["v"] = np.zeros((n_bins, L))
+    fill_params(params)
+    fill_trials(trials)
+    gp.make_cholesky(trials, params, cfg)
+    core.update_w(trials, params, cfg)
+    core.update_v(trials, params, cfg)
+    segs = cut_trials(trials, params, cfg)
+    gp.make_cholesky(segs, params, cfg)
+    fill_trials(segs)
+    traj = {"mu": [], "a": [], "b": [], "omega": []}
+
+    def spy(tr_, p_, c_):
+        traj["mu"].append(sl.norm(np.concatenate([s["mu"] for s in tr_])))
+        traj["a"].append(sl.norm(p_["a"]))
+        traj["b"].append(sl.norm(p_["b"]))
+        traj["omega"].append(np.array(p_["omega"]))
+
+    cfg["callbacks"] = [spy]
+    core.vem(segs, params, cfg)
+    pick = np.arange(0, len(segs), 20)
+    save("vem_c2", norm_mu=np.array(traj["mu"]), norm_a=np.array(traj["a"]), norm_b=np.array(traj["b"]),
+         omega=np.array(traj["omega"]), a=params["a"], b=params["b"], noise=params["noise"],
+         it=cfg["runtime"]["it"], pick=pick, seg_mu=np.stack([segs[i]["mu"] for i in pick]),
+         seg_v=np.stack([segs[i]["v"] for i in pick]), seg_w=np.stack([segs[i]["w"] for i in pick]),
+         y_checksum=np.array([float(np.concatenate([t["y"] for t in trials0]).sum())]))
+
+
 def gen_init():
     """preprocess.initialize on C1 (FactorAnalysis on the seeded 10 % subsample)."""
     from vlgp.preprocess import initialize

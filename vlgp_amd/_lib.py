@@ -19,6 +19,7 @@ ABI_VERSION = 1
 MAX_SETS = 4
 UNIQUE_ID_BYTES = 128
 PROF_ESTEP, PROF_MSTEP, PROF_HSTEP, PROF_PRIOR = 0, 1, 2, 3
+PROF_ESTEP_RA16, PROF_ESTEP_RA24, PROF_ESTEP_RA32, PROF_ESTEP_LONG, PROF_ESTEP_GENERIC = 4, 5, 6, 7, 8
 
 _lib = None
 
@@ -44,6 +45,7 @@ _SIGNATURES = {
     "vlgp_cut_units": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _i64p, C.c_int]),
     "vlgp_merge_units": (C.c_int, [_h, C.c_int]),
     "vlgp_download_units": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
+    "vlgp_stash_mu": (C.c_int, [_h, C.c_int, C.c_int]),
     "vlgp_free_units": (C.c_int, [_h, C.c_int]),
     "vlgp_set_params": (C.c_int, [_h, _dp, _dp, _dp]),
     "vlgp_get_params": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp]),

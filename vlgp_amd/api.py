@@ -41,7 +41,7 @@ def _segments(trials, window, eng):
             starts.append(row0 + int(s))
         row0 += T
     eng.cut(SET_TRIALS, SET_SEGMENTS, np.asarray(starts, dtype=np.int64), window)
-    return E.DeviceTrials(segs, eng, SET_SEGMENTS)
+    return E.DeviceTrials(segs, eng, SET_SEGMENTS, parent_set=SET_TRIALS)
 
 
 class FitSession:
@@ -141,6 +141,8 @@ class FitSession:
         try:
             if self.segs is not self.dev_trials:
                 eng.merge(SET_SEGMENTS)
+                if self.segs.detached:  # constrain_loading "svd": the trials kept their pre-rotation mu (core.py:407-408)
+                    eng.stash_mu(SET_TRIALS, restore=True)
             E.make_cholesky(self.dev_trials, params, config)
             E.update_w(self.dev_trials, params, config)
             E.update_v(self.dev_trials, params, config)

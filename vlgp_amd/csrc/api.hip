@@ -441,7 +441,7 @@ static void free_set(vlgp_ctx* ctx, UnitSet& us) {
     (void)hipStreamSynchronize(ctx->stream);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     if (!us.alias) { fr(us.y); fr(us.x); fr(us.mu); fr(us.v); fr(us.w); }
-    fr(us.dmu); fr(us.d_off); fr(us.d_src_start); fr(us.d_unit_prior); fr(us.d_xb); fr(us.d_scratch);
+    fr(us.dmu); fr(us.d_off); fr(us.d_src_start); fr(us.d_unit_prior); fr(us.d_xb); fr(us.d_scratch); fr(us.d_mu_stash);
     us = UnitSet();
 }
 
@@ -666,6 +666,23 @@ extern "C" int vlgp_merge_units(vlgp_ctx* ctx, int cut_set) {
     UnitSet* p = vlgp_get_set(ctx, c->parent, true);
     if (!p) return VLGP_ERR_STATE;
     return launch_scatter(ctx, *c, *p, (int)(c->off[1] - c->off[0]));
+}
+
+extern "C" int vlgp_stash_mu(vlgp_ctx* ctx, int set, int restore) {
+    NEED_CTX(ctx);
+    CHK(vlgp_join_m(ctx));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    const size_t nb = (size_t)us->rows * ctx->L * sizeof(double);
+    if (!restore) {
+        if (!us->d_mu_stash) HIPCHK(ctx, hipMalloc(&us->d_mu_stash, nb));
+        HIPCHK(ctx, hipMemcpyAsync(us->d_mu_stash, us->mu, nb, hipMemcpyDeviceToDevice, ctx->stream));
+        return VLGP_OK;
+    }
+    if (!us->d_mu_stash) return vlgp_fail(ctx, VLGP_ERR_STATE, "set %d has no stashed mu", set);
+    ctx->hmom_us = nullptr;
+    HIPCHK(ctx, hipMemcpyAsync(us->mu, us->d_mu_stash, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    return VLGP_OK;
 }
 
 extern "C" int vlgp_download_units(vlgp_ctx* ctx, int set, double* mu, double* v, double* w, double* dmu) {
@@ -1143,8 +1160,15 @@ extern "C" int vlgp_profile_get(vlgp_ctx* ctx, int kind, int64_t* launches, doub
     NEED_CTX(ctx);
     if (kind < 0 || kind >= VLGP_PROF_KINDS) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad profile kind %d", kind);
     prof_drain(ctx);
-    if (launches) *launches = ctx->prof[kind].launches;
-    if (total_ms) *total_ms = ctx->prof[kind].ms;
-    if (units) *units = ctx->prof[kind].units;
+    ProfSlot tot = ctx->prof[kind];
+    if (kind == VLGP_PROF_ESTEP)  // every E-step kernel, whichever instantiation ran
+        for (int k = VLGP_PROF_ESTEP_RA16; k <= VLGP_PROF_ESTEP_GENERIC; ++k) {
+            tot.launches += ctx->prof[k].launches;
+            tot.ms += ctx->prof[k].ms;
+            tot.units += ctx->prof[k].units;
+        }
+    if (launches) *launches = tot.launches;
+    if (total_ms) *total_ms = tot.ms;
+    if (units) *units = tot.units;
     return VLGP_OK;
 }

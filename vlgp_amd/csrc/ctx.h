@@ -39,6 +39,7 @@ struct UnitSet {
     int* d_unit_prior = nullptr;  // prior-table row per unit
     uint64_t prior_epoch = 0;     // epoch of the table d_unit_prior was built against
     double* d_xb = nullptr;       // (rows, N) x.b, only when !x_ones
+    double* d_mu_stash = nullptr; // copy of mu taken by vlgp_stash_mu (rows x L)
     double* d_scratch = nullptr;  // long-unit E-step scratch
     int64_t scratch_len = 0;
 };

@@ -480,9 +480,9 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     if (us.Tmax <= 256 && small_d * 8 <= LDS_MAX) {
         const int nthr = nw_s * 64;
         A.rg = pick_rg(us.Tmax, N, nthr);
-        vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
+        vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_GENERIC);
         int rc = launch_l<true>(ctx, A, us.M, nthr, (size_t)small_d * 8);
-        vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
+        vlgp_prof_end(ctx, VLGP_PROF_ESTEP_GENERIC, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
         return rc;
     }
 
@@ -513,8 +513,8 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.scratch = us.d_scratch;
     if (lc_total) A.lc_global = us.d_scratch + need;
     A.rg = 64;
-    vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
+    vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_GENERIC);
     int rc = launch_l<false>(ctx, A, us.M, nthr, (size_t)long_d * 8);
-    vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
+    vlgp_prof_end(ctx, VLGP_PROF_ESTEP_GENERIC, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
     return rc;
 }

@@ -542,9 +542,10 @@ static int launch_fast_t(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, siz
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, nthr, lds);
         fprintf(stderr, "estep_fast<%d,%d,%d>: %d threads, %zu B LDS -> %d blocks per CU\n", LT, RP, RA, nthr, lds, nb);
     }
-    vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
+    constexpr int kind = RA <= 16 ? VLGP_PROF_ESTEP_RA16 : (RA <= 24 ? VLGP_PROF_ESTEP_RA24 : VLGP_PROF_ESTEP_RA32);
+    vlgp_prof_begin(ctx, kind);
     hipLaunchKernelGGL(fn, dim3(M), dim3(nthr), lds, ctx->stream, A, A.cols_g);
-    vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)M * (A.n_iter > 0 ? A.n_iter : 1));
+    vlgp_prof_end(ctx, kind, (double)M * (A.n_iter > 0 ? A.n_iter : 1));
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }

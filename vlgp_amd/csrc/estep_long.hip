@@ -566,13 +566,13 @@ int launch_estep_long(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     A.lc_global = us.d_scratch + need;  // here: per-unit partial-sum area
     A.lc_stride = part;
     A.rg = N >= 16 ? 4 : 1;  // lanes per row in the (T x N) passes (measured: 4 beats 64 by 6x at N = 100)
-    vlgp_prof_begin(ctx, VLGP_PROF_ESTEP);
+    vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_LONG);
     int rc;
     if (LT == 3) rc = launch_long_t<3>(ctx, A, us.M, lds);
     else if (LT == 5) rc = launch_long_t<5>(ctx, A, us.M, lds);
     else if (LT == 8) rc = launch_long_t<8>(ctx, A, us.M, lds);
     else rc = launch_long_t<10>(ctx, A, us.M, lds);
-    vlgp_prof_end(ctx, VLGP_PROF_ESTEP, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
+    vlgp_prof_end(ctx, VLGP_PROF_ESTEP_LONG, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
     if (rc != VLGP_OK) return rc;
     *handled = 1;
     return VLGP_OK;

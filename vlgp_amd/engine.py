@@ -140,6 +140,10 @@ class Engine:
                                               dptr(out.get("w")), dptr(out.get("dmu"))))
         return out
 
+    def stash_mu(self, set_id, restore=False):
+        """Keep (or write back) a device-side copy of the set's mu (see vlgp_stash_mu)."""
+        self._ck(self.lib.vlgp_stash_mu(self.h, int(set_id), int(bool(restore))))
+
     def free_units(self, set_id):
         self._ck(self.lib.vlgp_free_units(self.h, set_id))
         self.sets.pop(set_id, None)
@@ -173,6 +177,12 @@ class Engine:
 
     def clear_prior(self):
         self._ck(self.lib.vlgp_clear_prior(self.h))
+
+    def prior_ranks(self, T):
+        """Effective rank (number of columns ichol_gauss built) per latent for length T; no device traffic."""
+        rk = np.zeros(self.L, dtype=np.int32)
+        self._ck(self.lib.vlgp_get_prior(self.h, int(T), None, iptr(rk)))
+        return rk
 
     def get_prior(self, T, with_rank=False):
         G = np.empty((self.L, int(T), self.R))
@@ -320,10 +330,12 @@ class DeviceTrials(list):
     mu/v/w/dmu are refreshed only by :meth:`pull` (callbacks, end of fit).
     """
 
-    def __init__(self, trials, engine, set_id):
+    def __init__(self, trials, engine, set_id, parent_set=None):
         super().__init__(trials)
         self.engine = engine
         self.set_id = set_id
+        self.parent_set = parent_set  # segments: the set of the trials they were cut from
+        self.detached = False         # True once the segments' mu stopped writing through (constrain_loading "svd")
 
     def pull(self, keys=("mu", "v", "w", "dmu")):
         """Copy device state into the dicts: mu, v, dmu in place, w rebound
@@ -544,6 +556,12 @@ def constrain_loading(trials, params, config):
         params["a"] /= s[:, None]
         mat = np.diag(s)
     if isinstance(trials, DeviceTrials):
+        if kind == "svd" and getattr(trials, "parent_set", None) is not None and not trials.detached:
+            # the reference REBINDS every segment's mu here (core.py:407-408): from now on the segments no longer
+            # write through to their trials, whose mu stays what it is at this moment (fit's final inference
+            # starts from it).  Keep that copy; FitSession.finish puts it back after the merge.
+            trials.engine.stash_mu(trials.parent_set)
+            trials.detached = True
         trials.engine.apply_latent_map(trials.set_id, mat)
         _push_params(trials.engine, params)
     else:
