@@ -178,6 +178,15 @@ int vlgp_project_units(vlgp_ctx* ctx, int set, const double* proj, const double*
  * *count = number of rows.  For core.constrain_latent. */
 int vlgp_latent_moments(vlgp_ctx* ctx, int set, double* sum1, double* sum2, double* count);
 
+/* ---- posterior draws --------------------------------------------------- */
+/* api.sample_posterior (vlgp/api.py:142-168) for one trial of T bins: out (nsamples, T, L) row-major,
+ * out[s, :, l] = mu[:, l] + G_l Lc^-T eps[l, :, s] with Lc Lc' = I + G_l' diag(w[:, l]) G_l -- a draw from
+ * N(mu_l, (K_l^-1 + W_l)^-1), K_l = G_l G_l', without any T x T matrix.  Host arrays: mu, w (T, L);
+ * G (L, T, R) = params["cholesky"][T]; eps (L, R, nsamples) standard normal draws (rows beyond a latent's
+ * effective rank are ignored). */
+int vlgp_sample_posterior(vlgp_ctx* ctx, int T, const double* mu, const double* w, const double* G,
+                          int nsamples, const double* eps, double* out, int* n_failed);
+
 /* ---- multi-GPU (RCCL over xGMI) --------------------------------------- */
 /* Rank 0 makes the id, every rank passes the same id to vlgp_comm_init. */
 int vlgp_comm_unique_id(char id[VLGP_UNIQUE_ID_BYTES]);

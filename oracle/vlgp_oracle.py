@@ -680,3 +680,28 @@ def mstep_sharded(y, x, mu, v, a, b, gauss, n_iter, allreduce=None, use_hessian=
                 b[:, n] = _spd_solve(XtX[n], XtY[:, n] - XtM[n] @ a[:, n])
                 b[1:, n] = 0
     return a, b, da, db, noise
+
+
+# --------------------------------------------------------------------------
+# api.sample_posterior  (vlgp/api.py:142-168)
+# --------------------------------------------------------------------------
+def posterior_covariance_reference(G_l, w_l, reg=1e-6):
+    """The covariance the reference samples from: inv(inv(K + reg I) + W), K = G G'.  api.py:160-163."""
+    K = G_l @ G_l.T
+    return np.linalg.inv(np.linalg.inv(K + reg * np.eye(K.shape[0])) + np.diag(w_l))
+
+
+def sample_posterior_lowrank(mu, w, G, eps):
+    """Draws mu_l + G_l Lc^-T eps_l with Lc Lc' = I + G_l' W_l G_l: the same Gaussian as the reference's
+    (reg -> 0) through the low-rank factor.  eps: list of (r_l, n) standard normal arrays, r_l = number of
+    leading non-zero columns of G_l.  Returns (n, T, L)."""
+    T, L = mu.shape
+    n = eps[0].shape[1]
+    out = np.empty((n, T, L))
+    for l in range(L):
+        r = eps[l].shape[0]
+        Gl = G[l][:, :r]
+        H = Gl.T @ (w[:, [l]] * Gl)
+        Lc = np.linalg.cholesky(np.eye(r) + H)
+        out[:, :, l] = mu[:, l][None, :] + (Gl @ sla.solve_triangular(Lc.T, eps[l], lower=False)).T
+    return out

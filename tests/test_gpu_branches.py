@@ -182,3 +182,55 @@ def test_transform_value_parity(V):
                             params["b"], params["noise"], gauss, G, config["max_iter"])
         for k, arr in zip(("mu", "v", "w"), want):
             assert relerr(tg[k], arr) < STAGE, (k, T)
+
+
+def test_sample_posterior_on_the_device(V):
+    """api.sample_posterior (vlgp/api.py:142-168) through vlgp_sample_posterior: bit-for-bit the same normal draws
+    as the oracle's low-rank restatement -> same samples to rounding; mean and covariance of many draws equal
+    the reference's inv(inv(K + reg I) + W) to sampling error."""
+    rng = np.random.default_rng(0)
+    T, L = 40, 3
+    omega, sigma = np.array([4e-3, 2e-2, 9e-3]), np.array([1.0, 0.7, 1.2])
+    chol = O.build_prior([T], omega, sigma, 50)
+    trial = {"mu": rng.standard_normal((T, L)), "w": rng.random((T, L)) * 3.0}
+    n = 64
+    got = V.sample_posterior(trial, {"cholesky": chol}, n, rng=np.random.default_rng(1))
+    assert got.shape == (n, T, L)
+    g2 = np.random.default_rng(1)
+    eps = []
+    for l in range(L):
+        r = int(np.flatnonzero(np.any(chol[T][l] != 0, axis=0))[-1]) + 1
+        eps.append(g2.standard_normal((r, n)))
+    want = O.sample_posterior_lowrank(trial["mu"], trial["w"], chol[T], eps)
+    assert relerr(got, want) < 1e-10
+    n = 100000
+    draws = V.sample_posterior(trial, {"cholesky": chol}, n, rng=np.random.default_rng(2))
+    for l in range(L):
+        cov = O.posterior_covariance_reference(chol[T][l], trial["w"][:, l])
+        assert np.abs(np.cov(draws[:, :, l].T) - cov).max() < 0.03 * np.abs(cov).max() + 2e-3
+        assert np.abs(draws[:, :, l].mean(0) - trial["mu"][:, l]).max() < 0.02
+
+
+def test_command_line_fit_and_result_file(V, tmp_path):
+    """python -m vlgp_amd FIN FOUT N_FACTORS --max_iter --min_iter (vlgp/__main__.py:6-22): the saved result is
+    the dict fit returns, loadable with util.load, and equals the in-process fit on the same input."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    from vlgp_amd import synth, util
+
+    trials = synth.make_trials(4, 100, 10, 2, seed=3)
+    fin, fout = tmp_path / "trials.npy", tmp_path / "result"
+    np.save(fin, np.array(trials, dtype=object), allow_pickle=True)
+    code = "import numpy as np, sys; np.random.seed(1); from vlgp_amd.__main__ import cli; sys.exit(cli(sys.argv[1:]))"
+    done = subprocess.run([sys.executable, "-c", code, str(fin), str(fout), "2", "--max_iter", "3", "--min_iter", "3"],
+                          cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert "Loading" in done.stdout and "saved" in done.stdout
+    res = util.load(str(fout) + ".npy")
+    assert set(res) == {"trials", "params", "config"} and res["config"]["runtime"]["it"] == 3
+    np.random.seed(1)
+    want = V.fit([{"ID": t["ID"], "y": t["y"].copy()} for t in trials], 2, max_iter=3, min_iter=3, verbose=False)
+    assert np.array_equal(res["params"]["a"], want["params"]["a"])
+    assert np.array_equal(np.stack([t["mu"] for t in res["trials"]]), np.stack([t["mu"] for t in want["trials"]]))

@@ -494,6 +494,8 @@ def test_fit_end_to_end_golden(V, golden):
                 verbose=False)
     assert res["trials"] is trials
     assert [id(t["mu"]) for t in trials] == mu_ids
+    # the default regressors come back as the reference leaves them: a writable (T, xdim, N) array of ones
+    assert trials[0]["x"].shape == (200, 1, 20) and trials[0]["x"].flags.writeable and np.all(trials[0]["x"] == 1.0)
     assert set(res) == {"trials", "params", "config"}
     for k in ("mu", "v", "w", "dmu"):
         assert relerr(np.stack([t[k] for t in trials]), g[k]) < TRAJ, k

@@ -173,26 +173,27 @@ def test_factor_analysis_matches_sklearn(shape):
     assert relerr(own.transform(y[:500]), fa.transform(y[:500])) < 1e-9
 
 
-def test_sample_posterior_matches_reference_covariance():
-    """api.sample_posterior through the low-rank factor: mean and covariance of the draws equal the
-    reference's (K^-1 + W)^-1 (vlgp/api.py:156-166) to sampling error."""
-    import vlgp_amd
-
+def test_sample_posterior_lowrank_form_has_the_reference_covariance():
+    """The low-rank form of api.sample_posterior that the device kernel implements (oracle restatement):
+    G (I + G'WG)^-1 G' equals the reference's inv(inv(K + reg I) + W) (vlgp/api.py:156-166) up to reg."""
     rng = np.random.default_rng(0)
     T, L = 40, 2
     omega, sigma = np.array([4e-3, 2e-2]), np.array([1.0, 0.7])
     chol = O.build_prior([T], omega, sigma, 50)
-    trial = {"mu": rng.standard_normal((T, L)), "w": rng.random((T, L)) * 3.0}
-    n = 200000
-    draws = vlgp_amd.sample_posterior(trial, {"cholesky": chol}, n, rng=np.random.default_rng(1))
-    assert draws.shape == (n, T, L)
+    w = rng.random((T, L)) * 3.0
     for l in range(L):
         G = chol[T][l]
-        K = G @ G.T
-        want = np.linalg.inv(np.linalg.inv(K + 1e-6 * np.eye(T)) + np.diag(trial["w"][:, l]))
-        got = np.cov(draws[:, :, l].T)
-        assert np.abs(got - want).max() < 0.02 * np.abs(want).max() + 2e-3
-        assert np.abs(draws[:, :, l].mean(0) - trial["mu"][:, l]).max() < 0.01
+        r = int(np.flatnonzero(np.any(G != 0, axis=0))[-1]) + 1
+        Gl = G[:, :r]
+        H = Gl.T @ (w[:, [l]] * Gl)
+        cov = Gl @ np.linalg.solve(np.eye(r) + H, Gl.T)
+        want = O.posterior_covariance_reference(G, w[:, l])
+        assert np.abs(cov - want).max() < 1e-4 * np.abs(want).max()
+        # and the draws of the restatement have exactly that covariance: (G Lc^-T)(G Lc^-T)' = cov
+        eye = [np.eye(r) if k == l else np.zeros((int(np.flatnonzero(np.any(chol[T][k] != 0, axis=0))[-1]) + 1, r))
+               for k in range(L)]
+        dev = O.sample_posterior_lowrank(np.zeros((T, L)), w, chol[T], eye)[:, :, l].T  # columns: G Lc^-T e_i
+        assert np.abs(dev @ dev.T - cov).max() < 1e-12
 
 
 def test_save_load_round_trip(tmp_path):

@@ -62,6 +62,7 @@ _SIGNATURES = {
                                    C.c_double]),
     "vlgp_mstep_end": (C.c_int, [_h, _ip, _dp]),
     "vlgp_hstep_objective": (C.c_int, [_h, C.c_int, C.c_int, C.c_double, C.c_int, _ip, _dp, _dp, _dp]),
+    "vlgp_sample_posterior": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _ip]),
     "vlgp_comm_host_exchange": (C.c_int, [_h]),
     "vlgp_comm_transport": (C.c_int, [_h]),
     "vlgp_project_units": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),

@@ -67,6 +67,9 @@ class FitSession:
         self.comm = comm
         self.eng = None
         self.runtime = E.new_runtime()
+        # the reference leaves a writable np.ones((T, xdim, N)) in every trial that came without regressors
+        # (preprocess.py:43-44); the fit itself works on a zero-stride view, the real arrays are made on the way out
+        self.materialize_x = bool(kwargs.get("materialize_x", True))
 
         if echo:
             echo("Initializing")
@@ -150,6 +153,11 @@ class FitSession:
                 echo("Inferring")
             E.infer(self.dev_trials, params, config, echo=echo)
             self.dev_trials.pull()
+            if self.materialize_x:
+                for tr in self.trials:
+                    x = tr.get("x")
+                    if isinstance(x, np.ndarray) and not x.flags.writeable and x.size and all(st == 0 for st in x.strides):
+                        tr["x"] = np.ones(x.shape)
             if isinstance(params["cholesky"], E._LazyPrior):
                 params["cholesky"] = params["cholesky"].materialize()
             if echo:
@@ -170,7 +178,9 @@ def fit(trials, n_factors, device=0, comm=None, verbose=True, **kwargs):
     Same arguments as the reference: ``lik``, ``history``, ``a``, ``b``,
     ``noise``, ``sigma``, ``omega`` and every ``get_config`` key.  Extra:
     ``device`` (GPU index), ``comm`` (a :class:`vlgp_amd.dist.Comm` when the
-    trials are sharded over ranks), ``verbose``, ``ichol`` ("device"/"host").
+    trials are sharded over ranks), ``verbose``, ``ichol`` ("device"/"host": who builds the prior
+    factor -- both bit-identical to the reference's), ``materialize_x`` (default True: trials that came
+    without regressors get a writable ``np.ones((T, xdim, N))`` back, as the reference leaves them).
     """
     return FitSession(trials, n_factors, device=device, comm=comm, verbose=verbose, **kwargs).run().finish()
 
@@ -203,7 +213,7 @@ def transform(trials, params, config, device=0):
     return trials
 
 
-def sample_posterior(trial, params, nsamples, reg=1e-6, rng=None):
+def sample_posterior(trial, params, nsamples, reg=1e-6, rng=None, device=0):
     """Draw ``nsamples`` latent trajectories from the variational posterior of one trial
     (vlgp/api.py:142-168): independent Gaussians per latent with mean ``mu[:, l]`` and covariance
     ``(K_l^-1 + W_l)^-1``, ``K_l = G_l G_l'`` the low-rank prior of this trial length.
@@ -212,25 +222,33 @@ def sample_posterior(trial, params, nsamples, reg=1e-6, rng=None):
     ``multivariate_normal``'s SVD: O(T^3)).  With ``H = G'WG`` (r x r) the same covariance is
     ``G (I + H)^-1 G'`` (the reference's ``reg`` regulariser set to zero; it only exists to make
     ``K`` invertible), so a draw is ``mu + G L^-T eps`` with ``L L' = I + H`` and ``eps ~ N(0, I_r)``:
-    O(T r^2) per latent.  ``reg`` is accepted and ignored.  Draws come from ``rng`` (a
-    ``numpy.random.Generator``/``RandomState``) or, like the reference, the global NumPy state.
+    O(T r^2) per latent, computed on the GPU (``vlgp_sample_posterior``).  ``reg`` is accepted and ignored.
+    The standard normal draws come from ``rng`` (a ``numpy.random.Generator``/``RandomState``) or, like
+    the reference, the global NumPy state: ``(r_l, nsamples)`` values per latent, in latent order.
 
     Returns an array of shape (nsamples, bins, nfactors)."""
     del reg
-    mu = np.asarray(trial["mu"], dtype=float)
-    w = np.asarray(trial["w"], dtype=float)
+    mu = np.ascontiguousarray(trial["mu"], dtype=float)
+    w = np.ascontiguousarray(trial["w"], dtype=float)
     nbins, nfactors = mu.shape
-    G = np.asarray(params["cholesky"][nbins], dtype=float)
-    normal = (rng.standard_normal if hasattr(rng, "standard_normal") else np.random.standard_normal) \
-        if rng is not None else np.random.standard_normal
-    samples = np.empty((nsamples, nbins, nfactors))
+    G = np.ascontiguousarray(params["cholesky"][nbins], dtype=float)
+    R = G.shape[-1]
+    normal = (rng.standard_normal if hasattr(rng, "standard_normal") else rng.normal) if rng is not None \
+        else np.random.standard_normal
+    eps = np.zeros((nfactors, R, int(nsamples)))
     for l in range(nfactors):
-        Gl = G[l]
-        keep = np.any(Gl != 0.0, axis=0)  # columns ichol_gauss left at zero carry nothing
-        Gl = Gl[:, keep]
-        H = Gl.T @ (w[:, [l]] * Gl)
-        Lf = np.linalg.cholesky(np.eye(H.shape[0]) + H)
-        eps = normal((H.shape[0], nsamples))
-        dev = Gl @ np.linalg.solve(Lf.T, eps)  # cov = G (I + H)^-1 G'
-        samples[:, :, l] = mu[:, l][None, :] + dev.T
-    return samples
+        nz = np.flatnonzero(np.any(G[l] != 0.0, axis=0))  # columns ichol_gauss left at zero carry nothing
+        r = int(nz[-1]) + 1 if nz.size else 1
+        eps[l, :r] = normal((r, int(nsamples)))
+    out = np.empty((int(nsamples), nbins, nfactors))
+    import ctypes as C
+
+    from ._lib import dptr
+
+    with E.Engine(2, nfactors, 1, R, device=device) as eng:
+        bad = C.c_int(0)
+        eng._ck(eng.lib.vlgp_sample_posterior(eng.h, nbins, dptr(mu), dptr(w), dptr(G), int(nsamples), dptr(eps),
+                                              dptr(out), C.byref(bad)))
+        if bad.value:
+            logger.error("I + G'WG was not positive definite for %d latent(s): their draws equal the mean", bad.value)
+    return out

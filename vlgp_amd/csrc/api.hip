@@ -1111,6 +1111,30 @@ extern "C" int vlgp_project_units(vlgp_ctx* ctx, int set, const double* proj, co
     return VLGP_OK;
 }
 
+// ---- posterior draws -----------------------------------------------------------
+extern "C" int vlgp_sample_posterior(vlgp_ctx* ctx, int T, const double* mu, const double* w, const double* G, int nsamples,
+                                     const double* eps, double* out, int* n_failed) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    if (T < 1 || nsamples < 1 || !mu || !w || !G || !eps || !out) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad sample_posterior arguments");
+    const int L = ctx->L, R = ctx->R;
+    const int64_t n_mu = (int64_t)T * L, n_G = (int64_t)L * T * R, n_eps = (int64_t)L * R * nsamples;
+    const int64_t n_out = (int64_t)nsamples * T * L;
+    const int64_t o_mu = 0, o_w = o_mu + n_mu, o_G = o_w + n_mu, o_eps = o_G + n_G, o_z = o_eps + n_eps, o_out = o_z + n_eps;
+    CHK(vlgp_ensure_work(ctx, o_out + n_out));
+    double* W = ctx->d_work;
+    if (n_failed) *n_failed = 0;
+    CHK(begin_count(ctx));
+    HIPCHK(ctx, hipMemcpyAsync(W + o_mu, mu, sizeof(double) * n_mu, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(W + o_w, w, sizeof(double) * n_mu, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(W + o_G, G, sizeof(double) * n_G, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(W + o_eps, eps, sizeof(double) * n_eps, hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_sample_posterior(ctx, T, nsamples, W + o_mu, W + o_w, W + o_G, W + o_eps, W + o_z, W + o_out));
+    HIPCHK(ctx, hipMemcpyAsync(out, W + o_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return end_count(ctx, n_failed);
+}
+
 // ---- measurement -------------------------------------------------------------
 extern "C" int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const double* b, double* out) {
     NEED_CTX(ctx);

@@ -166,6 +166,8 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
 int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
                      bool in_table);
 int launch_compact_prior(vlgp_ctx* ctx, Prior& pr);  // host-injected d_full -> rl, d_compact
+int launch_sample_posterior(vlgp_ctx* ctx, int T, int n, const double* d_mu, const double* d_w, const double* d_G,
+                            const double* d_eps, double* d_z, double* d_out);
 int launch_npx_probe(vlgp_ctx* ctx, int kind, int64_t n, const double* d_a, const double* d_b, double* d_out);
 int launch_xb(vlgp_ctx* ctx, UnitSet& us);
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
