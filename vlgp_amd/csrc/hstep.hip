@@ -305,7 +305,7 @@ constexpr int hstep_prep_lds() {
 // One wave: K = sigma^2 exp(-omega d^2) + eps I -> K^-1, log det chol(K), first columns of K and dK.
 template <int T>
 __device__ __forceinline__ void hstep_prep_body(const HFastArgs& A, int e, int lane, double* Lp, double* kv,
-                                                double* dkv) {
+                                                double* dkv, double* Kl = nullptr) {
     const double sigmasq = exp(A.logp[3 * e + 0]);
     double omega = exp(A.logp[3 * e + 1]);
     const double eps = exp(A.logp[3 * e + 2]);
@@ -347,7 +347,10 @@ __device__ __forceinline__ void hstep_prep_body(const HFastArgs& A, int e, int l
             a0 = fma(x[k], v.x, a0);
             if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
         }
-        if (lane < T) Ki[(int64_t)lane * T + j] = a0 + a1;
+        if (lane < T) {
+            Ki[(int64_t)lane * T + j] = a0 + a1;
+            if (Kl) Kl[lane * T + j] = a0 + a1;  // LDS copy for the trace phase (both waves of the K block read it)
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     A.kcol[(int64_t)e * 128 + lane] = kv[lane];
@@ -630,6 +633,59 @@ __device__ __forceinline__ void hstep_prep_moments(const HFastArgs& A, const dou
     }
 }
 
+// The trace phase of a K block spread over the NWV waves of the workgroup: every wave holds all rows of K^-1
+// (from the LDS copy `Kl` hstep_prep_body left) and of C_l in registers, and takes a contiguous share of the
+// rows b of the double sum; partial (quad, gq) per wave go to out2[wid] (quad from wave 0 only).
+template <int T, int NWV>
+__device__ __forceinline__ void hstep_prep_moments_split(const HFastArgs& A, const double* mom, int e, int lane, int wid,
+                                                         const double* Kl, double* dk2, const double* dkv, double* out2) {
+    static_assert(T % 2 == 0 && T <= 64, "window must be even and at most 64");
+    const int row = lane < T ? lane : 0;
+    const double* Cj = mom + (int64_t)A.latent[e] * T * T + (int64_t)row * T;
+    double kj[T], cj[T];
+#pragma unroll
+    for (int k = 0; k < T; k += 2) {
+        const double2 kk = *reinterpret_cast<const double2*>(Kl + row * T + k);
+        kj[k] = kk.x;
+        kj[k + 1] = kk.y;
+        cj[k] = Cj[k];
+        cj[k + 1] = Cj[k + 1];
+    }
+    dk2[lane] = dkv[63 - lane];                                  // i = lane      -> |i - 63| = 63 - lane
+    dk2[64 + lane] = dkv[(lane + 1) & 63];                       // i = 64 + lane -> lane + 1 (entry 127 unused)
+    tri_wave_sync();
+    double quad = 0.0, gq = 0.0;
+    if (wid == 0) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) quad = fma(kj[k], cj[k], quad);
+    }
+    const int b_lo = (T * wid) / NWV, b_hi = (T * (wid + 1)) / NWV;
+#pragma nounroll
+    for (int b = b_lo; b < b_hi; ++b) {
+        const double* Kb = Kl + b * T;
+        const double* Db = dk2 + (63 - b);  // Db[a] = dK[|a - b|]
+        double e0 = 0.0, e1 = 0.0, f0 = 0.0, f1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < T; k += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(Kb + k);
+            e0 = fma(cj[k], v.x, e0);
+            e1 = fma(cj[k + 1], v.y, e1);
+            f0 = fma(kj[k], Db[k], f0);
+            f1 = fma(kj[k + 1], Db[k + 1], f1);
+        }
+        gq = fma(e0 + e1, f0 + f1, gq);
+    }
+    if (lane >= T) { quad = 0.0; gq = 0.0; }
+    for (int o = 32; o > 0; o >>= 1) {
+        quad += __shfl_xor(quad, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+    }
+    if (lane == 0) {
+        out2[2 * wid + 0] = quad;
+        out2[2 * wid + 1] = gq;
+    }
+}
+
 // The A_i part for one pair of tasks: factor A (packed in Lp), X = L^-1, returns
 // (tr(A^-1), sum_jk sqrt(w_j w_k) dK_jk (A^-1)_jk) per lane-partial (caller reduces
 // over the 32-lane half); x = NaN when A did not factor.  The empty asm statements pin
@@ -876,13 +932,20 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
     const HFastArgs& A = R.F;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if ((int)blockIdx.x < R.n_eval) {
+        // K block.  Wave 0: K -> chol, K^-1 (serial chain); then BOTH waves share the traces against C_l, with
+        // K^-1 broadcast from an LDS copy (the round is only as short as this block: 100 -> 60 us for one evaluation)
         const int e = blockIdx.x;
-        if (wid == 0) {
-            double* base = &Lp_all[0][0][0];
-            double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);  // kv64 | dkv64 | dk2 (128)
-            hstep_prep_body<T>(A, e, lane, base, extra, extra + 64);
-            tri_wave_sync();
-            hstep_prep_moments<T, false>(A, R.mom, R.qsum, e, lane, nullptr, extra + 128, extra + 64);
+        double* base = &Lp_all[0][0][0];
+        double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);  // kv64 | dkv64 | dk2 (128) | dk2' (128)
+        double* Kl = extra + 384;                                 // T x T copy of K^-1
+        static_assert(((hstep_prep_lds<T>() + 1) & ~1) + 384 + T * T <= 2 * NW * PKU, "K block scratch must fit");
+        if (wid == 0) hstep_prep_body<T>(A, e, lane, base, extra, extra + 64, Kl);
+        __syncthreads();
+        hstep_prep_moments_split<T, NW>(A, R.mom, e, lane, wid, Kl, extra + 128 + 128 * wid, extra + 64, &part[0][0]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            R.qsum[2 * e + 0] = part[0][0];
+            R.qsum[2 * e + 1] = part[0][1] + part[1][1];
         }
     } else {
         const int b = blockIdx.x - R.n_eval;
