@@ -17,6 +17,7 @@
 
 #include "ctx.h"
 #include "wave_tri.h"
+#include "hstep_mfma.h"
 
 #define HS_MAXT 128  // generic kernels: rows are lane-strided, one T x T matrix per wave in LDS
 
@@ -1116,6 +1117,133 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
     }
 }
 
+// The round on the matrix pipe (hstep_mfma.h): one wave per segment, NW waves per block.  Blocks [0, n_eval) are
+// the K blocks as in hstep_round_lean (all NW waves share the trace phase).
+template <int T, int NW>
+__global__ void __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) hstep_round_mfma(HRoundArgs R) {
+    using G = HmGeom<T>;
+    constexpr int KPREP = (hstep_prep_lds<T>() + 1) & ~1;
+    constexpr int KBLK = KPREP + 128 + 128 * NW + T * T;  // kv64 | dkv64 | dk2 per wave (128) | K^-1
+    constexpr int LDSN = NW * G::TASK > KBLK ? NW * G::TASK : KBLK;
+    __shared__ __attribute__((aligned(16))) double lds[LDSN];
+    __shared__ double part[NW][2];
+    __shared__ int s_last;
+    const HFastArgs& A = R.F;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if ((int)blockIdx.x < R.n_eval) {
+        const int e = blockIdx.x;
+        double* extra = lds + KPREP;
+        double* Kl = extra + 128 + 128 * NW;
+        if (wid == 0) hstep_prep_body<T>(A, e, lane, lds, extra, extra + 64, Kl);
+        __syncthreads();
+        hstep_prep_moments_split<T, NW>(A, R.mom, e, lane, wid, Kl, extra + 128 + 128 * wid, extra + 64, &part[0][0]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double gq = part[0][1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) gq += part[w][1];
+            R.qsum[2 * e + 0] = part[0][0];
+            R.qsum[2 * e + 1] = gq;
+        }
+    } else {
+        const int b = blockIdx.x - R.n_eval;
+        const int e = b / R.nb, bx = b - e * R.nb;
+        const int seg = bx * NW + wid;
+        double tr = 0.0, cs = 0.0;
+        if (seg < A.M) {
+            double* buf = lds + wid * G::TASK;
+            const int l = A.latent[e];
+            const int64_t r0row = A.off[seg];
+            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
+            {
+                const double w = lane < A.Tr ? A.w[(r0row + lane) * A.L + l] : 0.0;  // rows >= Tr: identity padding
+                const double d = lane * A.dt, d2 = d * d;
+                const double kk = sigmasq * exp(-omega * d2);
+                buf[G::O_SV + lane] = sqrt(w);
+                buf[G::O_KVM + 63 + lane] = kk;
+                buf[G::O_KVM + 63 - lane] = kk;
+                buf[G::O_DKV + lane] = -kk * d2 * omega;
+            }
+            tri_wave_sync();
+            const bool ok = hstep_task_mfma<T>(buf, eps, lane, tr, cs);
+            if (!ok) { tr = nan(""); cs = nan(""); }  // failed factorisation: propagates into ll, dll
+            for (int o = 32; o > 0; o >>= 1) {
+                tr += __shfl_xor(tr, o, 64);
+                cs += __shfl_xor(cs, o, 64);
+            }
+            tr -= (double)(T - A.Tr);  // the identity padding's share of tr(A^-1)
+        }
+        if (lane == 0) {
+            part[wid][0] = tr;
+            part[wid][1] = cs;
+        }
+    }
+    // ---- completion: one partial per block, then the last block reduces and publishes ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if ((int)blockIdx.x >= R.n_eval) {
+            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
+            double t0 = part[0][0], t1 = part[0][1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                t0 += part[w][0];
+                t1 += part[w][1];
+            }
+            o[0] = t0;
+            o[1] = t1;
+        }
+        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    constexpr int NT = 64 * NW;
+    double* rs = lds;  // 2 x NT partials
+    for (int e = 0; e < R.n_eval; ++e) {
+        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int m = threadIdx.x; m < R.nb; m += NT) {
+            const double2 v = in[m];
+            s0 += v.x;
+            s1 += v.y;
+        }
+        __syncthreads();
+        rs[threadIdx.x] = s0;
+        rs[NT + threadIdx.x] = s1;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                rs[threadIdx.x] += rs[threadIdx.x + o];
+                rs[NT + threadIdx.x] += rs[NT + threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double okf = A.scal[4 * e + 3];
+            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
+            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[NT]);
+            R.red[2 * e + 0] = ll;
+            R.red[2 * e + 1] = dll;
+            R.red[2 * R.n_eval + e] = okf;
+            if (R.host) {
+                R.host[2 * e + 0] = ll;
+                R.host[2 * e + 1] = dll;
+                R.host[2 * R.n_eval + e] = okf;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        R.sync[16] = 0;  // next launch is stream-ordered after this one
+        if (R.host) {
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int T>
 static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
     hipLaunchKernelGGL((hstep_prep_fast<T>), dim3(n_eval), dim3(64), 0, ctx->stream, F);
@@ -1195,7 +1323,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             }
             HRoundArgs R;
             R.F = F;
-            R.n_eval = n_eval; R.nb = (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
+            constexpr int MFMA_NW = 4;  // waves (= segments) per block of the matrix-pipe round kernel
+            const bool padded = T == 50 && getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
+            const bool lean = getenv("VLGP_HSTEP_LEAN") != nullptr;                 // register-row kernel (round 1)
+            const bool mfma = !padded && !lean;
+            R.n_eval = n_eval; R.nb = mfma ? (M + MFMA_NW - 1) / MFMA_NW : (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
             // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
@@ -1204,11 +1336,13 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool mailbox = ctx->world == 1 || ctx->hx != nullptr;
             R.host = mailbox ? ctx->d_hres : nullptr;
             vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-            const bool padded = T == 50 && getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
             if (padded)
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
-            else
+            else if (lean)
                 hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
+            else
+                hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
+                                   ctx->stream, R);
             vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
             HIPCHK(ctx, hipGetLastError());
             if (mailbox) {

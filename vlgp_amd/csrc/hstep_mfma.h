@@ -1,0 +1,338 @@
+// H-step objective, per-segment part, on the matrix pipe (gfx950, v_mfma_f64_16x16x4).
+//
+// One wavefront = one segment.  For A = I + S K S (S = diag sqrt(w), eigenvalues >= 1) the round needs
+//     tr(A^-1)   and   sum_jk s_j s_k dK_jk (A^-1)_jk            (see hstep.hip, "Fast path")
+// i.e. a weighted sum over ALL entries of A^-1: O(T^3) whatever the algebra.  The register-resident row
+// kernels (wave_tri.h) spend one LDS broadcast per two FMAs and leave half of the lanes idle in every
+// triangular loop (measured: 10 % of the fp64 peak, latency- and LDS-bound).  Here the cubic work runs as
+// 16 x 16 x 4 matrix instructions on 16-row blocks and only the panel factorisations stay on the vector pipe:
+//
+//   * right-looking blocked Cholesky of the matrix AUGMENTED with identity rows, [A; I] -> [L; L^-T]:
+//     the same panel elimination that turns the rows of A into rows of L turns the unit rows into rows
+//     of X' = L^-T, so the triangular inverse costs no separate sweep and no diagonal-block inverse.
+//   * the Schur complements are never stored: N = sum_k L_:k L_:k' (for A) and M = sum_k X'_:k L_:k' (for
+//     X') accumulate in MFMA result registers and are subtracted from the freshly generated entries of A
+//     (Toeplitz first column from a small LDS table) when their panel comes up.
+//   * A^-1 = X'X accumulates panel by panel as well (P += X'_:k X'_:k'), so nothing but the current
+//     panel ever sits in LDS: 66 rows of 18 doubles per segment.
+//   * panel factorisation: every lane holds one row of the panel in registers (two register sets: rows of
+//     A, rows of X'); pivot and multipliers are wave-uniform v_readlane broadcasts from the lanes that
+//     hold the diagonal block.
+//   * T = 16 NB + E (50 = 3 x 16 + 2): the matrix instructions see NB x NB blocks only.  The last E rows and
+//     columns ("tail") never enter a 16 x 16 block: the last panel is 16 + E columns wide, and the tail's
+//     Schur terms (two columns of N and M) and its two columns of A^-1 are dot products in the one-row-per-
+//     lane layout -- a handful of vector FMAs instead of a fourth, almost empty, block row (130 -> 78 MFMA).
+//
+// fp64 MFMA and fp64 vector FMA share the SIMD's double-precision units on gfx950 (tools/mfma_f64_bench.hip:
+// a wave of back-to-back MFMAs leaves a co-resident wave one v_fma_f64 per 37 cycles), so the two kinds of
+// work add up rather than overlap; what more waves per SIMD hide is the latency of the 50 dependent pivots.
+//
+// Layouts (v_mfma_f64_16x16x4, cdna_hip_programming.md 3): operand lane (r = lane & 15, g = lane >> 4)
+// holds M[r][4 kk + g] for chunk kk -- the SAME registers serve as the A operand for M and as the B
+// operand for M'; result register p of lane (c = lane & 15, g) holds D[g + 4 p][c].
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_tri.h"
+
+typedef double hm_d4 __attribute__((ext_vector_type(4)));
+
+template <int TP>
+struct HmGeom {
+    static constexpr int NB = TP / 16;        // 16-row blocks seen by the matrix pipe
+    static constexpr int E = TP - 16 * NB;    // tail rows / columns
+    static constexpr int WL = 16 + E;         // width of the last panel
+    static_assert(NB >= 2 && NB <= 4 && E <= 8, "compiled window must be 16 NB + E, NB = 2..4, E <= 8");
+    static constexpr int LDB = WL <= 18 ? 18 : (WL <= 22 ? 22 : 26);  // row stride: 2 mod 4 -> operand reads conflict-free
+    static constexpr int ROWS = 16 * NB + 16 + E;  // rows of A at / below panel k (16 (NB - k) + E) + block rows of X' (16 (k + 1))
+    static constexpr int O_SV = ROWS * LDB;    // sqrt(w), 64
+    static constexpr int O_KVM = O_SV + 64;    // kvm[63 + d] = first column of K at |d|, d = -63..63
+    static constexpr int O_DKV = O_KVM + 128;  // first column of dK / dln omega, 64
+    static constexpr int O_NT = O_DKV + 64;    // ntail[E][64]: columns 16 NB + t of N
+    static constexpr int TASK = O_NT + (E > 0 ? E : 1) * 64;
+    __host__ __device__ static constexpr int width(int k) { return k == NB - 1 ? WL : 16; }
+    __host__ __device__ static constexpr int chunks(int k) { return (width(k) + 3) / 4; }
+};
+
+__device__ __forceinline__ double hm_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-d * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    return y;
+}
+
+// buf: TASK doubles of LDS owned by this wave; on entry the tables at O_SV, O_KVM, O_DKV are filled (sqrt(w) zero
+// beyond the rows present).  A pivot of A that is not positive and finite makes tr and cs NaN.  tr = tr(A^-1) over all
+// TP rows (the caller subtracts the identity padding's share), cs = sum_jk s_j s_k dK_jk (A^-1)_jk; both
+// per-lane partials.
+template <int TP>
+__device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lane, double& tr, double& cs) {
+    using G = HmGeom<TP>;
+    constexpr int NB = G::NB, E = G::E, LDB = G::LDB, WL = G::WL, TB = 16 * NB;
+    const double* sv = buf + G::O_SV;
+    const double* kvm = buf + G::O_KVM;
+    const double* dkv = buf + G::O_DKV;
+    double* ntail = buf + G::O_NT;
+    const int c = lane & 15, g = lane >> 4;
+    hm_d4 N[NB][NB], M[NB][NB], P[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            N[i][j] = hm_d4{0.0, 0.0, 0.0, 0.0};
+            M[i][j] = hm_d4{0.0, 0.0, 0.0, 0.0};
+            P[i][j] = hm_d4{0.0, 0.0, 0.0, 0.0};
+        }
+    double mt[E > 0 ? E : 1];  // columns 16 NB + t of M, lane <-> row of X'
+#pragma unroll
+    for (int t = 0; t < (E > 0 ? E : 1); ++t) mt[t] = 0.0;
+    double ra[WL], rx[WL];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int col0 = 16 * k;
+        const int W = G::width(k);
+        const bool last = k == NB - 1;
+        const int rowsA = TP - col0;             // rows of A at and below the diagonal block (lane <-> row col0 + lane)
+        const int nX = last ? TP : 16 * (k + 1);  // rows of X' with entries in this panel (lane <-> row)
+        double* bufA = buf;
+        double* bufX = buf + (TP - col0) * LDB;
+        // ---- 1. Schur terms of this panel from the result registers -> LDS ----
+        if (k > 0) {
+#pragma unroll
+            for (int bi = k; bi < NB; ++bi)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) bufA[(16 * (bi - k) + g + 4 * p) * LDB + c] = N[bi][k][p];
+#pragma unroll
+            for (int i = 0; i < k; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) bufX[(16 * i + g + 4 * p) * LDB + c] = M[i][k][p];
+            tri_wave_sync();
+        }
+        // ---- 2. one row per lane: ra = row (col0 + lane) of A - N, rx = row `lane` of I - M ----
+        {
+            const int i = col0 + lane;
+            const double si = sv[i < 64 ? i : 63];
+            // row of N: block rows from bufA, tail rows from ntail (N is symmetric)
+            const double* pn = (E > 0 && i >= TB) ? ntail + (i - TB < E ? i - TB : 0) * 64 + col0
+                                                  : bufA + (lane < TB - col0 ? lane : 0) * LDB;
+            const double* pm = bufX + (lane < col0 ? lane : 0) * LDB;
+            const double* pk = kvm + 63 + lane;  // kvm[63 + lane - q] = K0[|i - (col0 + q)|]
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const double2 sj = *reinterpret_cast<const double2*>(sv + col0 + q);
+                double2 nv = double2{0.0, 0.0}, mv = double2{0.0, 0.0};
+                if (k > 0) {
+                    nv = *reinterpret_cast<const double2*>(pn + q);
+                    mv = *reinterpret_cast<const double2*>(pm + q);
+                }
+                const double a0 = (si * sj.x) * pk[-q], a1 = (si * sj.y) * pk[-q - 1];
+                ra[q] = (lane == q ? fma(si * sj.x, eps, 1.0) : 0.0) + a0 - nv.x;
+                ra[q + 1] = (lane == q + 1 ? fma(si * sj.y, eps, 1.0) : 0.0) + a1 - nv.y;
+                rx[q] = (lane == col0 + q ? 1.0 : 0.0) - (lane < col0 ? mv.x : 0.0);
+                rx[q + 1] = (lane == col0 + q + 1 ? 1.0 : 0.0) - (lane < col0 ? mv.y : 0.0);
+            }
+            if (last) {
+#pragma unroll
+                for (int t = 0; t < E; ++t) {  // tail columns: N from ntail[t][row], M from mt[t]
+                    const double sj = sv[TB + t];
+                    const double nv = ntail[t * 64 + (i < 64 ? i : 63)];
+                    ra[16 + t] = (lane == 16 + t ? fma(si * sj, eps, 1.0) : 0.0) + (si * sj) * pk[-16 - t] - nv;
+                    rx[16 + t] = (lane == TB + t ? 1.0 : 0.0) - mt[t];
+                }
+            }
+        }
+        // pin the panel entries here: left alone, the compiler sinks their assembly into the elimination steps
+        // and keeps every loaded table value alive across them (measured: 530 spilled VGPRs)
+#pragma unroll
+        for (int q = 0; q < WL; ++q)
+            if (q < W) asm volatile("" : "+v"(ra[q]), "+v"(rx[q]));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. elimination of the panel.  Column j takes the updates of columns m <= j - 2 "lazily", one step
+        // ahead and with multipliers L[j][m] broadcast from an LDS copy of the diagonal block (they are final by
+        // then, so the LDS round trip is off the pivot chain); only the last update (m = j - 1) and the pivot
+        // itself are v_readlane broadcasts.
+        {
+            double* Ld = buf;  // rows of the diagonal block (lanes < W), stride LDD; the panel buffer is free meanwhile
+            constexpr int LDD = (WL + 1) & ~1;
+#pragma unroll
+            for (int j = 0; j < WL; ++j) {
+                if (j < W) {
+                    if (j > 0) {
+                        const double lv = tri_readlane(ra[j - 1], j);
+                        ra[j] = fma(-ra[j - 1], lv, ra[j]);
+                        rx[j] = fma(-rx[j - 1], lv, rx[j]);
+                    }
+                    const double d = tri_readlane(ra[j], j);
+                    double y = __builtin_amdgcn_rsq(d);
+                    if (j + 1 < W && j >= 1) {  // column j + 1 <- columns 0 .. j - 1
+                        const double* row = Ld + (j + 1) * LDD;
+                        double a0 = ra[j + 1], a1 = 0.0, x0 = rx[j + 1], x1 = 0.0;
+#pragma unroll
+                        for (int m = 0; m + 1 < j; m += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(row + m);
+                            a0 = fma(-ra[m], v.x, a0);
+                            a1 = fma(-ra[m + 1], v.y, a1);
+                            x0 = fma(-rx[m], v.x, x0);
+                            x1 = fma(-rx[m + 1], v.y, x1);
+                        }
+                        if (j & 1) {
+                            const double v = row[j - 1];
+                            a0 = fma(-ra[j - 1], v, a0);
+                            x0 = fma(-rx[j - 1], v, x0);
+                        }
+                        ra[j + 1] = a0 + a1;
+                        rx[j + 1] = x0 + x1;
+                        // evaluate the X' half HERE: unpinned, the compiler sinks the whole rx chain below the panel
+                        // and carries every multiplier to it through scratch
+                        asm volatile("" : "+v"(ra[j + 1]), "+v"(rx[j + 1]));
+                    }
+                    double e = fma(-d * y, y, 1.0);
+                    y = fma(y * 0.5, e, y);
+                    e = fma(-d * y, y, 1.0);
+                    y = fma(y * 0.5, e, y);
+                    ra[j] *= y;
+                    rx[j] *= y;
+                    asm volatile("" : "+v"(ra[j]), "+v"(rx[j]));
+                    if (j + 1 < W) {
+                        if (lane < W) Ld[lane * LDD + j] = ra[j];
+                        tri_wave_order();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- 4. finished rows back to LDS (block rows for the operands, tail rows for the dot products) ----
+        if (!last && lane >= 16 && lane < rowsA) {
+            double* pa = bufA + lane * LDB;
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) *reinterpret_cast<double2*>(pa + q) = double2{ra[q], ra[q + 1]};
+        }
+        if (lane < (nX < TB ? nX : TB)) {
+            double* px = bufX + lane * LDB;
+#pragma unroll
+            for (int q = 0; q + 1 < WL; q += 2)
+                if (q < W) *reinterpret_cast<double2*>(px + q) = double2{rx[q], rx[q + 1]};
+        }
+        tri_wave_sync();
+        // ---- 5. tail columns of the Schur terms: dot products with the tail rows of L (broadcast from LDS) ----
+        if (!last && E > 0) {
+#pragma unroll
+            for (int t = 0; t < E; ++t) {
+                const double* lt = bufA + (TB + t - col0) * LDB;
+                double n0 = 0.0, n1 = 0.0, m0 = 0.0, m1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    const double2 l2 = *reinterpret_cast<const double2*>(lt + q);
+                    n0 = fma(ra[q], l2.x, n0);
+                    n1 = fma(ra[q + 1], l2.y, n1);
+                    m0 = fma(rx[q], l2.x, m0);
+                    m1 = fma(rx[q + 1], l2.y, m1);
+                }
+                mt[t] += (lane < nX) ? m0 + m1 : 0.0;
+                if (lane >= 16 && lane < rowsA) {
+                    double* pn = ntail + t * 64 + col0 + lane;
+                    *pn = (k > 0 ? *pn : 0.0) + (n0 + n1);
+                }
+            }
+        }
+        constexpr int MAXCH = (WL + 3) / 4;
+        double opL[NB][4], opX[NB][MAXCH];
+        const int nch = G::chunks(k);
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) opL[bi][kk] = (bi > k) ? bufA[(16 * (bi - k) + c) * LDB + 4 * kk + g] : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < MAXCH; ++kk) {
+                opX[bi][kk] = 0.0;
+                if (bi <= k && kk < nch) {
+                    if (4 * kk + 4 <= W) {
+                        opX[bi][kk] = bufX[(16 * bi + c) * LDB + 4 * kk + g];
+                    } else {  // last chunk of the wide panel: columns beyond W are zero
+                        const bool in = 4 * kk + g < W;
+                        const double v = bufX[(16 * bi + c) * LDB + (in ? 4 * kk + g : 0)];
+                        opX[bi][kk] = in ? v : 0.0;
+                    }
+                }
+            }
+        }
+        tri_wave_order();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 6. rank-W updates on the matrix pipe; what the next panel needs goes first ----
+        if (!last) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int bi = k + 1; bi < NB; ++bi)
+                    N[bi][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[k + 1][kk], N[bi][k + 1], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i <= k; ++i)
+                    M[i][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[k + 1][kk], M[i][k + 1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int bj = k + 2; bj < NB; ++bj) {
+#pragma unroll
+                    for (int bi = bj; bi < NB; ++bi)
+                        N[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[bj][kk], N[bi][bj], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i <= k; ++i)
+                        M[i][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[bj][kk], M[i][bj], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < MAXCH; ++kk) {
+            if (kk < nch) {
+#pragma unroll
+                for (int i = 0; i <= k; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j)
+                        P[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opX[j][kk], P[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- weighted sums over A^-1: block part from P (lower blocks; off-diagonal blocks count twice) ----
+    tr = 0.0;
+    cs = 0.0;
+    double cd = 0.0;
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj) {
+        const double sj = sv[16 * bj + c];
+#pragma unroll
+        for (int bi = bj; bi < NB; ++bi) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int il = g + 4 * p;
+                const int i = 16 * bi + il;
+                const int dd = i - (16 * bj + c);
+                const double wgt = (sv[i] * sj) * dkv[dd < 0 ? -dd : dd];
+                if (bi == bj) {
+                    cd = fma(P[bi][bj][p], wgt, cd);
+                    tr += (il == c) ? P[bi][bj][p] : 0.0;
+                } else {
+                    cs = fma(P[bi][bj][p], wgt, cs);
+                }
+            }
+        }
+    }
+    // ---- tail columns of A^-1 in the row-per-lane layout (rx = rows of X' after the last panel) ----
+    if (E > 0) {
+        const double si = sv[lane];
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            double p = 0.0;  // (A^-1)[lane][TB + t] = sum_{u >= t} X'[lane][TB + u] X'[TB + t][TB + u]
+#pragma unroll
+            for (int u = t; u < E; ++u) p = fma(rx[16 + u], tri_readlane(rx[16 + u], TB + t), p);
+            const int dd = TB + t - lane;
+            const double wgt = (si * sv[TB + t]) * dkv[dd > 0 ? dd : 0];
+            if (lane < TB + t) cs = fma(p, wgt, cs);
+            if (lane == TB + t) tr += p;
+        }
+    }
+    cs = fma(2.0, cs, cd);
+    return true;  // a pivot that is not positive and finite turns tr and cs into NaN (the caller checks)
+}
