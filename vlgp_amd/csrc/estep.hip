@@ -460,6 +460,13 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.cols_g = nullptr; A.wconst_g = nullptr;
     A.lds_T = us.Tmax; A.lds_gsz = (int)gsz; A.lds_lcsz = (int)lcsz;
 
+    // SPLIT: many short units -> chip-wide launches per phase (estep_split.hip); declines for small sets
+    {
+        int handled = 0;
+        CHK(launch_estep_split(ctx, us, A, &handled));
+        if (handled) return VLGP_OK;
+    }
+
     // FAST: register-resident factorisations (estep_fast.hip); declines when it does not apply
     {
         int handled = 0;

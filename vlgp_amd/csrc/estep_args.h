@@ -43,3 +43,7 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);
 // estep_long.hip: long units (T > 64) with every wave of the workgroup on the per-latent phases;
 // declines (leaves *handled = 0) when rank > 50, L > 10 or the LDS budget does not fit.
 int launch_estep_long(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);
+
+// estep_split.hip: many window-sized units as a sequence of chip-wide launches (passes over rows, one wave per
+// (unit, latent) for the factor and mean phases); declines for small sets, T > 64, rank > 32 or L > 8.
+int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);

@@ -1,0 +1,636 @@
+// E-step for many window-sized units (T <= 64, effective rank <= 32) as a SEQUENCE of chip-wide launches
+// instead of one persistent workgroup per unit (estep_fast.hip).
+//
+// Same mathematics, phase order and per-(unit, latent) arithmetic as estep_fast.hip / estep.hip (reference
+// vlgp/core.py:22-120): per sweep  residual pass -> mean update -> curvature pass -> factor (+ variance).
+// Why split: inside one workgroup the four phases have opposite shapes -- the (T x N) passes want every lane on
+// a time bin and no synchronisation, the per-latent phases are chains of dependent 16-wide steps that only
+// many independent waves per SIMD can hide -- and the persistent form ties them together with barriers
+// (measured: 40 k CU-cycles per unit-sweep against ~12 k of issued work, VALU 45 % busy).  Between launches the
+// unit state (mu, v, w, residual projections: 8 MB each at 200 x 1000 x 5) makes a round trip through L2 /
+// Infinity Cache, which costs less than the barriers did; a dependent launch boundary is ~1.5 us.
+//
+//   esplit_pass<KIND>   lane <-> ROW of the packed unit set (any unit: rows are independent in the passes), all
+//                       N channels in sequence per lane: no cross-lane or cross-wave reduction, no LDS, 64 of 64
+//                       lanes busy whatever the unit length.  Channel records (a_l, a_l^2, b, 1/noise, id),
+//                       Poisson channels first, are wave-uniform scalar loads, the next record in flight while
+//                       the current one is consumed.
+//   esplit_factor       one wave per (unit, latent): I + G'WG on the matrix pipe, factor + inverse in registers
+//                       (rank <= 16) or through LDS (rank <= 32), variance update; X goes to global memory.
+//   esplit_mean         one wave per (unit, latent): Newton step on the posterior mean through X.
+//                       Each wave takes the code path of ITS latent's rank: one latent above 16 no longer moves
+//                       the whole launch to the slow instantiation.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "estep_args.h"
+#include "wave_tri.h"
+#include "fast_exp.h"
+
+namespace {
+
+enum { SP_YA = 0, SP_RES = 1, SP_W = 2 };
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct SplitArgs {
+    int N, L, M;
+    int64_t rows;
+    const int64_t* off;
+    const int* unit_prior;
+    const double* const* prior_base;
+    const int* prior_rl;
+    const int64_t* prior_goff;
+    const double* y;
+    const double* xb;
+    double *mu, *v, *w, *dmu;
+    double *ra, *ya;   // (rows, L)
+    double* xg;        // (M L, pkg): packed X = chol(I + G'WG)^-1 per (unit, latent)
+    int pkg;
+    int* failg;        // (M L): 1 = the factor of this (unit, latent) failed
+    int* fail;
+    const double* wconst;
+    double dmu_bound;
+    int np, ntot;      // Poisson channels, all channels
+    int lds_g;         // doubles of LDS per wave for the G tile
+    int do_v, last;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// channel records, Poisson channels first: a[LT] | a^2[LT] | b | c (1/noise or 1) | id (integer bits) | pad
+template <int LT>
+constexpr int rec_len() { return (2 * LT + 3 + 1) & ~1; }
+
+__global__ void __launch_bounds__(256)
+esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double* b, const double* noise, const int* gauss,
+                   double* cols, double* wconst) {
+    __shared__ int order[1024];
+    __shared__ int s_np;
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int n = 0; n < N; ++n)
+            if (!gauss[n]) order[k++] = n;
+        s_np = k;
+        for (int n = 0; n < N; ++n)
+            if (gauss[n]) order[k++] = n;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const int n = order[i];
+        double* rec = cols + (int64_t)i * REC;
+        for (int l = 0; l < LT; ++l) {
+            const double av = l < L ? a[l * N + n] : 0.0;
+            rec[l] = av;
+            rec[LT + l] = av * av;
+        }
+        rec[2 * LT] = b[n];
+        rec[2 * LT + 1] = gauss[n] ? 1.0 / noise[n] : 1.0;
+        rec[2 * LT + 2] = __longlong_as_double((long long)n);  // channel id, read back as an integer
+    }
+    if ((int)threadIdx.x < L) {  // w = U (a')^2 with U = 1/noise on Gaussian channels (core.py:103-104)
+        double s = 0.0;
+        for (int n = 0; n < N; ++n)
+            if (gauss[n]) s = fma(a[threadIdx.x * N + n] * a[threadIdx.x * N + n], 1.0 / noise[n], s);
+        wconst[threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int LT, int KIND, bool HASXB>
+__global__ void __launch_bounds__(256)
+esplit_pass(SplitArgs A, const double* __restrict__ cols) {
+    constexpr int REC = rec_len<LT>();
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = row < A.rows;
+    const int64_t rr = in ? row : 0;
+    const int N = A.N, L = A.L;
+    double mr[LT], vr[LT], acc[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        const bool use = l < L && KIND != SP_YA;
+        mr[l] = use ? A.mu[rr * L + l] : 0.0;
+        vr[l] = use ? A.v[rr * L + l] : 0.0;
+        acc[l] = 0.0;
+    }
+    const double* yrow = A.y + rr * N;
+    const double* xbrow = HASXB ? A.xb + rr * N : nullptr;
+    auto load_rec = [&](int i, double (&rv)[REC]) {
+        const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)i * REC);
+#pragma unroll
+        for (int q = 0; q < REC / 2; ++q) {
+            const double2 t2 = rp[q];
+            rv[2 * q] = t2.x;
+            rv[2 * q + 1] = t2.y;
+        }
+    };
+    const int np = A.np, ntot = A.ntot;
+    if constexpr (KIND == SP_YA) {
+        auto body = [&](const double (&rv)[REC]) {
+            const int n = (int)__double_as_longlong(rv[2 * LT + 2]);
+            const double yc = yrow[n] * rv[2 * LT + 1];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) acc[l] = fma(yc, rv[l], acc[l]);
+        };
+        double ra_[REC], rb_[REC];
+        load_rec(0, ra_);
+        int i = 0;
+        for (; i + 1 < ntot; i += 2) {
+            load_rec(i + 1, rb_);
+            body(ra_);
+            load_rec(i + 2 < ntot ? i + 2 : i + 1, ra_);
+            body(rb_);
+        }
+        if (i < ntot) body(ra_);
+    } else {
+        // one Poisson channel: rate = exp(min(eta + v.a^2/2, 10)) (math.trunc_exp, vlgp/math.py:24-38)
+        auto poisson = [&](const double (&rv)[REC]) {
+            double eta = HASXB ? xbrow[(int)__double_as_longlong(rv[2 * LT + 2])] : rv[2 * LT];
+            double lin = 0.0;
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                eta = fma(mr[l], rv[l], eta);
+                lin = fma(vr[l], rv[LT + l], lin);
+            }
+            const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+#pragma unroll
+            for (int l = 0; l < LT; ++l) acc[l] = fma(rate, rv[KIND == SP_RES ? l : LT + l], acc[l]);
+        };
+        double ra_[REC], rb_[REC];
+        if (np > 0) {
+            load_rec(0, ra_);
+            int i = 0;
+            for (; i + 1 < np; i += 2) {
+                load_rec(i + 1, rb_);
+                poisson(ra_);
+                load_rec(i + 2 < np ? i + 2 : i + 1, ra_);
+                poisson(rb_);
+            }
+            if (i < np) poisson(ra_);
+        }
+        if constexpr (KIND == SP_RES) {  // Gaussian channels: the residual mean is eta itself
+            for (int i = np; i < ntot; ++i) {
+                load_rec(i, ra_);
+                double eta = HASXB ? xbrow[(int)__double_as_longlong(ra_[2 * LT + 2])] : ra_[2 * LT];
+#pragma unroll
+                for (int l = 0; l < LT; ++l) eta = fma(mr[l], ra_[l], eta);
+                const double mval = eta * ra_[2 * LT + 1];
+#pragma unroll
+                for (int l = 0; l < LT; ++l) acc[l] = fma(mval, ra_[l], acc[l]);
+            }
+        }
+    }
+    if (in) {
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            if (l < L) {
+                if constexpr (KIND == SP_YA) A.ya[row * L + l] = acc[l];
+                else if constexpr (KIND == SP_RES) A.ra[row * L + l] = A.ya[row * L + l] - acc[l];
+                else A.w[row * L + l] = acc[l] + A.wconst[l];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-wave view of one (unit, latent) task
+struct Task {
+    int m, l, T, r, rs;
+    int64_t r0;
+    double* Gl;    // LDS: (T, rs) compact prior factor, zero-padded odd column
+    double* Xl;    // LDS: packed X
+    double* vec;   // LDS: 128 doubles
+    double* u;     // LDS: 64 doubles
+    double* tile;  // LDS: 256 doubles
+};
+
+__device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int pk_max, int lane) {
+    const int wid = threadIdx.x >> 6;
+    const int task = blockIdx.x * (blockDim.x >> 6) + wid;
+    if (task >= A.M * A.L) return false;
+    K.m = task / A.L;
+    K.l = task - K.m * A.L;
+    K.r0 = A.off[K.m];
+    K.T = (int)(A.off[K.m + 1] - K.r0);
+    const int pidx = A.unit_prior[K.m];
+    K.r = __builtin_amdgcn_readfirstlane(A.prior_rl[pidx * A.L + K.l]);
+    K.rs = (K.r + 1) & ~1;
+    K.Gl = lds_wave;
+    K.Xl = lds_wave + A.lds_g;
+    K.vec = K.Xl + pk_max;
+    K.u = K.vec + 128;
+    K.tile = K.u + 64;
+    const double* src = A.prior_base[pidx] + A.prior_goff[pidx * A.L + K.l];
+    const int n = K.T * K.rs, r = K.r, rs = K.rs;
+    for (int i = lane; i < n; i += 64) {
+        const int t = i / rs, c = i - t * rs;
+        K.Gl[i] = c < r ? src[t * r + c] : 0.0;
+    }
+    tri_wave_sync();
+    return true;
+}
+
+// factor I + G'WG, invert, optionally refresh v (estep_fast.hip factor_phase, one latent)
+template <int RP, int RA>
+__device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, int lane) {
+    const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
+    const double* Gl = K.Gl;
+    double* Xl = K.Xl;
+    const double* w_s = A.w + K.r0 * L;
+    double* v_s = A.v + K.r0 * L;
+    const int j = lane & (RP - 1);
+    bool ok;
+    const int col = lane & 15, kq = lane >> 4;
+    if constexpr (RP <= 16) {
+        double4_t c = {0.0, 0.0, 0.0, 0.0};
+        const bool cin = col < rs;
+        for (int t0 = 0; t0 < T; t0 += 4) {
+            const int t = t0 + kq;
+            double g = 0.0, wg = 0.0;
+            if (cin && t < T) {
+                g = Gl[t * rs + col];
+                wg = w_s[t * L + l] * g;
+            }
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
+        }
+        double* ht = K.tile;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ht[(kq + 4 * q) * 16 + col] = c[q];
+        tri_wave_sync();
+        double a[RP];
+#pragma unroll
+        for (int i = 0; i < RP; i += 2) {
+            const double2 h2 = *reinterpret_cast<const double2*>(ht + j * 16 + i);
+            a[i] = h2.x + (i == j ? 1.0 : 0.0);
+            a[i + 1] = h2.y + (i + 1 == j ? 1.0 : 0.0);
+        }
+        double x[RP];
+        ok = wave_chol_inv_regs<RP>(a, x, j, r);
+        if (lane < RP) {  // X row-major packed in LDS for the solves: X[i][c], i >= c
+#pragma unroll
+            for (int i = 0; i < RP; ++i)
+                if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
+        }
+    } else {
+#pragma unroll
+        for (int tile = 0; tile < 3; ++tile) {  // lower block triangle of the 32 x 32 matrix
+            const int bi = tile == 0 ? 0 : 1, bj = tile == 2 ? 1 : 0;
+            const int ca = 16 * bi + col, cb = 16 * bj + col;
+            double4_t c = {0.0, 0.0, 0.0, 0.0};
+            for (int t0 = 0; t0 < T; t0 += 4) {
+                const int t = t0 + kq;
+                double ga = 0.0, gb = 0.0;
+                if (t < T) {
+                    if (ca < rs) ga = w_s[t * L + l] * Gl[t * rs + ca];
+                    if (cb < rs) gb = Gl[t * rs + cb];
+                }
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, gb, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 * bi + kq + 4 * q;
+                if (cb <= row && row < RA) Xl[tri_row_off(row) + cb] = c[q] + (cb == row ? 1.0 : 0.0);
+            }
+        }
+        tri_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double rr[RA];
+            ok = wave_chol_rows<RA>(rr, Xl, lane);
+        }
+        {
+            double x[RA];
+            wave_tri_inverse_cols<RA>(Xl, x, lane);
+            tri_wave_sync();
+            if (lane < RA) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
+            }
+        }
+    }
+    tri_wave_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    if (A.do_v && ok && lane < T) {
+        const double* Gt = Gl + lane * rs;
+        double gt[RA];
+#pragma unroll
+        for (int i = 0; i < RA; i += 2) {
+            double2 g2 = {0.0, 0.0};
+            if (i < rs) g2 = *reinterpret_cast<const double2*>(Gt + i);
+            gt[i] = g2.x;
+            gt[i + 1] = g2.y;
+        }
+        double vv = 0.0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            if (i < r) {
+                const double* Xi = Xl + tri_row_off(i);
+                double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                for (int q = 0; q + 1 <= i; q += 2) {
+                    const double2 x2 = *reinterpret_cast<const double2*>(Xi + q);
+                    z0 = fma(x2.x, gt[q], z0);
+                    z1 = fma(x2.y, gt[q + 1], z1);
+                }
+                if (!(i & 1)) z0 = fma(Xi[i], gt[i], z0);
+                const double z = z0 + z1;
+                vv = fma(z, z, vv);
+            }
+        }
+        v_s[lane * L + l] = vv;
+    }
+    // X -> global for the mean update of the next sweep
+    {
+        double* xd = A.xg + (int64_t)(K.m * L + l) * A.pkg;
+        constexpr int PK = tri_packed_size(RA);
+        for (int i = lane; i < PK; i += 64) xd[i] = Xl[i];
+    }
+    if (lane == 0) {
+        A.failg[K.m * L + l] = ok ? 0 : 1;
+        if (!ok) atomicAdd(A.fail, 1);
+    }
+}
+
+// Newton step on the posterior mean (estep_fast.hip mean_phase, one latent)
+template <int RP, int RA>
+__device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int lane) {
+    constexpr int NCH = 64 / RP;
+    const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
+    const double* Gl = K.Gl;
+    double* Xl = K.Xl;
+    const double* w_s = A.w + K.r0 * L;
+    const double* ra_s = A.ra + K.r0 * L;
+    double* mu_s = A.mu + K.r0 * L;
+    double* vec = K.vec;
+    double* vec2 = vec + 64;
+    double* u = K.u;
+    {
+        const double* xs = A.xg + (int64_t)(K.m * L + l) * A.pkg;
+        constexpr int PK = tri_packed_size(RA);
+        for (int i = lane; i < PK; i += 64) Xl[i] = xs[i];
+    }
+    tri_wave_sync();
+    const int j = lane & (RP - 1), ch = lane / RP;
+    // g1 = G' (res a_l)
+    double acc = 0.0;
+    if (j < rs) {
+#pragma unroll 4
+        for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * rs + j], ra_s[t * L + l], acc);
+    }
+#pragma unroll
+    for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane < RA) vec[lane] = acc;
+    tri_wave_sync();
+    // u = G g1 - mu_l   (row t of G stays in registers for the last step)
+    double gt[RA];
+    double ut = 0.0;
+    {
+        const double* Gt = Gl + (lane < T ? lane : 0) * rs;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RA; i += 2) {
+            double2 g2 = {0.0, 0.0};
+            if (i < rs) {
+                g2 = *reinterpret_cast<const double2*>(Gt + i);
+                const double2 c2 = *reinterpret_cast<const double2*>(vec + i);
+                s0 = fma(g2.x, c2.x, s0);
+                s1 = fma(g2.y, c2.y, s1);
+            }
+            gt[i] = g2.x;
+            gt[i + 1] = g2.y;
+        }
+        if (lane < T) {
+            ut = (s0 + s1) - mu_s[lane * L + l];
+            u[lane] = ut;
+        }
+    }
+    tri_wave_sync();
+    // rhs = (W G)' u
+    acc = 0.0;
+    if (j < rs) {
+#pragma unroll 4
+        for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * rs + j], u[t], acc);
+    }
+#pragma unroll
+    for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane < RA) vec2[lane] = acc;
+    tri_wave_sync();
+    // z = X rhs, sol = X' z   (lane = row, then lane = column)
+    double z = 0.0;
+    if (lane < RA) {
+        const double* Xi = Xl + tri_row_off(lane);
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < RA; q += 4) {
+            if (q <= lane) z0 = fma(Xi[q], vec2[q], z0);
+            if (q + 1 <= lane) z1 = fma(Xi[q + 1], vec2[q + 1], z1);
+            if (q + 2 <= lane) z2 = fma(Xi[q + 2], vec2[q + 2], z2);
+            if (q + 3 <= lane) z3 = fma(Xi[q + 3], vec2[q + 3], z3);
+        }
+        z = (z0 + z1) + (z2 + z3);
+    }
+    tri_wave_sync();
+    if (lane < RA) vec[lane] = z;
+    tri_wave_sync();
+    double sol = 0.0;
+    if (lane < RA) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < RA; q += 4) {
+            if (q >= lane) s0 = fma(Xl[tri_row_off(q) + lane], vec[q], s0);
+            if (q + 1 >= lane) s1 = fma(Xl[tri_row_off(q + 1) + lane], vec[q + 1], s1);
+            if (q + 2 >= lane) s2 = fma(Xl[tri_row_off(q + 2) + lane], vec[q + 2], s2);
+            if (q + 3 >= lane) s3 = fma(Xl[tri_row_off(q + 3) + lane], vec[q + 3], s3);
+        }
+        sol = (s0 + s1) + (s2 + s3);
+    }
+    tri_wave_sync();
+    if (lane < RA) vec2[lane] = sol;
+    tri_wave_sync();
+    if (lane < T) {
+        double s0 = ut, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RA; i += 2)
+            if (i < rs) {
+                const double2 c2 = *reinterpret_cast<const double2*>(vec2 + i);
+                s0 = fma(-gt[i], c2.x, s0);
+                s1 = fma(-gt[i + 1], c2.y, s1);
+            }
+        double s = s0 + s1;
+        s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
+        if (A.last) A.dmu[(K.r0 + lane) * L + l] = s;
+        mu_s[lane * L + l] += s;
+    }
+}
+
+// MAXRA: largest register-array size compiled in (16: every latent of the launch has rank <= 16)
+template <int MAXRA, bool MEAN>
+__global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int PKM = tri_packed_size(MAXRA);
+    double* lds_wave = smem + (int64_t)wid * (A.lds_g + PKM + 448);
+    Task K;
+    if (!task_setup(A, K, lds_wave, PKM, lane)) return;
+    if constexpr (MEAN) {
+        if (A.failg[K.m * A.L + K.l]) {  // singular system: zero update (core.py:92-94)
+            if (lane == 0) atomicAdd(A.fail, 1);
+            if (A.last && lane < K.T) A.dmu[(K.r0 + lane) * A.L + K.l] = 0.0;
+            return;
+        }
+    }
+    if (K.r <= 16) {
+        if constexpr (MEAN) mean_task<16, 16>(A, K, lane);
+        else factor_task<16, 16>(A, K, lane);
+    } else if constexpr (MAXRA >= 24) {
+        if (K.r <= 24) {
+            if constexpr (MEAN) mean_task<32, 24>(A, K, lane);
+            else factor_task<32, 24>(A, K, lane);
+        } else if constexpr (MAXRA >= 32) {
+            if constexpr (MEAN) mean_task<32, 32>(A, K, lane);
+            else factor_task<32, 32>(A, K, lane);
+        }
+    }
+}
+
+template <int LT>
+int run_passes(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
+    const dim3 grid((unsigned)((A.rows + 255) / 256)), blk(256);
+    hipStream_t st = ctx->stream;
+    if (A.xb) {
+        if (kind == SP_YA) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, true>), grid, blk, 0, st, A, cols);
+        else if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, true>), grid, blk, 0, st, A, cols);
+        else hipLaunchKernelGGL((esplit_pass<LT, SP_W, true>), grid, blk, 0, st, A, cols);
+    } else {
+        if (kind == SP_YA) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, false>), grid, blk, 0, st, A, cols);
+        else if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, false>), grid, blk, 0, st, A, cols);
+        else hipLaunchKernelGGL((esplit_pass<LT, SP_W, false>), grid, blk, 0, st, A, cols);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
+int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* cols) {
+    if (LT == 3) return run_passes<3>(ctx, A, kind, cols);
+    if (LT == 5) return run_passes<5>(ctx, A, kind, cols);
+    return run_passes<8>(ctx, A, kind, cols);
+}
+
+int run_latent(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
+    const int tasks = A.M * A.L;
+    const dim3 grid((unsigned)((tasks + 3) / 4)), blk(256);
+    const int pkm = maxra == 16 ? tri_packed_size(16) : (maxra == 24 ? tri_packed_size(24) : tri_packed_size(32));
+    const size_t lds = (size_t)4 * (A.lds_g + pkm + 448) * 8;
+    hipStream_t st = ctx->stream;
+#define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
+    do {                                                                                                              \
+        auto fn = esplit_latent<RA, MEANV>;                                                                           \
+        if (lds > 64 * 1024)                                                                                          \
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                                        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL(fn, grid, blk, lds, st, A);                                                                \
+    } while (0)
+    if (maxra == 16) { if (mean) ESPLIT_LAUNCH(16, true); else ESPLIT_LAUNCH(16, false); }
+    else if (maxra == 24) { if (mean) ESPLIT_LAUNCH(24, true); else ESPLIT_LAUNCH(24, false); }
+    else { if (mean) ESPLIT_LAUNCH(32, true); else ESPLIT_LAUNCH(32, false); }
+#undef ESPLIT_LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
+}  // namespace
+
+int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
+    *handled = 0;
+    const int N = ctx->N, L = ctx->L;
+    const char* sw = getenv("VLGP_ESTEP_SPLIT");
+    if (sw && sw[0] == '0') return VLGP_OK;
+    if (getenv("VLGP_ESTEP_GENERIC")) return VLGP_OK;
+    if (us.Tmax > 64 || L > 8 || N > 1024) return VLGP_OK;
+    // the persistent kernel wins while a launch cannot fill the chip (its cost is latency, not throughput)
+    if (!(sw && sw[0] == '1') && (us.rows < 64LL * 1024 || us.M < 2 * ctx->n_cu)) return VLGP_OK;
+    const bool need_prior = (E.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
+    int rmax = 0;
+    int64_t gw = 0;  // doubles of G per (unit, latent)
+    if (need_prior) {
+        for (auto& kv : ctx->priors) {
+            const Prior& pr = kv.second;
+            if (pr.T < us.Tmin || pr.T > us.Tmax) continue;
+            for (int l = 0; l < L; ++l) {
+                rmax = pr.rl[l] > rmax ? pr.rl[l] : rmax;
+                const int64_t g = (int64_t)pr.T * ((pr.rl[l] + 1) & ~1);
+                gw = g > gw ? g : gw;
+            }
+        }
+    }
+    if (rmax > 32) return VLGP_OK;
+    const int maxra = rmax <= 16 ? 16 : (rmax <= 24 ? 24 : 32);
+    const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : 8);
+    const int REC = (2 * LT + 3 + 1) & ~1;
+    const int pkg = tri_packed_size(maxra);
+    // scratch of the set: ra | ya | xg | failg(int) ; records + wconst in ctx->d_ecols
+    const int64_t nRL = us.rows * L;
+    const int64_t need = 2 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8;
+    if (us.scratch_len < need) {
+        if (us.d_scratch) HIPCHK(ctx, hipFree(us.d_scratch));
+        us.d_scratch = nullptr;
+        us.scratch_len = 0;
+        HIPCHK(ctx, hipMalloc(&us.d_scratch, (size_t)need * 8));
+        us.scratch_len = need;
+    }
+    if (!ctx->d_ecols) HIPCHK(ctx, hipMalloc(&ctx->d_ecols, sizeof(double) * ((size_t)N * 34 + 32)));
+    if (REC > 34) return VLGP_OK;
+    double* cols = ctx->d_ecols;
+    double* wconst = ctx->d_ecols + (int64_t)N * 34;
+    hipLaunchKernelGGL(esplit_cols_kernel, dim3(1), dim3(256), 0, ctx->stream, N, L, LT, REC, ctx->d_a, ctx->d_b,
+                       ctx->d_noise, ctx->d_gauss, cols, wconst);
+    HIPCHK(ctx, hipGetLastError());
+
+    SplitArgs A;
+    A.N = N; A.L = L; A.M = us.M; A.rows = us.rows;
+    A.off = E.off; A.unit_prior = E.unit_prior; A.prior_base = E.prior_base; A.prior_rl = E.prior_rl;
+    A.prior_goff = E.prior_goff;
+    A.y = E.y; A.xb = E.xb; A.mu = E.mu; A.v = E.v; A.w = E.w; A.dmu = E.dmu;
+    A.ra = us.d_scratch; A.ya = A.ra + nRL; A.xg = A.ya + nRL; A.pkg = pkg;
+    A.failg = reinterpret_cast<int*>(A.xg + (int64_t)us.M * L * pkg);
+    A.fail = E.fail;
+    A.wconst = wconst;
+    A.dmu_bound = E.dmu_bound;
+    A.ntot = N; A.np = N - ctx->n_gauss;
+    A.lds_g = (int)((gw + 1) & ~1LL);
+    A.do_v = 0; A.last = 0;
+    if ((size_t)4 * (A.lds_g + pkg + 448) * 8 > 160 * 1024) return VLGP_OK;
+    *handled = 1;
+    HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
+
+    const int mode = E.mode;
+    const bool with_mean = (mode & EM_MEAN) != 0;
+    const int n_it = with_mean ? E.n_iter : ((mode & EM_W) ? 1 : 0);
+    const int kind = maxra <= 16 ? VLGP_PROF_ESTEP_RA16 : (maxra <= 24 ? VLGP_PROF_ESTEP_RA24 : VLGP_PROF_ESTEP_RA32);
+    vlgp_prof_begin(ctx, kind);
+    int rc = VLGP_OK;
+    if (with_mean) rc = run_pass(ctx, A, LT, SP_YA, cols);
+    for (int it = (mode & EM_FACTOR0) ? -1 : 0; it < n_it && rc == VLGP_OK; ++it) {
+        const bool last = it == n_it - 1;
+        bool do_factor, do_v;
+        if (it >= 0) {
+            if (with_mean) {
+                rc = run_pass(ctx, A, LT, SP_RES, cols);
+                A.last = last ? 1 : 0;
+                if (rc == VLGP_OK) rc = run_latent(ctx, A, maxra, true);
+            }
+            if (rc == VLGP_OK) rc = run_pass(ctx, A, LT, SP_W, cols);
+            do_factor = with_mean && (E.vb || !last);
+            do_v = E.vb != 0;
+        } else {
+            do_factor = true;
+            do_v = (mode & EM_V) && !with_mean;
+        }
+        if (do_factor && rc == VLGP_OK) {
+            A.do_v = do_v ? 1 : 0;
+            rc = run_latent(ctx, A, maxra, false);
+        }
+    }
+    vlgp_prof_end(ctx, kind, (double)us.M * (E.n_iter > 0 ? E.n_iter : 1));
+    return rc;
+}
