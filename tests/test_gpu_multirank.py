@@ -64,6 +64,10 @@ def _collect(q, procs, limit=600.0):
     return got
 
 
+PARAM_TOL = 1e-5  # a, b, noise, posterior means: sharded against unsharded fit
+OMEGA_TOL = 1e-4  # omega: limited by L-BFGS-B's own stopping rule (ftol = 2.2e-9), see the first test
+
+
 def _run_worlds(worlds, inject):
     import multiprocessing as mp
 
@@ -93,12 +97,16 @@ def test_ranks_on_one_gpu_match_single_process():
         for r in rs[1:]:
             for i in (1, 2, 3, 4):
                 assert np.array_equal(rs[0][i], r[i])
-        # and equal to the single-process fit up to the order of the row sums (the prior factor is a bit-exact
-        # function of omega, so nothing amplifies the last-bit differences of the M/H-step sums)
-        for i in (1, 2, 3, 4):
-            assert relerr(rs[0][i], one[i]) < 1e-6, (world, i)
+        # and equal to the single-process fit up to the order of the row sums.  The sharded sums differ from the
+        # unsharded ones in the last bit; the only amplifier left is L-BFGS-B itself (gp.py:114): SciPy stops on a
+        # relative decrease of 2.2e-9 in the objective, which pins the minimiser omega to a few 1e-5 at best (a
+        # last-bit change in (ll, dll) can end a line search one evaluation earlier or later), so omega is held
+        # to OMEGA_TOL and what depends on it to PARAM_TOL
+        for i in (1, 2, 3):
+            assert relerr(rs[0][i], one[i]) < PARAM_TOL, (world, i)
+        assert relerr(rs[0][4], one[4]) < OMEGA_TOL, world
         assert sum((r[5] for r in rs), []) == one[5]  # contiguous shards cover the trials in order
-        assert relerr(np.concatenate([r[6] for r in rs]), one[6]) < 1e-6  # full-length posterior means
+        assert relerr(np.concatenate([r[6] for r in rs]), one[6]) < PARAM_TOL  # full-length posterior means
         assert all(r[7] == 3 for r in rs) and one[7] == 3
 
 
@@ -109,8 +117,8 @@ def test_two_ranks_default_initialisation_matches_single_process():
     one, (r0, r1) = out[1][0], out[2]
     for i in (1, 2, 3, 4):
         assert np.array_equal(r0[i], r1[i])
-        assert relerr(r0[i], one[i]) < 1e-6, i
-    assert relerr(np.concatenate([r0[6], r1[6]]), one[6]) < 1e-6
+        assert relerr(r0[i], one[i]) < (OMEGA_TOL if i == 4 else PARAM_TOL), i
+    assert relerr(np.concatenate([r0[6], r1[6]]), one[6]) < PARAM_TOL
 
 
 def test_bench_launch_line_two_ranks_one_gpu():

@@ -196,14 +196,14 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
 struct Task {
     int m, l, T, r, rs;
     int64_t r0;
-    double* Gl;    // LDS: (T, rs) compact prior factor, zero-padded odd column
+    const double* Gl;  // global: (T, r) compact prior factor of this latent
     double* Xl;    // LDS: packed X
     double* vec;   // LDS: 128 doubles
     double* u;     // LDS: 64 doubles
     double* tile;  // LDS: 256 doubles
 };
 
-__device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int pk_max, int lane) {
+__device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int lane) {
     const int wid = threadIdx.x >> 6;
     const int task = blockIdx.x * (blockDim.x >> 6) + wid;
     if (task >= A.M * A.L) return false;
@@ -214,26 +214,73 @@ __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* 
     const int pidx = A.unit_prior[K.m];
     K.r = __builtin_amdgcn_readfirstlane(A.prior_rl[pidx * A.L + K.l]);
     K.rs = (K.r + 1) & ~1;
-    K.Gl = lds_wave;
-    K.Xl = lds_wave + A.lds_g;
-    K.vec = K.Xl + pk_max;
+    K.Gl = A.prior_base[pidx] + A.prior_goff[pidx * A.L + K.l];
+    K.Xl = lds_wave;
+    K.vec = K.Xl + A.pkg;
     K.u = K.vec + 128;
     K.tile = K.u + 64;
-    const double* src = A.prior_base[pidx] + A.prior_goff[pidx * A.L + K.l];
-    const int n = K.T * K.rs, r = K.r, rs = K.rs;
-    for (int i = lane; i < n; i += 64) {
-        const int t = i / rs, c = i - t * rs;
-        K.Gl[i] = c < r ? src[t * r + c] : 0.0;
-    }
-    tri_wave_sync();
     return true;
+}
+
+// row t of the compact factor (r entries, zero beyond) into registers; rows are only 8-byte aligned
+template <int RA>
+__device__ __forceinline__ void load_g_row(double (&gt)[RA], const double* Gl, int t, int r) {
+    const double* Gt = Gl + (int64_t)t * r;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) gt[i] = i < r ? Gt[i] : 0.0;
+}
+
+// Rank <= 16: Cholesky factor AND inverse in one elimination of the augmented matrix [H; I] (lanes 0..15 hold the
+// rows of H, lanes 16..31 the unit rows): the unit rows come out as the rows of X' = L^-T, i.e. lane 16 + c holds
+// X[i][c] in a[i].  Column k takes the updates of columns m <= k - 2 one step ahead, with multipliers L[k][m]
+// broadcast from an LDS copy of the finished columns (off the pivot chain); the last update and the pivot are
+// v_readlane broadcasts.  Steps k >= r (identity padding) are skipped.  Ld: 16 x 16 doubles of LDS.
+__device__ __forceinline__ bool wave_chol_aug16(double (&a)[16], int lane, int r, double* Ld) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < r) {
+            if (k > 0) {
+                const double lv = tri_readlane(a[k - 1], k);
+                a[k] = fma(-a[k - 1], lv, a[k]);
+            }
+            const double d = tri_readlane(a[k], k);
+            if (!(d > 0.0) || !(d < 1e300)) ok = false;
+            double y = __builtin_amdgcn_rsq(d);
+            if (k + 1 < 16 && k >= 1) {  // column k + 1 <- columns 0 .. k - 1
+                const double* row = Ld + (k + 1) * 16;
+                double a0 = a[k + 1], a1 = 0.0;
+#pragma unroll
+                for (int m = 0; m + 1 < k; m += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(row + m);
+                    a0 = fma(-a[m], v.x, a0);
+                    a1 = fma(-a[m + 1], v.y, a1);
+                }
+                if (k & 1) a0 = fma(-a[k - 1], row[k - 1], a0);
+                a[k + 1] = a0 + a1;
+                asm volatile("" : "+v"(a[k + 1]));
+            }
+            double e = fma(-d * y, y, 1.0);
+            y = fma(y * 0.5, e, y);
+            e = fma(-d * y, y, 1.0);
+            y = fma(y * 0.5, e, y);
+            a[k] *= y;
+            asm volatile("" : "+v"(a[k]));
+            if (k + 1 < 16) {
+                if (lane < 16) Ld[lane * 16 + k] = a[k];
+                tri_wave_order();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return ok;
 }
 
 // factor I + G'WG, invert, optionally refresh v (estep_fast.hip factor_phase, one latent)
 template <int RP, int RA>
 __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, int lane) {
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
-    const double* Gl = K.Gl;
+    const double* __restrict__ Gl = K.Gl;
     double* Xl = K.Xl;
     const double* w_s = A.w + K.r0 * L;
     double* v_s = A.v + K.r0 * L;
@@ -242,12 +289,12 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     const int col = lane & 15, kq = lane >> 4;
     if constexpr (RP <= 16) {
         double4_t c = {0.0, 0.0, 0.0, 0.0};
-        const bool cin = col < rs;
+        const bool cin = col < r;
         for (int t0 = 0; t0 < T; t0 += 4) {
             const int t = t0 + kq;
             double g = 0.0, wg = 0.0;
             if (cin && t < T) {
-                g = Gl[t * rs + col];
+                g = Gl[t * r + col];
                 wg = w_s[t * L + l] * g;
             }
             c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
@@ -256,19 +303,22 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) ht[(kq + 4 * q) * 16 + col] = c[q];
         tri_wave_sync();
-        double a[RP];
+        double a[16];  // lanes 0..15: rows of I + G'WG; lanes 16..31: unit rows
 #pragma unroll
-        for (int i = 0; i < RP; i += 2) {
+        for (int i = 0; i < 16; i += 2) {
             const double2 h2 = *reinterpret_cast<const double2*>(ht + j * 16 + i);
-            a[i] = h2.x + (i == j ? 1.0 : 0.0);
-            a[i + 1] = h2.y + (i + 1 == j ? 1.0 : 0.0);
+            a[i] = (lane < 16 ? h2.x : 0.0) + (i == j ? 1.0 : 0.0);
+            a[i + 1] = (lane < 16 ? h2.y : 0.0) + (i + 1 == j ? 1.0 : 0.0);
         }
-        double x[RP];
-        ok = wave_chol_inv_regs<RP>(a, x, j, r);
-        if (lane < RP) {  // X row-major packed in LDS for the solves: X[i][c], i >= c
 #pragma unroll
-            for (int i = 0; i < RP; ++i)
-                if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(a[i]));
+        tri_wave_order();
+        ok = wave_chol_aug16(a, lane, r, K.tile);
+        tri_wave_order();
+        if (lane >= 16 && lane < 32) {  // X row-major packed in LDS for the solves: X[i][c], i >= c = lane - 16
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i >= lane - 16) Xl[tri_row_off(i) + lane - 16] = i < r ? a[i] : (i == lane - 16 ? 1.0 : 0.0);
         }
     } else {
 #pragma unroll
@@ -280,8 +330,8 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
                 const int t = t0 + kq;
                 double ga = 0.0, gb = 0.0;
                 if (t < T) {
-                    if (ca < rs) ga = w_s[t * L + l] * Gl[t * rs + ca];
-                    if (cb < rs) gb = Gl[t * rs + cb];
+                    if (ca < r) ga = w_s[t * L + l] * Gl[t * r + ca];
+                    if (cb < r) gb = Gl[t * r + cb];
                 }
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, gb, c, 0, 0, 0);
             }
@@ -311,15 +361,8 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     tri_wave_sync();
     __builtin_amdgcn_sched_barrier(0);
     if (A.do_v && ok && lane < T) {
-        const double* Gt = Gl + lane * rs;
         double gt[RA];
-#pragma unroll
-        for (int i = 0; i < RA; i += 2) {
-            double2 g2 = {0.0, 0.0};
-            if (i < rs) g2 = *reinterpret_cast<const double2*>(Gt + i);
-            gt[i] = g2.x;
-            gt[i + 1] = g2.y;
-        }
+        load_g_row<RA>(gt, Gl, lane, r);
         double vv = 0.0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -373,9 +416,9 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     const int j = lane & (RP - 1), ch = lane / RP;
     // g1 = G' (res a_l)
     double acc = 0.0;
-    if (j < rs) {
+    if (j < r) {
 #pragma unroll 4
-        for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * rs + j], ra_s[t * L + l], acc);
+        for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * r + j], ra_s[t * L + l], acc);
     }
 #pragma unroll
     for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
@@ -385,19 +428,15 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     double gt[RA];
     double ut = 0.0;
     {
-        const double* Gt = Gl + (lane < T ? lane : 0) * rs;
+        load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int i = 0; i < RA; i += 2) {
-            double2 g2 = {0.0, 0.0};
             if (i < rs) {
-                g2 = *reinterpret_cast<const double2*>(Gt + i);
                 const double2 c2 = *reinterpret_cast<const double2*>(vec + i);
-                s0 = fma(g2.x, c2.x, s0);
-                s1 = fma(g2.y, c2.y, s1);
+                s0 = fma(gt[i], c2.x, s0);
+                s1 = fma(gt[i + 1], c2.y, s1);
             }
-            gt[i] = g2.x;
-            gt[i + 1] = g2.y;
         }
         if (lane < T) {
             ut = (s0 + s1) - mu_s[lane * L + l];
@@ -407,9 +446,9 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     tri_wave_sync();
     // rhs = (W G)' u
     acc = 0.0;
-    if (j < rs) {
+    if (j < r) {
 #pragma unroll 4
-        for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * rs + j], u[t], acc);
+        for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * r + j], u[t], acc);
     }
 #pragma unroll
     for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
@@ -468,10 +507,9 @@ template <int MAXRA, bool MEAN>
 __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr int PKM = tri_packed_size(MAXRA);
-    double* lds_wave = smem + (int64_t)wid * (A.lds_g + PKM + 448);
+    double* lds_wave = smem + (int64_t)wid * (A.pkg + 448);
     Task K;
-    if (!task_setup(A, K, lds_wave, PKM, lane)) return;
+    if (!task_setup(A, K, lds_wave, lane)) return;
     if constexpr (MEAN) {
         if (A.failg[K.m * A.L + K.l]) {  // singular system: zero update (core.py:92-94)
             if (lane == 0) atomicAdd(A.fail, 1);
@@ -519,8 +557,7 @@ int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* 
 int run_latent(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     const int tasks = A.M * A.L;
     const dim3 grid((unsigned)((tasks + 3) / 4)), blk(256);
-    const int pkm = maxra == 16 ? tri_packed_size(16) : (maxra == 24 ? tri_packed_size(24) : tri_packed_size(32));
-    const size_t lds = (size_t)4 * (A.lds_g + pkm + 448) * 8;
+    const size_t lds = (size_t)4 * (A.pkg + 448) * 8;
     hipStream_t st = ctx->stream;
 #define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
     do {                                                                                                              \
@@ -599,7 +636,6 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.ntot = N; A.np = N - ctx->n_gauss;
     A.lds_g = (int)((gw + 1) & ~1LL);
     A.do_v = 0; A.last = 0;
-    if ((size_t)4 * (A.lds_g + pkg + 448) * 8 > 160 * 1024) return VLGP_OK;
     *handled = 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
 
