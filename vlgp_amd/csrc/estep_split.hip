@@ -200,7 +200,8 @@ struct Task {
     double* Xl;    // LDS: packed X
     double* vec;   // LDS: 128 doubles
     double* u;     // LDS: 64 doubles
-    double* tile;  // LDS: 256 doubles
+    double* tile;  // LDS: max(256, gcap) doubles (MFMA staging tile / staged G), then two 64-entry columns
+    int gcap;      // doubles reserved for the staged G (>= 256)
 };
 
 __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int lane) {
@@ -216,9 +217,10 @@ __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* 
     K.rs = (K.r + 1) & ~1;
     K.Gl = A.prior_base[pidx] + A.prior_goff[pidx * A.L + K.l];
     K.Xl = lds_wave;
-    K.vec = K.Xl + A.pkg;
+    K.tile = K.Xl + A.pkg;
+    K.gcap = A.lds_g;
+    K.vec = K.tile + A.lds_g + 128;  // mean kernel only
     K.u = K.vec + 128;
-    K.tile = K.u + 64;
     return true;
 }
 
@@ -277,7 +279,7 @@ __device__ __forceinline__ bool wave_chol_aug16(double (&a)[16], int lane, int r
 }
 
 // factor I + G'WG, invert, optionally refresh v (estep_fast.hip factor_phase, one latent)
-template <int RP, int RA>
+template <int RP, int RA, bool STAGE>
 __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, int lane) {
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
     const double* __restrict__ Gl = K.Gl;
@@ -289,16 +291,44 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     const int col = lane & 15, kq = lane >> 4;
     if constexpr (RP <= 16) {
         double4_t c = {0.0, 0.0, 0.0, 0.0};
-        const bool cin = col < r;
-        for (int t0 = 0; t0 < T; t0 += 4) {
-            const int t = t0 + kq;
-            double g = 0.0, wg = 0.0;
-            if (cin && t < T) {
-                g = Gl[t * r + col];
-                wg = w_s[t * L + l] * g;
+        if constexpr (STAGE) {
+            // one round trip to global memory: every lane fetches its row of G and its curvature, then the build
+            // reads them back from LDS in the (column, time-chunk) layout of the matrix instruction
+            double gt0[16];
+            load_g_row<16>(gt0, Gl, lane < T ? lane : 0, r);
+            const double wt = lane < T ? w_s[lane * L + l] : 0.0;
+            double* Gs = K.tile;  // (T, rs); the staging tile of the result reuses it afterwards
+            double* wcol = K.tile + K.gcap;
+            if (lane < T) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2)
+                    if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt0[i], gt0[i + 1]};
+                wcol[lane] = wt;
             }
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
+            tri_wave_sync();
+            const bool cin = col < rs;
+            for (int t0 = 0; t0 < T; t0 += 4) {
+                const int t = t0 + kq;
+                double g = 0.0, wg = 0.0;
+                if (cin && t < T) {
+                    g = Gs[t * rs + col];
+                    wg = wcol[t] * g;
+                }
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
+            }
+        } else {
+            const bool cin = col < r;
+            for (int t0 = 0; t0 < T; t0 += 4) {
+                const int t = t0 + kq;
+                double g = 0.0, wg = 0.0;
+                if (cin && t < T) {
+                    g = Gl[t * r + col];
+                    wg = w_s[t * L + l] * g;
+                }
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
+            }
         }
+        tri_wave_order();
         double* ht = K.tile;
 #pragma unroll
         for (int q = 0; q < 4; ++q) ht[(kq + 4 * q) * 16 + col] = c[q];
@@ -362,7 +392,7 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     __builtin_amdgcn_sched_barrier(0);
     if (A.do_v && ok && lane < T) {
         double gt[RA];
-        load_g_row<RA>(gt, Gl, lane, r);
+        load_g_row<RA>(gt, Gl, lane, r);  // (rank <= 16: the same loads as at the top, the compiler keeps the registers)
         double vv = 0.0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -395,7 +425,7 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
 }
 
 // Newton step on the posterior mean (estep_fast.hip mean_phase, one latent)
-template <int RP, int RA>
+template <int RP, int RA, bool STAGE>
 __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int lane) {
     constexpr int NCH = 64 / RP;
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
@@ -407,28 +437,52 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     double* vec = K.vec;
     double* vec2 = vec + 64;
     double* u = K.u;
+    // STAGE (rank <= 16 in an all-rank-<=-16 launch): G, the residual and the curvature of this latent staged in LDS
+    double gt[RA];
+    double mu_t = 0.0;
+    double* Gs = K.tile;
+    double* racol = K.tile + K.gcap;
+    double* wcol = racol + 64;
     {
         const double* xs = A.xg + (int64_t)(K.m * L + l) * A.pkg;
         constexpr int PK = tri_packed_size(RA);
         for (int i = lane; i < PK; i += 64) Xl[i] = xs[i];
+    }
+    if constexpr (STAGE) {
+        load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
+        if (lane < T) {
+            mu_t = mu_s[lane * L + l];
+            racol[lane] = ra_s[lane * L + l];
+            wcol[lane] = w_s[lane * L + l];
+#pragma unroll
+            for (int i = 0; i < RA; i += 2)
+                if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt[i], gt[i + 1]};
+        }
     }
     tri_wave_sync();
     const int j = lane & (RP - 1), ch = lane / RP;
     // g1 = G' (res a_l)
     double acc = 0.0;
     if (j < r) {
+        if constexpr (STAGE) {
 #pragma unroll 4
-        for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * r + j], ra_s[t * L + l], acc);
+            for (int t = ch; t < T; t += NCH) acc = fma(Gs[t * rs + j], racol[t], acc);
+        } else {
+#pragma unroll 4
+            for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * r + j], ra_s[t * L + l], acc);
+        }
     }
 #pragma unroll
     for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (lane < RA) vec[lane] = acc;
     tri_wave_sync();
     // u = G g1 - mu_l   (row t of G stays in registers for the last step)
-    double gt[RA];
     double ut = 0.0;
     {
-        load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
+        if constexpr (!STAGE) {
+            load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
+            if (lane < T) mu_t = mu_s[lane * L + l];
+        }
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int i = 0; i < RA; i += 2) {
@@ -439,7 +493,7 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
             }
         }
         if (lane < T) {
-            ut = (s0 + s1) - mu_s[lane * L + l];
+            ut = (s0 + s1) - mu_t;
             u[lane] = ut;
         }
     }
@@ -447,8 +501,13 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     // rhs = (W G)' u
     acc = 0.0;
     if (j < r) {
+        if constexpr (STAGE) {
 #pragma unroll 4
-        for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * r + j], u[t], acc);
+            for (int t = ch; t < T; t += NCH) acc = fma(wcol[t] * Gs[t * rs + j], u[t], acc);
+        } else {
+#pragma unroll 4
+            for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * r + j], u[t], acc);
+        }
     }
 #pragma unroll
     for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
@@ -498,7 +557,7 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
         double s = s0 + s1;
         s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
         if (A.last) A.dmu[(K.r0 + lane) * L + l] = s;
-        mu_s[lane * L + l] += s;
+        mu_s[lane * L + l] = mu_t + s;
     }
 }
 
@@ -507,7 +566,7 @@ template <int MAXRA, bool MEAN>
 __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    double* lds_wave = smem + (int64_t)wid * (A.pkg + 448);
+    double* lds_wave = smem + (int64_t)wid * (A.pkg + A.lds_g + 128 + (MEAN ? 192 : 0));
     Task K;
     if (!task_setup(A, K, lds_wave, lane)) return;
     if constexpr (MEAN) {
@@ -518,15 +577,15 @@ __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
         }
     }
     if (K.r <= 16) {
-        if constexpr (MEAN) mean_task<16, 16>(A, K, lane);
-        else factor_task<16, 16>(A, K, lane);
+        if constexpr (MEAN) mean_task<16, 16, MAXRA == 16>(A, K, lane);
+        else factor_task<16, 16, MAXRA == 16>(A, K, lane);
     } else if constexpr (MAXRA >= 24) {
         if (K.r <= 24) {
-            if constexpr (MEAN) mean_task<32, 24>(A, K, lane);
-            else factor_task<32, 24>(A, K, lane);
+            if constexpr (MEAN) mean_task<32, 24, false>(A, K, lane);
+            else factor_task<32, 24, false>(A, K, lane);
         } else if constexpr (MAXRA >= 32) {
-            if constexpr (MEAN) mean_task<32, 32>(A, K, lane);
-            else factor_task<32, 32>(A, K, lane);
+            if constexpr (MEAN) mean_task<32, 32, false>(A, K, lane);
+            else factor_task<32, 32, false>(A, K, lane);
         }
     }
 }
@@ -557,7 +616,7 @@ int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* 
 int run_latent(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     const int tasks = A.M * A.L;
     const dim3 grid((unsigned)((tasks + 3) / 4)), blk(256);
-    const size_t lds = (size_t)4 * (A.pkg + 448) * 8;
+    const size_t lds = (size_t)4 * (A.pkg + A.lds_g + 128 + (mean ? 192 : 0)) * 8;
     hipStream_t st = ctx->stream;
 #define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
     do {                                                                                                              \
@@ -634,7 +693,8 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.wconst = wconst;
     A.dmu_bound = E.dmu_bound;
     A.ntot = N; A.np = N - ctx->n_gauss;
-    A.lds_g = (int)((gw + 1) & ~1LL);
+    A.lds_g = (int)((gw + 1) & ~1LL);  // staged G of a rank <= 16 latent (and the 16 x 16 staging tile)
+    if (maxra > 16 || A.lds_g < 256) A.lds_g = 256;  // mixed-rank launches read G from global memory
     A.do_v = 0; A.last = 0;
     *handled = 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
