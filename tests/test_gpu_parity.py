@@ -355,7 +355,8 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
         monkeypatch.delenv("VLGP_HSTEP_UNFUSED")
         for other in (first, again):
             assert np.array_equal(other[0], plain[0]) and np.array_equal(other[1], plain[1])
-        assert relerr(unfused[0], plain[0]) < 1e-12 and relerr(unfused[1], plain[1]) < 1e-10
+        # two different factorisations of K (cond ~ 1e5): agreement to cond x eps, far inside the parity tolerance
+        assert relerr(unfused[0], plain[0]) < 1e-10 and relerr(unfused[1], plain[1]) < 1e-9
         # new mu: the cached moments must not survive the upload
         for u in units:
             u["mu"] = u["mu"] + 0.1 * rng.standard_normal(u["mu"].shape)
@@ -390,8 +391,8 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
         monkeypatch.setenv("VLGP_HSTEP_UNFUSED", "1")
         unfused = eng.hstep_objective(0, T, 1.0, lat, logp)
     for other in (padded, unfused):
-        assert relerr(other[0], lean[0]) < 1e-12
-        assert relerr(other[1][:, 1], lean[1][:, 1]) < 1e-10
+        assert relerr(other[0], lean[0]) < 1e-10
+        assert relerr(other[1][:, 1], lean[1][:, 1]) < 1e-9
     t = np.arange(T) * 1.0
     want = O.gp_objective(logp[2], t, np.stack([u["mu"][:, 2] for u in units[:40]], 1),
                           np.stack([u["w"][:, 2] for u in units[:40]], 1))

@@ -1122,8 +1122,8 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
 template <int T, int NW>
 __global__ void __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) hstep_round_mfma(HRoundArgs R) {
     using G = HmGeom<T>;
-    constexpr int KPREP = (hstep_prep_lds<T>() + 1) & ~1;
-    constexpr int KBLK = KPREP + 128 + 128 * NW + T * T;  // kv64 | dkv64 | dk2 per wave (128) | K^-1
+    constexpr int LDK = T | 2;                  // row stride of K^-1 in LDS: 2 mod 4 -> conflict-free operand reads
+    constexpr int KBLK = G::TASK + T * LDK;     // wave 0's task buffer | K^-1
     constexpr int LDSN = NW * G::TASK > KBLK ? NW * G::TASK : KBLK;
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
     __shared__ double part[NW][2];
@@ -1131,19 +1131,53 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) hstep_round_mfma(HRo
     const HFastArgs& A = R.F;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if ((int)blockIdx.x < R.n_eval) {
+        // K block.  Wave 0: K -> K^-1 and log det through the same blocked elimination as the segments (KMODE);
+        // then every wave takes block rows of the two products against the second moments of this latent.
         const int e = blockIdx.x;
-        double* extra = lds + KPREP;
-        double* Kl = extra + 128 + 128 * NW;
-        if (wid == 0) hstep_prep_body<T>(A, e, lane, lds, extra, extra + 64, Kl);
+        double* buf = lds;
+        double* Kl = lds + G::TASK;
+        if (wid == 0) {
+            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
+            {
+                const double d = lane * A.dt, d2 = d * d;
+                const double kk = sigmasq * exp(-omega * d2);
+                buf[G::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
+                buf[G::O_KVM + 63 + lane] = kk;
+                buf[G::O_KVM + 63 - lane] = kk;
+                buf[G::O_DKV + lane] = -kk * d2 * omega;
+            }
+            tri_wave_sync();
+            double logdet, unused;
+            hstep_task_mfma<T, true>(buf, eps, lane, logdet, unused, A.Tr, Kl, LDK);
+            if (lane == 0) {
+                A.scal[4 * e + 0] = logdet;
+                A.scal[4 * e + 1] = 0.0;
+                A.scal[4 * e + 2] = omega;
+                A.scal[4 * e + 3] = (logdet == logdet && fabs(logdet) < 1e300) ? 1.0 : 0.0;  // a bad pivot -> NaN / inf
+            }
+        }
         __syncthreads();
-        hstep_prep_moments_split<T, NW>(A, R.mom, e, lane, wid, Kl, extra + 128 + 128 * wid, extra + 64, &part[0][0]);
+        double quad, gq;
+        hstep_kblock_products<T>(Kl, LDK, R.mom + (int64_t)A.latent[e] * T * T, buf + G::O_DKV, A.Tr, lane, wid, NW,
+                                 quad, gq);
+        for (int o = 32; o > 0; o >>= 1) {
+            quad += __shfl_xor(quad, o, 64);
+            gq += __shfl_xor(gq, o, 64);
+        }
+        if (lane == 0) {
+            part[wid][0] = quad;
+            part[wid][1] = gq;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double gq = part[0][1];
+            double q0 = part[0][0], q1 = part[0][1];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) gq += part[w][1];
-            R.qsum[2 * e + 0] = part[0][0];
-            R.qsum[2 * e + 1] = gq;
+            for (int w = 1; w < NW; ++w) {
+                q0 += part[w][0];
+                q1 += part[w][1];
+            }
+            R.qsum[2 * e + 0] = q0;
+            R.qsum[2 * e + 1] = q1;
         }
     } else {
         const int b = blockIdx.x - R.n_eval;

@@ -66,8 +66,13 @@ __device__ __forceinline__ double hm_rsqrt(double d) {
 // beyond the rows present).  A pivot of A that is not positive and finite makes tr and cs NaN.  tr = tr(A^-1) over all
 // TP rows (the caller subtracts the identity padding's share), cs = sum_jk s_j s_k dK_jk (A^-1)_jk; both
 // per-lane partials.
-template <int TP>
-__device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lane, double& tr, double& cs) {
+//
+// KMODE (the K block of the round): the same elimination applied to K itself -- sv holds 1 for the rows present and
+// 0 beyond, rows >= tr_k carry a unit diagonal (identity padding) -- and instead of the two sums the routine leaves
+// K^-1 as a full symmetric TP x ldk matrix in `kl` (LDS) and returns log det chol(K) in tr.
+template <int TP, bool KMODE = false>
+__device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lane, double& tr, double& cs,
+                                                int tr_k = 0, double* kl = nullptr, int ldk = 0) {
     using G = HmGeom<TP>;
     constexpr int NB = G::NB, E = G::E, LDB = G::LDB, WL = G::WL, TB = 16 * NB;
     const double* sv = buf + G::O_SV;
@@ -88,6 +93,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
 #pragma unroll
     for (int t = 0; t < (E > 0 ? E : 1); ++t) mt[t] = 0.0;
     double ra[WL], rx[WL];
+    double logdet = 0.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int col0 = 16 * k;
@@ -113,6 +119,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
         {
             const int i = col0 + lane;
             const double si = sv[i < 64 ? i : 63];
+            const double one = KMODE ? (i < tr_k ? 0.0 : 1.0) : 1.0;
             // row of N: block rows from bufA, tail rows from ntail (N is symmetric)
             const double* pn = (E > 0 && i >= TB) ? ntail + (i - TB < E ? i - TB : 0) * 64 + col0
                                                   : bufA + (lane < TB - col0 ? lane : 0) * LDB;
@@ -127,8 +134,8 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     mv = *reinterpret_cast<const double2*>(pm + q);
                 }
                 const double a0 = (si * sj.x) * pk[-q], a1 = (si * sj.y) * pk[-q - 1];
-                ra[q] = (lane == q ? fma(si * sj.x, eps, 1.0) : 0.0) + a0 - nv.x;
-                ra[q + 1] = (lane == q + 1 ? fma(si * sj.y, eps, 1.0) : 0.0) + a1 - nv.y;
+                ra[q] = (lane == q ? fma(si * sj.x, eps, one) : 0.0) + a0 - nv.x;
+                ra[q + 1] = (lane == q + 1 ? fma(si * sj.y, eps, one) : 0.0) + a1 - nv.y;
                 rx[q] = (lane == col0 + q ? 1.0 : 0.0) - (lane < col0 ? mv.x : 0.0);
                 rx[q + 1] = (lane == col0 + q + 1 ? 1.0 : 0.0) - (lane < col0 ? mv.y : 0.0);
             }
@@ -137,7 +144,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                 for (int t = 0; t < E; ++t) {  // tail columns: N from ntail[t][row], M from mt[t]
                     const double sj = sv[TB + t];
                     const double nv = ntail[t * 64 + (i < 64 ? i : 63)];
-                    ra[16 + t] = (lane == 16 + t ? fma(si * sj, eps, 1.0) : 0.0) + (si * sj) * pk[-16 - t] - nv;
+                    ra[16 + t] = (lane == 16 + t ? fma(si * sj, eps, one) : 0.0) + (si * sj) * pk[-16 - t] - nv;
                     rx[16 + t] = (lane == TB + t ? 1.0 : 0.0) - mt[t];
                 }
             }
@@ -155,6 +162,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
         {
             double* Ld = buf;  // rows of the diagonal block (lanes < W), stride LDD; the panel buffer is free meanwhile
             constexpr int LDD = (WL + 1) & ~1;
+            double yprod = 1.0;  // KMODE: product of the reciprocal pivots of this panel
 #pragma unroll
             for (int j = 0; j < WL; ++j) {
                 if (j < W) {
@@ -193,6 +201,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     y = fma(y * 0.5, e, y);
                     ra[j] *= y;
                     rx[j] *= y;
+                    if (KMODE) yprod *= y;
                     asm volatile("" : "+v"(ra[j]), "+v"(rx[j]));
                     if (j + 1 < W) {
                         if (lane < W) Ld[lane * LDD + j] = ra[j];
@@ -201,6 +210,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (KMODE) logdet -= log(yprod);  // log det chol(K) = -sum log(1 / L_jj)
         }
         // ---- 4. finished rows back to LDS (block rows for the operands, tail rows for the dot products) ----
         if (!last && lane >= 16 && lane < rowsA) {
@@ -295,6 +305,34 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (KMODE) {
+        // ---- K^-1 = P as a full symmetric matrix in LDS ----
+#pragma unroll
+        for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+            for (int bi = bj; bi < NB; ++bi)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int i = 16 * bi + g + 4 * p, j = 16 * bj + c;
+                    kl[i * ldk + j] = P[bi][bj][p];
+                    if (bi != bj) kl[j * ldk + i] = P[bi][bj][p];
+                }
+        if (E > 0) {
+#pragma unroll
+            for (int t = 0; t < E; ++t) {
+                double p = 0.0;
+#pragma unroll
+                for (int u = t; u < E; ++u) p = fma(rx[16 + u], tri_readlane(rx[16 + u], TB + t), p);
+                if (lane < TP) {
+                    kl[lane * ldk + TB + t] = p;
+                    kl[(TB + t) * ldk + lane] = p;
+                }
+            }
+        }
+        tr = logdet;
+        cs = 0.0;
+        return true;
+    }
     // ---- weighted sums over A^-1: block part from P (lower blocks; off-diagonal blocks count twice) ----
     tr = 0.0;
     cs = 0.0;
@@ -335,4 +373,54 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
     }
     cs = fma(2.0, cs, cd);
     return true;  // a pivot that is not positive and finite turns tr and cs into NaN (the caller checks)
+}
+
+
+// The traces of the K block against the second moments C = sum_i mu_i mu_i' of one latent, on the matrix pipe:
+//     quad = tr(K^-1 C),   gq = tr(K^-1 dK K^-1 C) = <C K^-1, K^-1 dK>_F
+// with K^-1 in LDS (`kl`, full symmetric, stride ldk = 2 mod 4), C in global memory (TP x TP, zero beyond the rows
+// present) and dK Toeplitz from its first column `dkv` (zero beyond tr).  Wave `wid` of `nwv` takes the 16-row
+// block rows wid, wid + nwv, ...; returns this wave's partial sums (per lane; the caller reduces over the wave).
+template <int TP>
+__device__ __forceinline__ void hstep_kblock_products(const double* kl, int ldk, const double* __restrict__ C,
+                                                      const double* dkv, int tr_k, int lane, int wid, int nwv,
+                                                      double& quad, double& gq) {
+    constexpr int NBK = (TP + 15) / 16, NK = (TP + 3) / 4;
+    const int c = lane & 15, g = lane >> 4;
+    quad = 0.0;
+    gq = 0.0;
+    for (int a = wid; a < NBK; a += nwv) {
+        hm_d4 Eb[NBK], Gb[NBK];
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            Eb[b] = hm_d4{0.0, 0.0, 0.0, 0.0};
+            Gb[b] = hm_d4{0.0, 0.0, 0.0, 0.0};
+        }
+        const int ra_ = 16 * a + c;  // operand row of this lane
+        const bool rin = ra_ < TP;
+#pragma unroll 2
+        for (int kk = 0; kk < NK; ++kk) {
+            const int kcol = 4 * kk + g;
+            const bool kin = kcol < TP;
+            const double opC = (rin && kin) ? C[ra_ * TP + kcol] : 0.0;
+            const double opKa = (rin && kin) ? kl[ra_ * ldk + kcol] : 0.0;
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                const int rb_ = 16 * b + c;
+                const bool bin = rb_ < TP && kin;
+                const double opKb = bin ? kl[rb_ * ldk + kcol] : 0.0;
+                const int dd = kcol - rb_;
+                const double opD = (bin && kcol < tr_k && rb_ < tr_k) ? dkv[dd < 0 ? -dd : dd] : 0.0;
+                Eb[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(opC, opKb, Eb[b], 0, 0, 0);
+                Gb[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(opKa, opD, Gb[b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                gq = fma(Eb[b][p], Gb[b][p], gq);
+                if (b == a && g + 4 * p == c) quad += Eb[b][p];
+            }
+    }
 }
