@@ -1297,8 +1297,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
         return vlgp_fail(ctx, VLGP_ERR_STATE, "H-step needs every unit to have exactly window=%d rows", T);
     // the T = 50 kernels, identity-padded; below ~half the compiled size the padding costs more than the
     // generic kernels (measured: window 25 14 vs 24 ms per H-step, window 20 21 vs 13 ms)
-    const bool fast = T <= 50 && T >= 24 && !getenv("VLGP_HSTEP_GENERIC");
-    const int64_t TT = fast ? 2500 : (int64_t)T * T;
+    // windows 24..50 run the kernels compiled for 50, 51..64 those compiled for 64 (matrix-pipe round only)
+    const bool old_kernels = getenv("VLGP_HSTEP_UNFUSED") || getenv("VLGP_HSTEP_PADDED") || getenv("VLGP_HSTEP_LEAN");
+    const bool fast = T <= (old_kernels ? 50 : 64) && T >= 24 && !getenv("VLGP_HSTEP_GENERIC");
+    const int TC = T <= 50 ? 50 : 64;  // compiled window
+    const int64_t TT = fast ? (int64_t)TC * TC : (int64_t)T * T;
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
     const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
@@ -1337,7 +1340,8 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                 memset(ctx->h_hres, 0, 64 * sizeof(double));
                 HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_hres), ctx->h_hres, 0));
             }
-            constexpr int HT = 50, NCH = 64;
+            const int HT = TC;
+            constexpr int NCH = 64;
             if (!ctx->d_hmom || ctx->hmom_len < (int64_t)L * HT * HT) {
                 if (ctx->d_hmom) HIPCHK(ctx, hipFree(ctx->d_hmom));
                 ctx->d_hmom = nullptr;
@@ -1347,8 +1351,12 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             }
             if (!ctx->hmom_bracket || ctx->hmom_us != &us || ctx->hmom_T != T) {
                 // second moments of mu: once per vlgp_hstep_begin bracket, else per call
-                hipLaunchKernelGGL((hstep_moment_kernel<HT>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T, us.d_off,
-                                   us.mu, NCH, W + o_mpart);
+                if (HT == 50)
+                    hipLaunchKernelGGL((hstep_moment_kernel<50>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
+                                       us.d_off, us.mu, NCH, W + o_mpart);
+                else
+                    hipLaunchKernelGGL((hstep_moment_kernel<64>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
+                                       us.d_off, us.mu, NCH, W + o_mpart);
                 hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, ctx->stream, NCH,
                                    HT * HT, W + o_mpart, ctx->d_hmom);
                 HIPCHK(ctx, hipGetLastError());
@@ -1374,8 +1382,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else if (lean)
                 hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
-            else
+            else if (TC == 50)
                 hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
+                                   ctx->stream, R);
+            else
+                hipLaunchKernelGGL((hstep_round_mfma<64, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
                                    ctx->stream, R);
             vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
             HIPCHK(ctx, hipGetLastError());
