@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-trials", type=int, default=12)
+    ap.add_argument("--kernel-steps", type=int, default=6,
+                    help="extra EM iterations after the timed region, M-step serialised, for the per-kernel timings")
     args = ap.parse_args()
 
     import vlgp_amd
@@ -208,10 +210,36 @@ def main():
     kinds = (("estep", _lib.PROF_ESTEP), ("mstep", _lib.PROF_MSTEP), ("hstep", _lib.PROF_HSTEP),
              ("prior", _lib.PROF_PRIOR), ("estep_ra16", _lib.PROF_ESTEP_RA16), ("estep_ra24", _lib.PROF_ESTEP_RA24),
              ("estep_ra32", _lib.PROF_ESTEP_RA32), ("estep_long", _lib.PROF_ESTEP_LONG),
-             ("estep_generic", _lib.PROF_ESTEP_GENERIC))
-    prof = {k: eng.profile_get(i) for k, i in kinds}
-    eng.profile(False)
+             ("estep_generic", _lib.PROF_ESTEP_GENERIC), ("estep_pass", _lib.PROF_ESTEP_PASS),
+             ("estep_factor", _lib.PROF_ESTEP_FACTOR), ("estep_mean", _lib.PROF_ESTEP_MEAN))
+    prof_live = {k: eng.profile_get(i) for k, i in kinds}
+    # Kernel-timing pass.  In the timed region the M-step lane runs beside the H-step rounds: a HIP-event pair
+    # then brackets the dispatch arbitration between the two lanes as well as the kernel (both lanes are
+    # throughput-bound, each kernel appears ~1.3-2x longer than it runs alone; rocprofv3 serialises the lanes and
+    # reports the stand-alone durations).  The per-kernel figures below therefore come from extra EM iterations
+    # run right after the timed region with the M-step serialised (VLGP_M_SEQUENTIAL), same data, same state;
+    # the overlapped averages of the timed region are kept as avg_ms_overlapped.  `value` is untouched by this.
     rt = sess.runtime
+    n_timed_iters = len(rt["em_elapsed"])
+    prof = prof_live
+    k_steps, k_ranks = args.steps, ranks_per_step
+    kernel_timing = "HIP events inside the timed region"
+    if world == 1 and args.kernel_steps > 0:
+        os.environ["VLGP_M_SEQUENTIAL"] = "1"
+        eng.profile_reset()
+        sess.config["max_iter"] = sess.config["min_iter"] = total_iters + args.kernel_steps
+        ranks_kernel = []
+        for _ in range(args.kernel_steps):
+            ranks_kernel.append([int(r) for r in eng.prior_ranks(cfg["window"])])
+            sess.em_iteration()
+        eng.synchronize()
+        prof = {k: eng.profile_get(i) for k, i in kinds}
+        k_steps, k_ranks = args.kernel_steps, ranks_kernel
+        kernel_timing = ("HIP events over %d EM iterations run right after the timed region with the M-step lane serialised "
+                         "(in the timed region the two lanes overlap and an event pair also brackets their dispatch "
+                         "arbitration; that figure is avg_launch_ms_overlapped_in_timed_region)" % args.kernel_steps)
+        os.environ.pop("VLGP_M_SEQUENTIAL", None)
+    eng.profile(False)
     timed = slice(args.warmup, args.warmup + args.steps)
     phase_ms = {k: 1e3 * float(np.mean(rt[k + "_elapsed"][timed])) for k in ("e", "m", "h", "em")}
     omega = np.array(sess.params["omega"]).tolist()
@@ -239,23 +267,56 @@ def main():
     # reference's fixed rank 50 (what a dense rank-50 implementation would have to do).
     seg_local = n_seg_local
     by_ra = {16: [], 24: [], 32: []}
-    for rk in ranks_per_step:
+    for rk in k_ranks:
         rmax = max(rk)
         by_ra[16 if rmax <= 16 else (24 if rmax <= 24 else 32)].append(rk)
+    split = prof["estep_pass"][0] > 0   # the E-step ran as a sequence of chip-wide launches (estep_split.hip)
     for ra, key in ((16, "estep_ra16"), (24, "estep_ra24"), (32, "estep_ra32")):
         n_e, ms_e, u_e = prof[key]
         if not n_e:
             continue
-        rks = by_ra[ra] or ranks_per_step
+        rks = by_ra[ra] or k_ranks
         exe = float(np.mean([estep_flops(T, N, L, rk) for rk in rks])) * u_e / n_e
         nom = estep_flops(T, N, L, [50] * L) * u_e / n_e
-        name = "estep_fast_kernel<%d, %d, %d>" % (LT, 16 if ra == 16 else 32, ra)
+        if split:
+            name = "E-step call, max rank <= %d (sequence of esplit_* launches, one HIP-event pair around all of them)" % ra
+        else:
+            name = "estep_fast_kernel<%d, %d, %d>" % (LT, 16 if ra == 16 else 32, ra)
         kernels[name] = entry(n_e, ms_e, exe, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_e / n_e,
                               flops_per_launch_executed=exe, flops_per_launch_nominal_rank50=nom,
                               achieved_nominal_rank50=nom / (ms_e / n_e * 1e-3) / 1e12,
                               frac_nominal_rank50=nom / (ms_e / n_e * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                               mean_effective_ranks=np.mean(np.array(rks, dtype=float), axis=0).round(2).tolist(),
-                              pmc_key=name)
+                              pmc_key=name, per_step_ms=ms_e / k_steps)
+        if split:
+            kernels[name]["sequence"] = True   # not a single kernel: never the "dominant kernel"
+    if split:
+        # the launches of one sweep per E-step call carry their own event pairs (sampled inside the timed region)
+        sweeps = cfg["Eniter"] if "Eniter" in cfg else 25
+        rk_mean = np.mean(np.array(k_ranks, dtype=float), axis=0)
+        ra_typ = max(by_ra, key=lambda k: len(by_ra[k]))  # the instantiation most E-step calls used
+        n_p, ms_p, u_p = prof["estep_pass"]
+        fl = 6.0 * L * N * u_p / n_p  # 12 T L N per unit-sweep for the two passes
+        kernels["esplit_pass<%d>" % LT] = entry(
+            n_p, ms_p, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_p / n_p,
+            flops_per_launch_executed=fl, sampled="one residual and one curvature pass per E-step call",
+            per_step_ms=ms_p / n_p * 2 * sweeps, pmc_key="esplit_pass<%d, 1, false>" % LT,
+            note="lane <-> row, all channels per lane; the count leaves out the exp (about as many flops again)")
+        n_f, ms_f, u_f = prof["estep_factor"]
+        if n_f:
+            fl = float(np.mean([5.0 * T * r * r + 2.0 / 3.0 * r ** 3 for r in rk_mean])) * u_f / n_f
+            kernels["esplit_latent<factor>"] = entry(
+                n_f, ms_f, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_f / n_f,
+                flops_per_launch_executed=fl, sampled="one launch per E-step call",
+                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_latent<%d, false>" % ra_typ,
+                note="one wave per (unit, latent): I + G'WG (MFMA), factor + inverse, variance; latency-bound chains")
+        n_u, ms_u, u_u = prof["estep_mean"]
+        if n_u:
+            fl = float(np.mean([8.0 * T * r for r in rk_mean])) * u_u / n_u
+            kernels["esplit_latent<mean>"] = entry(
+                n_u, ms_u, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_u / n_u,
+                flops_per_launch_executed=fl, sampled="one launch per E-step call",
+                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_latent<%d, true>" % ra_typ)
     n_m, ms_m, u_m = prof["mstep"]
     if n_m:
         fl = work["mstep_flops_per_row"] * u_m / n_m
@@ -264,16 +325,21 @@ def main():
             flops_per_launch_executed=fl,
             bytes_per_launch_streamed=work["mstep_bytes_per_row_kernel"] * u_m / n_m,
             bytes_per_launch_survey_count=work["mstep_bytes_per_row_survey"] * u_m / n_m,
-            pmc_key="mstep_accum<%d, 1, 1>" % LT,
+            pmc_key="mstep_accum<%d, 1, 1>" % LT, per_step_ms=ms_m / k_steps,
+            avg_ms_overlapped=(prof_live["mstep"][1] / prof_live["mstep"][0]) if prof_live["mstep"][0] else None,
             note="compute-bound (exp + FMA per (row, channel)); y is read once per M-step by the PREP pass, "
                  "each Newton launch streams only mu, v")
     n_h, ms_h, u_h = prof["hstep"]
     if n_h:
         fl = work["hstep_flops_per_seg_eval"] * u_h / n_h
-        kernels["hstep_round_lean<50>"] = entry(
+        hname = "hstep_round_lean<50>" if os.environ.get("VLGP_HSTEP_LEAN") else "hstep_round_mfma<%d, 4>" % (50 if T <= 50 else 64)
+        kernels[hname] = entry(
             n_h, ms_h, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_h / n_h,
             flops_per_launch_executed=fl, bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_h / n_h,
-            pmc_key="hstep_round_lean<50>")
+            pmc_key=hname, per_step_ms=ms_h / k_steps,
+            avg_ms_overlapped=(prof_live["hstep"][1] / prof_live["hstep"][0]) if prof_live["hstep"][0] else None,
+            note="algorithmic count M (T^3 + 4 T^2) per evaluation (SURVEY 8d); the matrix-pipe kernel issues 78 "
+                 "v_mfma_f64_16x16x4 = 160 kflop per segment plus the panel eliminations")
     n_p, ms_p, u_p = prof["prior"]
     if n_p:
         kernels["ichol_exact_kernel"] = {"launches": n_p, "avg_ms": ms_p / n_p, "total_ms": ms_p,
@@ -286,8 +352,8 @@ def main():
             kd["hbm_bytes_per_launch_pmc"] = tb
             kd["hbm_gbs"] = tb / (kd["avg_ms"] * 1e-3) / 1e9
             kd["hbm_frac"] = kd["hbm_gbs"] / HBM_PEAK_GBS
-    timed_kernels = {k: v for k, v in kernels.items() if "achieved" in v}
-    dominant = max(timed_kernels, key=lambda k: timed_kernels[k]["total_ms"]) if timed_kernels else None
+    timed_kernels = {k: v for k, v in kernels.items() if "achieved" in v and not v.get("sequence")}
+    dominant = max(timed_kernels, key=lambda k: timed_kernels[k].get("per_step_ms", 0.0)) if timed_kernels else None
     roofline = None
     if dominant:
         kd = kernels[dominant]
@@ -297,7 +363,9 @@ def main():
                     "hbm_gbs": kd.get("hbm_gbs"), "hbm_frac": kd.get("hbm_frac"),
                     "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"],
                     "units_per_launch": kd["units_per_launch"],
-                    "algorithmic_flops_per_launch": kd["flops_per_launch_executed"]}
+                    "algorithmic_flops_per_launch": kd["flops_per_launch_executed"],
+                    "avg_launch_ms_overlapped_in_timed_region": kd.get("avg_ms_overlapped"),
+                    "timing": kernel_timing}
 
     out = {
         "metric": "EM iterations/sec", "value": args.steps / elapsed, "unit": "EM it/s",

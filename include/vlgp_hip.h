@@ -222,7 +222,10 @@ int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n);
 #define VLGP_PROF_ESTEP_RA32 6
 #define VLGP_PROF_ESTEP_LONG 7
 #define VLGP_PROF_ESTEP_GENERIC 8
-#define VLGP_PROF_KINDS 9
+#define VLGP_PROF_ESTEP_PASS 9     /* split E-step: one (T x N) pass over all rows (sampled: one sweep per call) */
+#define VLGP_PROF_ESTEP_FACTOR 10  /* split E-step: factor + variance launch, units = (unit, latent) tasks */
+#define VLGP_PROF_ESTEP_MEAN 11    /* split E-step: mean-update launch, units = (unit, latent) tasks */
+#define VLGP_PROF_KINDS 12
 int vlgp_profile_enable(vlgp_ctx* ctx, int on);
 int vlgp_profile_reset(vlgp_ctx* ctx);
 /* launches, total milliseconds and work units recorded for `kind` since the last

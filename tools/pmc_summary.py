@@ -8,7 +8,7 @@ import collections, csv, json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fetch_csv, write_csv = sys.argv[1], sys.argv[2]
-out_path = os.path.join(root, "profiles", "r1", "pmc_summary.json") if len(sys.argv) < 4 else sys.argv[3]
+out_path = os.path.join(root, "profiles", "r2", "pmc_summary.json") if len(sys.argv) < 4 else sys.argv[3]
 
 
 def collect(path, name):

@@ -99,14 +99,18 @@ void vlgp_prof_begin(vlgp_ctx* ctx, int kind, hipStream_t st) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     (void)hipEventRecord(a, st ? st : ctx->stream);
-    ctx->pending.push_back({kind, a, b, 0.0});
+    ctx->pending.push_back({kind, a, b, 0.0, false});
 }
 void vlgp_prof_end(vlgp_ctx* ctx, int kind, double units, hipStream_t st) {
-    if (!ctx->prof_on || ctx->pending.empty()) return;
-    auto& p = ctx->pending.back();
-    if (p.kind != kind) return;
-    p.units = units;
-    (void)hipEventRecord(p.b, st ? st : ctx->stream);
+    if (!ctx->prof_on) return;
+    // brackets nest (a whole E-step around the sampled launches inside it): close the innermost open one of this kind
+    for (auto it = ctx->pending.rbegin(); it != ctx->pending.rend(); ++it) {
+        if (it->kind != kind || it->done) continue;
+        it->units = units;
+        it->done = true;
+        (void)hipEventRecord(it->b, st ? st : ctx->stream);
+        return;
+    }
 }
 static void prof_drain(vlgp_ctx* ctx) {
     if (ctx->pending.empty()) return;
@@ -114,7 +118,7 @@ static void prof_drain(vlgp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->mstream);
     for (auto& p : ctx->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (p.done && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ctx->prof[p.kind].launches += 1;
             ctx->prof[p.kind].ms += ms;
             ctx->prof[p.kind].units += p.units;

@@ -107,7 +107,7 @@ struct vlgp_ctx {
     bool prof_on = false;
     ProfSlot prof[VLGP_PROF_KINDS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    struct PendingProf { int kind; hipEvent_t a, b; double units; };
+    struct PendingProf { int kind; hipEvent_t a, b; double units; bool done; };
     std::vector<PendingProf> pending;
 
     // RCCL

@@ -709,13 +709,22 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     for (int it = (mode & EM_FACTOR0) ? -1 : 0; it < n_it && rc == VLGP_OK; ++it) {
         const bool last = it == n_it - 1;
         bool do_factor, do_v;
+        // per-kernel timing: the launches of ONE sweep per call are bracketed (events on every launch would cost
+        // more than they measure)
+        const bool sample = ctx->prof_on && it == (n_it > 1 ? 1 : 0);
         if (it >= 0) {
             if (with_mean) {
+                if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS);
                 rc = run_pass(ctx, A, LT, SP_RES, cols);
+                if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, (double)us.rows);
                 A.last = last ? 1 : 0;
+                if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_MEAN);
                 if (rc == VLGP_OK) rc = run_latent(ctx, A, maxra, true);
+                if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_MEAN, (double)us.M * L);
             }
+            if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS);
             if (rc == VLGP_OK) rc = run_pass(ctx, A, LT, SP_W, cols);
+            if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, (double)us.rows);
             do_factor = with_mean && (E.vb || !last);
             do_v = E.vb != 0;
         } else {
@@ -724,7 +733,9 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         }
         if (do_factor && rc == VLGP_OK) {
             A.do_v = do_v ? 1 : 0;
+            if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_FACTOR);
             rc = run_latent(ctx, A, maxra, false);
+            if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_FACTOR, (double)us.M * L);
         }
     }
     vlgp_prof_end(ctx, kind, (double)us.M * (E.n_iter > 0 ? E.n_iter : 1));
