@@ -46,7 +46,8 @@ struct SplitArgs {
     double *mu, *v, *w, *dmu;
     double *ra, *ya;   // (rows, L)
     double* xg;        // (M L, pkg): packed X = chol(I + G'WG)^-1 per (unit, latent)
-    int pkg;
+    int pkg;           // stride of xg
+    int pkl;           // doubles of LDS per wave for the packed X of this launch's rank class
     int* failg;        // (M L): 1 = the factor of this (unit, latent) failed
     int* fail;
     const double* wconst;
@@ -54,6 +55,8 @@ struct SplitArgs {
     int np, ntot;      // Poisson channels, all channels
     int lds_g;         // doubles of LDS per wave for the G tile
     int do_v, last;
+    int n_lat;         // latents covered by this launch (tasks = M n_lat)
+    int lat[8];        // their indices
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -207,9 +210,9 @@ struct Task {
 __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int lane) {
     const int wid = threadIdx.x >> 6;
     const int task = blockIdx.x * (blockDim.x >> 6) + wid;
-    if (task >= A.M * A.L) return false;
-    K.m = task / A.L;
-    K.l = task - K.m * A.L;
+    if (task >= A.M * A.n_lat) return false;
+    K.m = task / A.n_lat;
+    K.l = A.lat[task - K.m * A.n_lat];
     K.r0 = A.off[K.m];
     K.T = (int)(A.off[K.m + 1] - K.r0);
     const int pidx = A.unit_prior[K.m];
@@ -217,7 +220,7 @@ __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* 
     K.rs = (K.r + 1) & ~1;
     K.Gl = A.prior_base[pidx] + A.prior_goff[pidx * A.L + K.l];
     K.Xl = lds_wave;
-    K.tile = K.Xl + A.pkg;
+    K.tile = K.Xl + A.pkl;
     K.gcap = A.lds_g;
     K.vec = K.tile + A.lds_g + 128;  // mean kernel only
     K.u = K.vec + 128;
@@ -566,7 +569,7 @@ template <int MAXRA, bool MEAN>
 __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    double* lds_wave = smem + (int64_t)wid * (A.pkg + A.lds_g + 128 + (MEAN ? 192 : 0));
+    double* lds_wave = smem + (int64_t)wid * (A.pkl + A.lds_g + 128 + (MEAN ? 192 : 0));
     Task K;
     if (!task_setup(A, K, lds_wave, lane)) return;
     if constexpr (MEAN) {
@@ -613,10 +616,11 @@ int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* 
     return run_passes<8>(ctx, A, kind, cols);
 }
 
-int run_latent(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
-    const int tasks = A.M * A.L;
+int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
+    const int tasks = A.M * A.n_lat;
+    if (tasks == 0) return VLGP_OK;
     const dim3 grid((unsigned)((tasks + 3) / 4)), blk(256);
-    const size_t lds = (size_t)4 * (A.pkg + A.lds_g + 128 + (mean ? 192 : 0)) * 8;
+    const size_t lds = (size_t)4 * (A.pkl + A.lds_g + 128 + (mean ? 192 : 0)) * 8;
     hipStream_t st = ctx->stream;
 #define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
     do {                                                                                                              \
@@ -634,6 +638,33 @@ int run_latent(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     return VLGP_OK;
 }
 
+// One launch per rank class: the latents of rank <= 16 run the lean instantiation (staged G, small LDS footprint),
+// the others the mixed one -- a single latent above 16 slows its own waves only.
+struct LatentClasses {
+    int n_lo = 0, lo[8];
+    int n_hi = 0, hi[8];
+    int maxra_hi = 16;
+    int lds_g_lo = 256;
+};
+
+int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
+    if (C.n_hi) {  // the long tasks first
+        A.n_lat = C.n_hi;
+        for (int i = 0; i < C.n_hi; ++i) A.lat[i] = C.hi[i];
+        A.pkl = tri_packed_size(C.maxra_hi <= 24 ? 24 : 32);
+        A.lds_g = 256;
+        CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
+    }
+    if (C.n_lo) {
+        A.n_lat = C.n_lo;
+        for (int i = 0; i < C.n_lo; ++i) A.lat[i] = C.lo[i];
+        A.pkl = tri_packed_size(16);
+        A.lds_g = C.lds_g_lo;
+        CHK(run_latent_class(ctx, A, 16, mean));
+    }
+    return VLGP_OK;
+}
+
 }  // namespace
 
 int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
@@ -647,15 +678,24 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     if (!(sw && sw[0] == '1') && (us.rows < 64LL * 1024 || us.M < 2 * ctx->n_cu)) return VLGP_OK;
     const bool need_prior = (E.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
     int rmax = 0;
-    int64_t gw = 0;  // doubles of G per (unit, latent)
+    int rlat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // largest rank of each latent over the priors this set uses
+    int64_t gw_lo = 0;                       // doubles of staged G per (unit, latent) among the rank <= 16 latents
     if (need_prior) {
         for (auto& kv : ctx->priors) {
             const Prior& pr = kv.second;
             if (pr.T < us.Tmin || pr.T > us.Tmax) continue;
             for (int l = 0; l < L; ++l) {
                 rmax = pr.rl[l] > rmax ? pr.rl[l] : rmax;
+                rlat[l] = pr.rl[l] > rlat[l] ? pr.rl[l] : rlat[l];
+            }
+        }
+        for (auto& kv : ctx->priors) {
+            const Prior& pr = kv.second;
+            if (pr.T < us.Tmin || pr.T > us.Tmax) continue;
+            for (int l = 0; l < L; ++l) {
+                if (rlat[l] > 16) continue;
                 const int64_t g = (int64_t)pr.T * ((pr.rl[l] + 1) & ~1);
-                gw = g > gw ? g : gw;
+                gw_lo = g > gw_lo ? g : gw_lo;
             }
         }
     }
@@ -693,8 +733,15 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.wconst = wconst;
     A.dmu_bound = E.dmu_bound;
     A.ntot = N; A.np = N - ctx->n_gauss;
-    A.lds_g = (int)((gw + 1) & ~1LL);  // staged G of a rank <= 16 latent (and the 16 x 16 staging tile)
-    if (maxra > 16 || A.lds_g < 256) A.lds_g = 256;  // mixed-rank launches read G from global memory
+    LatentClasses C;
+    for (int l = 0; l < L; ++l) {
+        if (rlat[l] <= 16) C.lo[C.n_lo++] = l;
+        else C.hi[C.n_hi++] = l;
+    }
+    C.maxra_hi = maxra;
+    C.lds_g_lo = (int)((gw_lo + 1) & ~1LL);  // staged G of a rank <= 16 latent (and the 16 x 16 staging tile)
+    if (C.lds_g_lo < 256) C.lds_g_lo = 256;
+    A.lds_g = 256; A.pkl = pkg; A.n_lat = 0;
     A.do_v = 0; A.last = 0;
     *handled = 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
@@ -719,7 +766,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
                 if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, (double)us.rows);
                 A.last = last ? 1 : 0;
                 if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_MEAN);
-                if (rc == VLGP_OK) rc = run_latent(ctx, A, maxra, true);
+                if (rc == VLGP_OK) rc = run_latent(ctx, A, C, true);
                 if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_MEAN, (double)us.M * L);
             }
             if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS);
@@ -734,7 +781,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         if (do_factor && rc == VLGP_OK) {
             A.do_v = do_v ? 1 : 0;
             if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_FACTOR);
-            rc = run_latent(ctx, A, maxra, false);
+            rc = run_latent(ctx, A, C, false);
             if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_FACTOR, (double)us.M * L);
         }
     }
