@@ -45,5 +45,5 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);
 int launch_estep_long(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);
 
 // estep_split.hip: many window-sized units as a sequence of chip-wide launches (passes over rows, one wave per
-// (unit, latent) for the factor and mean phases); declines for small sets, T > 64, rank > 32 or L > 8.
+// (unit, latent) for the factor and mean phases); declines for small sets, T > 64, rank > 32 or L > 10.
 int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled);

@@ -56,7 +56,7 @@ struct SplitArgs {
     int lds_g;         // doubles of LDS per wave for the G tile
     int do_v, last;
     int n_lat;         // latents covered by this launch (tasks = M n_lat)
-    int lat[8];        // their indices
+    int lat[16];       // their indices
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -613,7 +613,8 @@ int run_passes(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) 
 int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* cols) {
     if (LT == 3) return run_passes<3>(ctx, A, kind, cols);
     if (LT == 5) return run_passes<5>(ctx, A, kind, cols);
-    return run_passes<8>(ctx, A, kind, cols);
+    if (LT == 8) return run_passes<8>(ctx, A, kind, cols);
+    return run_passes<10>(ctx, A, kind, cols);
 }
 
 int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
@@ -641,8 +642,8 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
 // One launch per rank class: the latents of rank <= 16 run the lean instantiation (staged G, small LDS footprint),
 // the others the mixed one -- a single latent above 16 slows its own waves only.
 struct LatentClasses {
-    int n_lo = 0, lo[8];
-    int n_hi = 0, hi[8];
+    int n_lo = 0, lo[16];
+    int n_hi = 0, hi[16];
     int maxra_hi = 16;
     int lds_g_lo = 256;
 };
@@ -673,12 +674,12 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     const char* sw = getenv("VLGP_ESTEP_SPLIT");
     if (sw && sw[0] == '0') return VLGP_OK;
     if (getenv("VLGP_ESTEP_GENERIC")) return VLGP_OK;
-    if (us.Tmax > 64 || L > 8 || N > 1024) return VLGP_OK;
+    if (us.Tmax > 64 || L > 10 || N > 1024) return VLGP_OK;
     // the persistent kernel wins while a launch cannot fill the chip (its cost is latency, not throughput)
     if (!(sw && sw[0] == '1') && (us.rows < 64LL * 1024 || us.M < 2 * ctx->n_cu)) return VLGP_OK;
     const bool need_prior = (E.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
     int rmax = 0;
-    int rlat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // largest rank of each latent over the priors this set uses
+    int rlat[16] = {0};  // largest rank of each latent over the priors this set uses
     int64_t gw_lo = 0;                       // doubles of staged G per (unit, latent) among the rank <= 16 latents
     if (need_prior) {
         for (auto& kv : ctx->priors) {
@@ -701,7 +702,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     }
     if (rmax > 32) return VLGP_OK;
     const int maxra = rmax <= 16 ? 16 : (rmax <= 24 ? 24 : 32);
-    const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : 8);
+    const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : 10));
     const int REC = (2 * LT + 3 + 1) & ~1;
     const int pkg = tri_packed_size(maxra);
     // scratch of the set: ra | ya | xg | failg(int) ; records + wconst in ctx->d_ecols

@@ -163,47 +163,66 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
             double* Ld = buf;  // rows of the diagonal block (lanes < W), stride LDD; the panel buffer is free meanwhile
             constexpr int LDD = (WL + 1) & ~1;
             double yprod = 1.0;  // KMODE: product of the reciprocal pivots of this panel
+            // pre[]: multipliers L[j + 1][0 .. j - 2] for the lazy update of step j, fetched one step EARLIER (they
+            // were final by then): no LDS latency inside a step; L[j + 1][j - 1], one step old, comes by v_readlane
+            double pre[WL];
+#pragma unroll
+            for (int q = 0; q < WL; ++q) pre[q] = 0.0;
 #pragma unroll
             for (int j = 0; j < WL; ++j) {
                 if (j < W) {
+                    double cur[WL];
+#pragma unroll
+                    for (int q = 0; q < WL; ++q) cur[q] = pre[q];
+                    if (j + 2 < W && j >= 1) {  // for step j + 1: row j + 2, entries 0 .. j - 1
+                        const double* row = Ld + (j + 2) * LDD;
+#pragma unroll
+                        for (int m = 0; m + 1 < j; m += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(row + m);
+                            pre[m] = v.x;
+                            pre[m + 1] = v.y;
+                        }
+                        if (j & 1) pre[j - 1] = row[j - 1];
+                    }
+                    double lv2 = 0.0;
                     if (j > 0) {
                         const double lv = tri_readlane(ra[j - 1], j);
                         ra[j] = fma(-ra[j - 1], lv, ra[j]);
                         rx[j] = fma(-rx[j - 1], lv, rx[j]);
+                        if (j + 1 < W) lv2 = tri_readlane(ra[j - 1], j + 1);
                     }
                     const double d = tri_readlane(ra[j], j);
                     double y = __builtin_amdgcn_rsq(d);
                     if (j + 1 < W && j >= 1) {  // column j + 1 <- columns 0 .. j - 1
-                        const double* row = Ld + (j + 1) * LDD;
                         double a0 = ra[j + 1], a1 = 0.0, x0 = rx[j + 1], x1 = 0.0;
 #pragma unroll
-                        for (int m = 0; m + 1 < j; m += 2) {
-                            const double2 v = *reinterpret_cast<const double2*>(row + m);
-                            a0 = fma(-ra[m], v.x, a0);
-                            a1 = fma(-ra[m + 1], v.y, a1);
-                            x0 = fma(-rx[m], v.x, x0);
-                            x1 = fma(-rx[m + 1], v.y, x1);
+                        for (int m = 0; m + 1 < j - 1; m += 2) {
+                            a0 = fma(-ra[m], cur[m], a0);
+                            a1 = fma(-ra[m + 1], cur[m + 1], a1);
+                            x0 = fma(-rx[m], cur[m], x0);
+                            x1 = fma(-rx[m + 1], cur[m + 1], x1);
                         }
-                        if (j & 1) {
-                            const double v = row[j - 1];
-                            a0 = fma(-ra[j - 1], v, a0);
-                            x0 = fma(-rx[j - 1], v, x0);
+                        if (j >= 2 && ((j - 1) & 1)) {
+                            a0 = fma(-ra[j - 2], cur[j - 2], a0);
+                            x0 = fma(-rx[j - 2], cur[j - 2], x0);
                         }
+                        a1 = fma(-ra[j - 1], lv2, a1);
+                        x1 = fma(-rx[j - 1], lv2, x1);
                         ra[j + 1] = a0 + a1;
                         rx[j + 1] = x0 + x1;
                         // evaluate the X' half HERE: unpinned, the compiler sinks the whole rx chain below the panel
                         // and carries every multiplier to it through scratch
                         asm volatile("" : "+v"(ra[j + 1]), "+v"(rx[j + 1]));
                     }
-                    double e = fma(-d * y, y, 1.0);
-                    y = fma(y * 0.5, e, y);
-                    e = fma(-d * y, y, 1.0);
-                    y = fma(y * 0.5, e, y);
+                    {   // one third-order step: y (1 + e / 2 + 3 e^2 / 8), e = 1 - d y^2 (v_rsq_f64 starts at ~2^-26)
+                        const double e = fma(-d * y, y, 1.0);
+                        y = fma(y * e, fma(0.375, e, 0.5), y);
+                    }
                     ra[j] *= y;
                     rx[j] *= y;
                     if (KMODE) yprod *= y;
                     asm volatile("" : "+v"(ra[j]), "+v"(rx[j]));
-                    if (j + 1 < W) {
+                    if (j + 2 < W) {
                         if (lane < W) Ld[lane * LDD + j] = ra[j];
                         tri_wave_order();
                     }
