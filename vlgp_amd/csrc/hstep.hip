@@ -1142,9 +1142,10 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) hstep_round_mfma(HRo
                 const double d = lane * A.dt, d2 = d * d;
                 const double kk = sigmasq * exp(-omega * d2);
                 buf[G::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
-                buf[G::O_KVM + 63 + lane] = kk;
-                buf[G::O_KVM + 63 - lane] = kk;
+                buf[G::O_KVM + 63 + lane] = kk + (lane == 0 ? eps : 0.0);
+                buf[G::O_KVM + 63 - lane] = kk + (lane == 0 ? eps : 0.0);
                 buf[G::O_DKV + lane] = -kk * d2 * omega;
+                if (lane < 32) buf[G::O_Z + lane] = 0.0;
             }
             tri_wave_sync();
             double logdet, unused;
@@ -1194,9 +1195,10 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) hstep_round_mfma(HRo
                 const double d = lane * A.dt, d2 = d * d;
                 const double kk = sigmasq * exp(-omega * d2);
                 buf[G::O_SV + lane] = sqrt(w);
-                buf[G::O_KVM + 63 + lane] = kk;
-                buf[G::O_KVM + 63 - lane] = kk;
+                buf[G::O_KVM + 63 + lane] = kk + (lane == 0 ? eps : 0.0);
+                buf[G::O_KVM + 63 - lane] = kk + (lane == 0 ? eps : 0.0);
                 buf[G::O_DKV + lane] = -kk * d2 * omega;
+                if (lane < 32) buf[G::O_Z + lane] = 0.0;
             }
             tri_wave_sync();
             const bool ok = hstep_task_mfma<T>(buf, eps, lane, tr, cs);

@@ -48,7 +48,8 @@ struct HmGeom {
     static constexpr int O_KVM = O_SV + 64;    // kvm[63 + d] = first column of K at |d|, d = -63..63
     static constexpr int O_DKV = O_KVM + 128;  // first column of dK / dln omega, 64
     static constexpr int O_NT = O_DKV + 64;    // ntail[E][64]: columns 16 NB + t of N
-    static constexpr int TASK = O_NT + (E > 0 ? E : 1) * 64;
+    static constexpr int O_Z = O_NT + (E > 0 ? E : 1) * 64;  // 32 zeros
+    static constexpr int TASK = O_Z + 32;
     __host__ __device__ static constexpr int width(int k) { return k == NB - 1 ? WL : 16; }
     __host__ __device__ static constexpr int chunks(int k) { return (width(k) + 3) / 4; }
 };
@@ -62,8 +63,8 @@ __device__ __forceinline__ double hm_rsqrt(double d) {
     return y;
 }
 
-// buf: TASK doubles of LDS owned by this wave; on entry the tables at O_SV, O_KVM, O_DKV are filled (sqrt(w) zero
-// beyond the rows present).  A pivot of A that is not positive and finite makes tr and cs NaN.  tr = tr(A^-1) over all
+// buf: TASK doubles of LDS owned by this wave; on entry the tables at O_SV, O_KVM (jitter eps added at distance 0),
+// O_DKV and the zeros at O_Z are filled (sqrt(w) zero beyond the rows present).  A pivot of A that is not positive and finite makes tr and cs NaN.  tr = tr(A^-1) over all
 // TP rows (the caller subtracts the identity padding's share), cs = sum_jk s_j s_k dK_jk (A^-1)_jk; both
 // per-lane partials.
 //
@@ -79,6 +80,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
     const double* kvm = buf + G::O_KVM;
     const double* dkv = buf + G::O_DKV;
     double* ntail = buf + G::O_NT;
+    const double* zrow = buf + G::O_Z;
     const int c = lane & 15, g = lane >> 4;
     hm_d4 N[NB][NB], M[NB][NB], P[NB][NB];
 #pragma unroll
@@ -123,8 +125,12 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
             // row of N: block rows from bufA, tail rows from ntail (N is symmetric)
             const double* pn = (E > 0 && i >= TB) ? ntail + (i - TB < E ? i - TB : 0) * 64 + col0
                                                   : bufA + (lane < TB - col0 ? lane : 0) * LDB;
-            const double* pm = bufX + (lane < col0 ? lane : 0) * LDB;
-            const double* pk = kvm + 63 + lane;  // kvm[63 + lane - q] = K0[|i - (col0 + q)|]
+            // an opaque copy of the lane index per panel: the unit-diagonal selects below are otherwise common
+            // subexpressions of all panels, computed once at the top and kept in ~40 registers to the end
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const double* pm = lane < col0 ? bufX + lane * LDB : zrow;  // rows of X' at / below the panel have no M terms
+            const double* pk = kvm + 63 + lane;  // kvm[63 + lane - q] = K[|i - (col0 + q)|], jitter included at distance 0
 #pragma unroll
             for (int q = 0; q < 16; q += 2) {
                 const double2 sj = *reinterpret_cast<const double2*>(sv + col0 + q);
@@ -133,19 +139,19 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     nv = *reinterpret_cast<const double2*>(pn + q);
                     mv = *reinterpret_cast<const double2*>(pm + q);
                 }
-                const double a0 = (si * sj.x) * pk[-q], a1 = (si * sj.y) * pk[-q - 1];
-                ra[q] = (lane == q ? fma(si * sj.x, eps, one) : 0.0) + a0 - nv.x;
-                ra[q + 1] = (lane == q + 1 ? fma(si * sj.y, eps, one) : 0.0) + a1 - nv.y;
-                rx[q] = (lane == col0 + q ? 1.0 : 0.0) - (lane < col0 ? mv.x : 0.0);
-                rx[q + 1] = (lane == col0 + q + 1 ? 1.0 : 0.0) - (lane < col0 ? mv.y : 0.0);
+                // A = diag(one) + S K S: the unit diagonal rides in the FMA's addend
+                ra[q] = fma(si * sj.x, pk[-q], (ln == q ? one : 0.0) - nv.x);
+                ra[q + 1] = fma(si * sj.y, pk[-q - 1], (ln == q + 1 ? one : 0.0) - nv.y);
+                rx[q] = (ln == col0 + q ? 1.0 : 0.0) - mv.x;
+                rx[q + 1] = (ln == col0 + q + 1 ? 1.0 : 0.0) - mv.y;
             }
             if (last) {
 #pragma unroll
                 for (int t = 0; t < E; ++t) {  // tail columns: N from ntail[t][row], M from mt[t]
                     const double sj = sv[TB + t];
                     const double nv = ntail[t * 64 + (i < 64 ? i : 63)];
-                    ra[16 + t] = (lane == 16 + t ? fma(si * sj, eps, one) : 0.0) + (si * sj) * pk[-16 - t] - nv;
-                    rx[16 + t] = (lane == TB + t ? 1.0 : 0.0) - mt[t];
+                    ra[16 + t] = fma(si * sj, pk[-16 - t], (ln == 16 + t ? one : 0.0) - nv);
+                    rx[16 + t] = (ln == TB + t ? 1.0 : 0.0) - mt[t];
                 }
             }
         }
@@ -163,51 +169,32 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
             double* Ld = buf;  // rows of the diagonal block (lanes < W), stride LDD; the panel buffer is free meanwhile
             constexpr int LDD = (WL + 1) & ~1;
             double yprod = 1.0;  // KMODE: product of the reciprocal pivots of this panel
-            // pre[]: multipliers L[j + 1][0 .. j - 2] for the lazy update of step j, fetched one step EARLIER (they
-            // were final by then): no LDS latency inside a step; L[j + 1][j - 1], one step old, comes by v_readlane
-            double pre[WL];
-#pragma unroll
-            for (int q = 0; q < WL; ++q) pre[q] = 0.0;
 #pragma unroll
             for (int j = 0; j < WL; ++j) {
                 if (j < W) {
-                    double cur[WL];
-#pragma unroll
-                    for (int q = 0; q < WL; ++q) cur[q] = pre[q];
-                    if (j + 2 < W && j >= 1) {  // for step j + 1: row j + 2, entries 0 .. j - 1
-                        const double* row = Ld + (j + 2) * LDD;
-#pragma unroll
-                        for (int m = 0; m + 1 < j; m += 2) {
-                            const double2 v = *reinterpret_cast<const double2*>(row + m);
-                            pre[m] = v.x;
-                            pre[m + 1] = v.y;
-                        }
-                        if (j & 1) pre[j - 1] = row[j - 1];
-                    }
-                    double lv2 = 0.0;
                     if (j > 0) {
                         const double lv = tri_readlane(ra[j - 1], j);
                         ra[j] = fma(-ra[j - 1], lv, ra[j]);
                         rx[j] = fma(-rx[j - 1], lv, rx[j]);
-                        if (j + 1 < W) lv2 = tri_readlane(ra[j - 1], j + 1);
                     }
                     const double d = tri_readlane(ra[j], j);
                     double y = __builtin_amdgcn_rsq(d);
                     if (j + 1 < W && j >= 1) {  // column j + 1 <- columns 0 .. j - 1
+                        const double* row = Ld + (j + 1) * LDD;
                         double a0 = ra[j + 1], a1 = 0.0, x0 = rx[j + 1], x1 = 0.0;
 #pragma unroll
-                        for (int m = 0; m + 1 < j - 1; m += 2) {
-                            a0 = fma(-ra[m], cur[m], a0);
-                            a1 = fma(-ra[m + 1], cur[m + 1], a1);
-                            x0 = fma(-rx[m], cur[m], x0);
-                            x1 = fma(-rx[m + 1], cur[m + 1], x1);
+                        for (int m = 0; m + 1 < j; m += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(row + m);
+                            a0 = fma(-ra[m], v.x, a0);
+                            a1 = fma(-ra[m + 1], v.y, a1);
+                            x0 = fma(-rx[m], v.x, x0);
+                            x1 = fma(-rx[m + 1], v.y, x1);
                         }
-                        if (j >= 2 && ((j - 1) & 1)) {
-                            a0 = fma(-ra[j - 2], cur[j - 2], a0);
-                            x0 = fma(-rx[j - 2], cur[j - 2], x0);
+                        if (j & 1) {
+                            const double v = row[j - 1];
+                            a0 = fma(-ra[j - 1], v, a0);
+                            x0 = fma(-rx[j - 1], v, x0);
                         }
-                        a1 = fma(-ra[j - 1], lv2, a1);
-                        x1 = fma(-rx[j - 1], lv2, x1);
                         ra[j + 1] = a0 + a1;
                         rx[j + 1] = x0 + x1;
                         // evaluate the X' half HERE: unpinned, the compiler sinks the whole rx chain below the panel
@@ -222,7 +209,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     rx[j] *= y;
                     if (KMODE) yprod *= y;
                     asm volatile("" : "+v"(ra[j]), "+v"(rx[j]));
-                    if (j + 2 < W) {
+                    if (j + 1 < W) {
                         if (lane < W) Ld[lane * LDD + j] = ra[j];
                         tri_wave_order();
                     }
