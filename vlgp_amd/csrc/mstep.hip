@@ -334,9 +334,7 @@ struct SolveArgs {
     int* fail;
 };
 
-__global__ void __launch_bounds__(64) mstep_solve_kernel(SolveArgs A) {
-    const int n = blockIdx.x * 64 + threadIdx.x;
-    if (n >= A.N) return;
+__device__ void mstep_solve_channel(const SolveArgs& A, int n) {
     const int N = A.N, L = A.L, P = A.P;
     double H[SOLVE_MAXD * SOLVE_MAXD], g[SOLVE_MAXD];
     const double* MtY = A.prep;                       // L rows
@@ -431,6 +429,54 @@ __global__ void __launch_bounds__(64) mstep_solve_kernel(SolveArgs A) {
         A.b[(int64_t)0 * N + n] = g[0];
         for (int j = 1; j < P; ++j) A.b[(int64_t)j * N + n] = 0.0;
     }
+}
+
+__global__ void __launch_bounds__(64) mstep_solve_kernel(SolveArgs A) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n < A.N) mstep_solve_channel(A, n);
+}
+
+// Single rank: the fixed-order sum of the partials and the per-channel solves in ONE launch -- every block sums its
+// 64 outputs as sum_partials_kernel does, the block that draws the last ticket then runs the solves (one launch
+// boundary and the latency of a 2-wave launch less per Newton iteration).
+__global__ void __launch_bounds__(512) mstep_sum_solve_kernel(const double* partial, int G, int64_t K, double* out,
+                                                              unsigned* ticket, SolveArgs A) {
+    __shared__ double red[8][64];
+    __shared__ int s_last;
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < K) {
+        int g = sl;
+        for (; g + 8 < G; g += 16) {
+            s0 += partial[(int64_t)g * K + i];
+            s1 += partial[(int64_t)(g + 8) * K + i];
+        }
+        if (g < G) s0 += partial[(int64_t)g * K + i];
+    }
+    red[sl][o] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && i < K) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][o];
+        out[i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = tk == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *ticket = 0;  // the next launch is stream-ordered after this one
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < A.N; n += 512) mstep_solve_channel(A, n);
 }
 
 __global__ void noise_mean_kernel(int N, double count, const double* s1, double* mean) {
@@ -566,7 +612,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     const int Kmax = Kp > Kn ? Kp : Kn;
     // workspace: prep | stats | lat | noise1 | mean | partial
     const int64_t o_prep = 0, o_stats = o_prep + (int64_t)Kp * N, o_lat = o_stats + (int64_t)Kn * N;
-    const int64_t o_s1 = o_lat + Kl + 8, o_mean = o_s1 + N, o_part = o_mean + N;
+    const int64_t o_s1 = o_lat + Kl + 8, o_mean = o_s1 + N, o_tick = o_mean + N, o_part = o_tick + 2;
     int64_t part_len = (int64_t)g.G * Kmax * N;
     if (part_len < 256LL * Kl) part_len = 256LL * Kl;
     CHK(vlgp_ensure_work_m(ctx, o_part + part_len));
@@ -574,6 +620,8 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     hipStream_t st = ctx->mstream;
     double *d_prep = W + o_prep, *d_stats = W + o_stats, *d_lat = W + o_lat, *d_s1 = W + o_s1,
            *d_mean = W + o_mean, *d_part = W + o_part;
+    unsigned* d_ticket = reinterpret_cast<unsigned*>(W + o_tick);
+    HIPCHK(ctx, hipMemsetAsync(d_ticket, 0, sizeof(double) * 2, st));
 
     MArgs A;
     A.N = N; A.L = L; A.P = P; A.rows = us.rows; A.rows_per_wg = g.rows_per_wg; A.CT = g.CT; A.S = g.S;
@@ -629,6 +677,13 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
             int rc = launch_accum(ctx, K_NEWTON, g, A);
             vlgp_prof_end(ctx, VLGP_PROF_MSTEP, (double)us.rows, st);
             CHK(rc);
+            if (ctx->world == 1) {  // no all-reduce between the sum and the solves: one launch for both
+                const int64_t n = (int64_t)Kn * N;
+                hipLaunchKernelGGL(mstep_sum_solve_kernel, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, st, d_part,
+                                   g.G, n, d_stats, d_ticket, S);
+                HIPCHK(ctx, hipGetLastError());
+                continue;
+            }
             CHK(reduce_to(Kn, d_stats));
         }
         hipLaunchKernelGGL(mstep_solve_kernel, dim3((N + 63) / 64), dim3(64), 0, st, S);
