@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
 // The round on the matrix pipe (hstep_mfma.h): one wave per segment, NW waves per block.  Blocks [0, n_eval) are
 // the K blocks as in hstep_round_lean (all NW waves share the trace phase).
 template <int T, int NW>
-__global__ void __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) hstep_round_mfma(HRoundArgs R) {
+__global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hstep_round_mfma(HRoundArgs R) {
     using G = HmGeom<T>;
     constexpr int LDK = T | 2;                  // row stride of K^-1 in LDS: 2 mod 4 -> conflict-free operand reads
     constexpr int KBLK = G::TASK + T * LDK;     // wave 0's task buffer | K^-1

@@ -246,6 +246,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     m1 = fma(rx[q + 1], l2.y, m1);
                 }
                 mt[t] += (lane < nX) ? m0 + m1 : 0.0;
+                asm volatile("" : "+v"(mt[t]));  // evaluate now (else the dot product waits, operands and all, for the last panel)
                 if (lane >= 16 && lane < rowsA) {
                     double* pn = ntail + t * 64 + col0 + lane;
                     *pn = (k > 0 ? *pn : 0.0) + (n0 + n1);
