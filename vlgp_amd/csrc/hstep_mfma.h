@@ -207,7 +207,10 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     }
                     ra[j] *= y;
                     rx[j] *= y;
-                    if (KMODE) yprod *= y;
+                    if (KMODE) {
+                        yprod *= y;
+                        asm volatile("" : "+v"(yprod));  // (else the product is formed at the end from fifty kept values)
+                    }
                     asm volatile("" : "+v"(ra[j]), "+v"(rx[j]));
                     if (j + 1 < W) {
                         if (lane < W) Ld[lane * LDD + j] = ra[j];
