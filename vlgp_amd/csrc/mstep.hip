@@ -54,13 +54,16 @@ static inline int nstat_rt(int L, int P, int kind) {
     return kind == K_PREP ? L + P + P * L + tri(P) : kind == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
 }
 
-template <int LT, int PT, int KIND>
+// EXACT: L == LT, P == PT and x == 1 known at compile time -- the common case (3, 5, 8, 10 latents, no regressors):
+// no per-latent predicates or branches in the row loop, and the scalar registers they held go to the exp constants
+template <int LT, int PT, int KIND, bool EXACT>
 // four waves per SIMD (128 VGPRs) up to five latents; the 2 L + L (L + 1) / 2 accumulators of more latents
 // need the registers more than the occupancy
 __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_accum(MArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NA = nacc<LT, PT, KIND>();
-    const int N = A.N, L = A.L, P = A.P, CT = A.CT, S = A.S;
+    const int N = A.N, CT = A.CT, S = A.S;
+    const int L = EXACT ? LT : A.L, P = EXACT ? PT : A.P;
     const int tid = threadIdx.x;
     const int nl = tid % CT, s = tid / CT;
     const int n = blockIdx.y * CT + nl;
@@ -69,9 +72,12 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
     double* v_t = mu_t + M_TILE * L;   // M_TILE x L
     double* red = v_t + M_TILE * L;    // S x CT
 
-    double al[LT], bl[PT], acc[NA];
+    double al[LT], al2[LT], bl[PT], acc[NA];
 #pragma unroll
-    for (int l = 0; l < LT; ++l) al[l] = (active && l < L) ? A.a[l * N + n] : 0.0;
+    for (int l = 0; l < LT; ++l) {
+        al[l] = (active && l < L) ? A.a[l * N + n] : 0.0;
+        al2[l] = al[l] * al[l];
+    }
 #pragma unroll
     for (int j = 0; j < PT; ++j) bl[j] = (active && j < P) ? A.b[j * N + n] : 0.0;
 #pragma unroll
@@ -98,12 +104,12 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
             double xv[PT];
 #pragma unroll
             for (int j = 0; j < PT; ++j)
-                xv[j] = (j < P) ? (A.x ? A.x[(row * P + j) * N + n] : 1.0) : 0.0;
+                xv[j] = EXACT ? 1.0 : ((j < P) ? (A.x ? A.x[(row * P + j) * N + n] : 1.0) : 0.0);
             double mr[LT], vr[LT];
 #pragma unroll
             for (int l = 0; l < LT; ++l) {
-                mr[l] = l < L ? mu_t[rr * L + l] : 0.0;
-                vr[l] = l < L ? v_t[rr * L + l] : 0.0;
+                mr[l] = (EXACT || l < L) ? mu_t[rr * L + l] : 0.0;
+                vr[l] = (EXACT || l < L) ? v_t[rr * L + l] : 0.0;
             }
             if constexpr (KIND == K_PREP) {
                 const double yv = A.y[row * N + n];
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
 #pragma unroll
                 for (int l = 0; l < LT; ++l) {
                     eta = fma(mr[l], al[l], eta);
-                    lin = fma(vr[l] * al[l], al[l], lin);
+                    lin = fma(vr[l], al2[l], lin);
                 }
                 if constexpr (KIND == K_NEWTON) {
                     const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
@@ -533,11 +539,15 @@ static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
 template <int LT, int PT>
 static void launch_accum_k(hipStream_t st, int kind, const Geometry& g, const MArgs& A) {
     dim3 grid(g.G, g.tiles), blk(g.nthr);
+    if (kind == K_NEWTON && A.L == LT && A.P == PT && PT == 1 && A.x == nullptr) {  // the hot launch, specialised
+        hipLaunchKernelGGL((mstep_accum<LT, PT, K_NEWTON, true>), grid, blk, g.lds, st, A);
+        return;
+    }
     switch (kind) {
-        case K_PREP: hipLaunchKernelGGL((mstep_accum<LT, PT, K_PREP>), grid, blk, g.lds, st, A); break;
-        case K_NEWTON: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NEWTON>), grid, blk, g.lds, st, A); break;
-        case K_NOISE1: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NOISE1>), grid, blk, g.lds, st, A); break;
-        default: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NOISE2>), grid, blk, g.lds, st, A); break;
+        case K_PREP: hipLaunchKernelGGL((mstep_accum<LT, PT, K_PREP, false>), grid, blk, g.lds, st, A); break;
+        case K_NEWTON: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NEWTON, false>), grid, blk, g.lds, st, A); break;
+        case K_NOISE1: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NOISE1, false>), grid, blk, g.lds, st, A); break;
+        default: hipLaunchKernelGGL((mstep_accum<LT, PT, K_NOISE2, false>), grid, blk, g.lds, st, A); break;
     }
 }
 template <int LT>
