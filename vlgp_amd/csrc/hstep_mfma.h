@@ -181,22 +181,23 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     double y = __builtin_amdgcn_rsq(d);
                     if (j + 1 < W && j >= 1) {  // column j + 1 <- columns 0 .. j - 1
                         const double* row = Ld + (j + 1) * LDD;
-                        double a0 = ra[j + 1], a1 = 0.0, x0 = rx[j + 1], x1 = 0.0;
+                        // one chain per register set: with three waves per SIMD the FMA latency is covered
+                        double a0 = ra[j + 1], x0 = rx[j + 1];
 #pragma unroll
                         for (int m = 0; m + 1 < j; m += 2) {
                             const double2 v = *reinterpret_cast<const double2*>(row + m);
                             a0 = fma(-ra[m], v.x, a0);
-                            a1 = fma(-ra[m + 1], v.y, a1);
                             x0 = fma(-rx[m], v.x, x0);
-                            x1 = fma(-rx[m + 1], v.y, x1);
+                            a0 = fma(-ra[m + 1], v.y, a0);
+                            x0 = fma(-rx[m + 1], v.y, x0);
                         }
                         if (j & 1) {
                             const double v = row[j - 1];
                             a0 = fma(-ra[j - 1], v, a0);
                             x0 = fma(-rx[j - 1], v, x0);
                         }
-                        ra[j + 1] = a0 + a1;
-                        rx[j + 1] = x0 + x1;
+                        ra[j + 1] = a0;
+                        rx[j + 1] = x0;
                         // evaluate the X' half HERE: unpinned, the compiler sinks the whole rx chain below the panel
                         // and carries every multiplier to it through scratch
                         asm volatile("" : "+v"(ra[j + 1]), "+v"(rx[j + 1]));
