@@ -424,7 +424,12 @@ def make_cholesky(trials, params, config=None):
     DESIGN.md, "pivot chaos")."""
     from . import gp as _gp
 
-    lengths = sorted({int(tr["y"].shape[0]) for tr in trials})
+    if isinstance(trials, DeviceTrials):
+        # the unit lengths of a resident set are fixed at upload: the engine holds the offsets
+        _, _, off = trials.engine.sets[trials.set_id]
+        lengths = sorted({int(t) for t in np.unique(np.diff(np.asarray(off)))})
+    else:
+        lengths = sorted({int(tr["y"].shape[0]) for tr in trials})
     mode = (config or {}).get("ichol", "device")
     if mode == "host":
         chol = {T: np.stack([_gp.ichol_gauss_host(T, params["omega"][l], params["rank"]) * params["sigma"][l]
