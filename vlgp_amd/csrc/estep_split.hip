@@ -99,24 +99,45 @@ esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double*
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int LT, int KIND, bool HASXB>
+// CS: the channels of one row group are split over CS waves of the workgroup (a lone wave walking all N channels
+// is a chain of N dependent record loads + exponentials: measured 35 us at two waves per SIMD and 41 us at four --
+// latency, not throughput); the partial sums meet in LDS and are added in wave order (deterministic).
+// RPL: rows per lane (rows row0 + 64 q): one channel record serves RPL rows -- fewer scalar loads per (row, channel)
+// and RPL independent exp chains per record.
+template <int LT, int KIND, bool HASXB, int CS, int RPL>
 __global__ void __launch_bounds__(256)
 esplit_pass(SplitArgs A, const double* __restrict__ cols) {
     constexpr int REC = rec_len<LT>();
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool in = row < A.rows;
-    const int64_t rr = in ? row : 0;
-    const int N = A.N, L = A.L;
-    double mr[LT], vr[LT], acc[LT];
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-        const bool use = l < L && KIND != SP_YA;
-        mr[l] = use ? A.mu[rr * L + l] : 0.0;
-        vr[l] = use ? A.v[rr * L + l] : 0.0;
-        acc[l] = 0.0;
+    constexpr int RPB = (256 / CS) * RPL;  // rows per workgroup
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int part = CS == 1 ? 0 : wid % CS;
+    const int64_t row0 = (int64_t)blockIdx.x * RPB + (wid / CS) * (64 * RPL) + lane;
+    __shared__ double etab[64];  // 2^(j/64) for fast_exp_tab
+    if constexpr (KIND != SP_YA) {
+        fast_exp_tab_init(etab, threadIdx.x);
+        __syncthreads();
     }
-    const double* yrow = A.y + rr * N;
-    const double* xbrow = HASXB ? A.xb + rr * N : nullptr;
+    const int N = A.N, L = A.L;
+    bool in[RPL];
+    int64_t rr[RPL];
+    double mr[RPL][LT], vr[RPL][LT], acc[RPL][LT];
+    const double* yrow[RPL];
+    const double* xbrow[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        in[q] = row0 + 64 * q < A.rows;
+        rr[q] = in[q] ? row0 + 64 * q : 0;
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const bool use = l < L && KIND != SP_YA;
+            mr[q][l] = use ? A.mu[rr[q] * L + l] : 0.0;
+            vr[q][l] = use ? A.v[rr[q] * L + l] : 0.0;
+            acc[q][l] = 0.0;
+        }
+        yrow[q] = A.y + rr[q] * N;
+        xbrow[q] = HASXB ? A.xb + rr[q] * N : nullptr;
+    }
     auto load_rec = [&](int i, double (&rv)[REC]) {
         const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)i * REC);
 #pragma unroll
@@ -126,13 +147,18 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
             rv[2 * q + 1] = t2.y;
         }
     };
-    const int np = A.np, ntot = A.ntot;
+    // this wave's share of the Poisson list [p_lo, np) and of the Gaussian list [g_lo, ntot)
+    const int p_lo = CS == 1 ? 0 : (A.np * part) / CS;
+    const int np = CS == 1 ? A.np : (A.np * (part + 1)) / CS;
+    const int g_lo = CS == 1 ? A.np : A.np + ((A.ntot - A.np) * part) / CS;
+    const int ntot = CS == 1 ? A.ntot : A.np + ((A.ntot - A.np) * (part + 1)) / CS;
     if constexpr (KIND == SP_YA) {
+        static_assert(CS == 1 && RPL == 1, "the y pass is not split");
         auto body = [&](const double (&rv)[REC]) {
             const int n = (int)__double_as_longlong(rv[2 * LT + 2]);
-            const double yc = yrow[n] * rv[2 * LT + 1];
+            const double yc = yrow[0][n] * rv[2 * LT + 1];
 #pragma unroll
-            for (int l = 0; l < LT; ++l) acc[l] = fma(yc, rv[l], acc[l]);
+            for (int l = 0; l < LT; ++l) acc[0][l] = fma(yc, rv[l], acc[0][l]);
         };
         double ra_[REC], rb_[REC];
         load_rec(0, ra_);
@@ -147,21 +173,24 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
     } else {
         // one Poisson channel: rate = exp(min(eta + v.a^2/2, 10)) (math.trunc_exp, vlgp/math.py:24-38)
         auto poisson = [&](const double (&rv)[REC]) {
-            double eta = HASXB ? xbrow[(int)__double_as_longlong(rv[2 * LT + 2])] : rv[2 * LT];
-            double lin = 0.0;
 #pragma unroll
-            for (int l = 0; l < LT; ++l) {
-                eta = fma(mr[l], rv[l], eta);
-                lin = fma(vr[l], rv[LT + l], lin);
+            for (int q = 0; q < RPL; ++q) {
+                double eta = HASXB ? xbrow[q][(int)__double_as_longlong(rv[2 * LT + 2])] : rv[2 * LT];
+                double lin = 0.0;
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    eta = fma(mr[q][l], rv[l], eta);
+                    lin = fma(vr[q][l], rv[LT + l], lin);
+                }
+                const double rate = fast_exp_tab(fmin(fma(0.5, lin, eta), 10.0), etab);
+#pragma unroll
+                for (int l = 0; l < LT; ++l) acc[q][l] = fma(rate, rv[KIND == SP_RES ? l : LT + l], acc[q][l]);
             }
-            const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
-#pragma unroll
-            for (int l = 0; l < LT; ++l) acc[l] = fma(rate, rv[KIND == SP_RES ? l : LT + l], acc[l]);
         };
         double ra_[REC], rb_[REC];
-        if (np > 0) {
-            load_rec(0, ra_);
-            int i = 0;
+        if (np > p_lo) {
+            load_rec(p_lo, ra_);
+            int i = p_lo;
             for (; i + 1 < np; i += 2) {
                 load_rec(i + 1, rb_);
                 poisson(ra_);
@@ -171,24 +200,48 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
             if (i < np) poisson(ra_);
         }
         if constexpr (KIND == SP_RES) {  // Gaussian channels: the residual mean is eta itself
-            for (int i = np; i < ntot; ++i) {
+            for (int i = g_lo; i < ntot; ++i) {
                 load_rec(i, ra_);
-                double eta = HASXB ? xbrow[(int)__double_as_longlong(ra_[2 * LT + 2])] : ra_[2 * LT];
 #pragma unroll
-                for (int l = 0; l < LT; ++l) eta = fma(mr[l], ra_[l], eta);
-                const double mval = eta * ra_[2 * LT + 1];
+                for (int q = 0; q < RPL; ++q) {
+                    double eta = HASXB ? xbrow[q][(int)__double_as_longlong(ra_[2 * LT + 2])] : ra_[2 * LT];
 #pragma unroll
-                for (int l = 0; l < LT; ++l) acc[l] = fma(mval, ra_[l], acc[l]);
+                    for (int l = 0; l < LT; ++l) eta = fma(mr[q][l], ra_[l], eta);
+                    const double mval = eta * ra_[2 * LT + 1];
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) acc[q][l] = fma(mval, ra_[l], acc[q][l]);
+                }
             }
         }
     }
-    if (in) {
+    if constexpr (CS > 1) {
+        __shared__ double part_acc[4][RPL][LT][64];
+        if (part > 0) {
 #pragma unroll
-        for (int l = 0; l < LT; ++l) {
-            if (l < L) {
-                if constexpr (KIND == SP_YA) A.ya[row * L + l] = acc[l];
-                else if constexpr (KIND == SP_RES) A.ra[row * L + l] = A.ya[row * L + l] - acc[l];
-                else A.w[row * L + l] = acc[l] + A.wconst[l];
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int l = 0; l < LT; ++l) part_acc[wid][q][l][lane] = acc[q][l];
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int p = 1; p < CS; ++p)
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int l = 0; l < LT; ++l) acc[q][l] += part_acc[wid + p][q][l][lane];
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        if (in[q]) {
+            const int64_t row = rr[q];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                if (l < L) {
+                    if constexpr (KIND == SP_YA) A.ya[row * L + l] = acc[q][l];
+                    else if constexpr (KIND == SP_RES) A.ra[row * L + l] = A.ya[row * L + l] - acc[q][l];
+                    else A.w[row * L + l] = acc[q][l] + A.wconst[l];
+                }
             }
         }
     }
@@ -593,21 +646,48 @@ __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     }
 }
 
-template <int LT>
-int run_passes(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
-    const dim3 grid((unsigned)((A.rows + 255) / 256)), blk(256);
+template <int LT, int CS, int RPL>
+int run_passes_cs(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
+    constexpr int RPB = (256 / CS) * RPL;
+    const dim3 grid((unsigned)((A.rows + RPB - 1) / RPB)), blk(256);
     hipStream_t st = ctx->stream;
     if (A.xb) {
-        if (kind == SP_YA) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, true>), grid, blk, 0, st, A, cols);
-        else if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, true>), grid, blk, 0, st, A, cols);
-        else hipLaunchKernelGGL((esplit_pass<LT, SP_W, true>), grid, blk, 0, st, A, cols);
+        if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, true, CS, RPL>), grid, blk, 0, st, A, cols);
+        else hipLaunchKernelGGL((esplit_pass<LT, SP_W, true, CS, RPL>), grid, blk, 0, st, A, cols);
     } else {
-        if (kind == SP_YA) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, false>), grid, blk, 0, st, A, cols);
-        else if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, false>), grid, blk, 0, st, A, cols);
-        else hipLaunchKernelGGL((esplit_pass<LT, SP_W, false>), grid, blk, 0, st, A, cols);
+        if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, false, CS, RPL>), grid, blk, 0, st, A, cols);
+        else hipLaunchKernelGGL((esplit_pass<LT, SP_W, false, CS, RPL>), grid, blk, 0, st, A, cols);
     }
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
+}
+
+template <int LT>
+int run_passes(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
+    if (kind == SP_YA) {
+        const dim3 grid((unsigned)((A.rows + 255) / 256)), blk(256);
+        if (A.xb) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, true, 1, 1>), grid, blk, 0, ctx->stream, A, cols);
+        else hipLaunchKernelGGL((esplit_pass<LT, SP_YA, false, 1, 1>), grid, blk, 0, ctx->stream, A, cols);
+        HIPCHK(ctx, hipGetLastError());
+        return VLGP_OK;
+    }
+    // channel split: four waves per row group while a wave keeps >= 16 channels (measured at 200 k rows x 100
+    // channels: 39.4 / 34.4 / 32.2 us for 1 / 2 / 4; at 131 k rows 35.9 / 24.8 / 24.6 us)
+    static const int forced = getenv("VLGP_PASS_SPLIT") ? atoi(getenv("VLGP_PASS_SPLIT")) : 0;
+    static const int forced_rpl = getenv("VLGP_PASS_RPL") ? atoi(getenv("VLGP_PASS_RPL")) : 0;
+    int cs = forced;
+    if (cs != 1 && cs != 2 && cs != 4) cs = A.ntot >= 64 ? 4 : (A.ntot >= 32 ? 2 : 1);
+    const int rpl = forced_rpl == 2 && LT <= 5 ? 2 : 1;
+    if constexpr (LT <= 5) {
+        if (rpl == 2) {
+            if (cs == 4) return run_passes_cs<LT, 4, 2>(ctx, A, kind, cols);
+            if (cs == 2) return run_passes_cs<LT, 2, 2>(ctx, A, kind, cols);
+            return run_passes_cs<LT, 1, 2>(ctx, A, kind, cols);
+        }
+    }
+    if (cs == 4) return run_passes_cs<LT, 4, 1>(ctx, A, kind, cols);
+    if (cs == 2) return run_passes_cs<LT, 2, 1>(ctx, A, kind, cols);
+    return run_passes_cs<LT, 1, 1>(ctx, A, kind, cols);
 }
 
 int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* cols) {

@@ -71,6 +71,8 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
     double* mu_t = smem;               // M_TILE x L
     double* v_t = mu_t + M_TILE * L;   // M_TILE x L
     double* red = v_t + M_TILE * L;    // S x CT
+    double* etab = red + S * CT;       // NEWTON: 2^(j/64) for fast_exp_tab (visible after the first barrier of the row loop)
+    if constexpr (KIND == K_NEWTON) fast_exp_tab_init(etab, tid);
 
     double al[LT], al2[LT], bl[PT], acc[NA];
 #pragma unroll
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
                     lin = fma(vr[l], al2[l], lin);
                 }
                 if constexpr (KIND == K_NEWTON) {
-                    const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+                    const double rate = fast_exp_tab(fmin(fma(0.5, lin, eta), 10.0), etab);
                     double mt[LT], q[LT];
 #pragma unroll
                     for (int l = 0; l < LT; ++l) {
@@ -532,7 +534,7 @@ static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
     g.rows_per_wg = (int)((rows + G - 1) / G);
     g.rows_per_wg = ((g.rows_per_wg + 7) / 8) * 8;  // an even split over the workgroups: every CU gets the same share
     g.G = (int)((rows + g.rows_per_wg - 1) / g.rows_per_wg);
-    g.lds = (size_t)(2 * M_TILE * L + g.S * g.CT) * 8;
+    g.lds = (size_t)(2 * M_TILE * L + g.S * g.CT + 64) * 8;  // + the exp table
     return g;
 }
 
