@@ -56,6 +56,9 @@ struct SplitArgs {
     int lds_g;         // doubles of LDS per wave for the G tile
     int do_v, last;
     int n_lat;         // latents covered by this launch (tasks = M n_lat)
+    int shg;           // 1: every unit has the same prior; a workgroup = one latent x four units, G staged ONCE per
+                       //    workgroup at the start of the LDS (shg_cap doubles) instead of once per wave
+    int shg_cap, shg_T;
     int lat[16];       // their indices
 };
 
@@ -257,15 +260,22 @@ struct Task {
     double* vec;   // LDS: 128 doubles
     double* u;     // LDS: 64 doubles
     double* tile;  // LDS: max(256, gcap) doubles (MFMA staging tile / staged G), then two 64-entry columns
+    double* Gs;    // LDS: the staged G (T, rs): `tile`, or the workgroup's shared copy
     int gcap;      // doubles reserved for the staged G (>= 256)
 };
 
 __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int lane) {
     const int wid = threadIdx.x >> 6;
-    const int task = blockIdx.x * (blockDim.x >> 6) + wid;
-    if (task >= A.M * A.n_lat) return false;
-    K.m = task / A.n_lat;
-    K.l = A.lat[task - K.m * A.n_lat];
+    if (A.shg) {
+        K.m = 4 * (blockIdx.x / A.n_lat) + wid;
+        if (K.m >= A.M) return false;
+        K.l = A.lat[blockIdx.x % A.n_lat];
+    } else {
+        const int task = blockIdx.x * (blockDim.x >> 6) + wid;
+        if (task >= A.M * A.n_lat) return false;
+        K.m = task / A.n_lat;
+        K.l = A.lat[task - K.m * A.n_lat];
+    }
     K.r0 = A.off[K.m];
     K.T = (int)(A.off[K.m + 1] - K.r0);
     const int pidx = A.unit_prior[K.m];
@@ -274,6 +284,7 @@ __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* 
     K.Gl = A.prior_base[pidx] + A.prior_goff[pidx * A.L + K.l];
     K.Xl = lds_wave;
     K.tile = K.Xl + A.pkl;
+    K.Gs = K.tile;
     K.gcap = A.lds_g;
     K.vec = K.tile + A.lds_g + 128;  // mean kernel only
     K.u = K.vec + 128;
@@ -286,6 +297,19 @@ __device__ __forceinline__ void load_g_row(double (&gt)[RA], const double* Gl, i
     const double* Gt = Gl + (int64_t)t * r;
 #pragma unroll
     for (int i = 0; i < RA; ++i) gt[i] = i < r ? Gt[i] : 0.0;
+}
+
+// the same row from the staged copy (T, rs), rs even, columns r .. rs - 1 zero
+template <int RA>
+__device__ __forceinline__ void load_g_row_lds(double (&gt)[RA], const double* Gs, int t, int rs) {
+    const double* Gt = Gs + t * rs;
+#pragma unroll
+    for (int i = 0; i < RA; i += 2) {
+        double2 g2 = double2{0.0, 0.0};
+        if (i < rs) g2 = *reinterpret_cast<const double2*>(Gt + i);
+        gt[i] = g2.x;
+        gt[i + 1] = g2.y;
+    }
 }
 
 // Rank <= 16: Cholesky factor AND inverse in one elimination of the augmented matrix [H; I] (lanes 0..15 hold the
@@ -350,17 +374,19 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
         if constexpr (STAGE) {
             // one round trip to global memory: every lane fetches its row of G and its curvature, then the build
             // reads them back from LDS in the (column, time-chunk) layout of the matrix instruction
-            double gt0[16];
-            load_g_row<16>(gt0, Gl, lane < T ? lane : 0, r);
             const double wt = lane < T ? w_s[lane * L + l] : 0.0;
-            double* Gs = K.tile;  // (T, rs); the staging tile of the result reuses it afterwards
+            double* Gs = K.Gs;  // (T, rs); per wave, the staging tile of the result reuses it afterwards
             double* wcol = K.tile + K.gcap;
-            if (lane < T) {
+            if (!A.shg) {
+                double gt0[16];
+                load_g_row<16>(gt0, Gl, lane < T ? lane : 0, r);
+                if (lane < T) {
 #pragma unroll
-                for (int i = 0; i < 16; i += 2)
-                    if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt0[i], gt0[i + 1]};
-                wcol[lane] = wt;
+                    for (int i = 0; i < 16; i += 2)
+                        if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt0[i], gt0[i + 1]};
+                }
             }
+            if (lane < T) wcol[lane] = wt;
             tri_wave_sync();
             const bool cin = col < rs;
             for (int t0 = 0; t0 < T; t0 += 4) {
@@ -448,7 +474,8 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     __builtin_amdgcn_sched_barrier(0);
     if (A.do_v && ok && lane < T) {
         double gt[RA];
-        load_g_row<RA>(gt, Gl, lane, r);  // (rank <= 16: the same loads as at the top, the compiler keeps the registers)
+        if (STAGE && A.shg) load_g_row_lds<RA>(gt, K.Gs, lane, rs);
+        else load_g_row<RA>(gt, Gl, lane, r);  // (rank <= 16: the same loads as at the top, the compiler keeps the registers)
         double vv = 0.0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -480,9 +507,114 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     }
 }
 
-// Newton step on the posterior mean (estep_fast.hip mean_phase, one latent)
+// Newton step on the posterior mean of one latent (vlgp/core.py:80-95).  With K = GG', H = G'WG and the residual
+// projection ra, the step delta = (I + KW)^-1 (K ra - mu) is evaluated as
+//     delta = G (I + H)^-1 G' (ra + W mu) - mu
+// (push-through identity; the form of estep_fast.hip, u = G G'ra - mu, delta = u - G (I + H)^-1 G'W u, is the same
+// vector with two reductions over the time axis and two expansions instead of one each): one reduction over the
+// rows, two triangular products with X = chol(I + H)^-1, one expansion.
 template <int RP, int RA, bool STAGE>
 __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int lane) {
+    constexpr int NCH = 64 / RP;
+    const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
+    const double* Gl = K.Gl;
+    double* Xl = K.Xl;
+    const double* w_s = A.w + K.r0 * L;
+    const double* ra_s = A.ra + K.r0 * L;
+    double* mu_s = A.mu + K.r0 * L;
+    double* vec = K.vec;
+    double* vec2 = vec + 64;
+    double* scol = K.u;  // s = ra + w mu, one entry per row
+    double gt[RA];
+    double mu_t = 0.0;
+    double* Gs = K.Gs;
+    {
+        const double* xs = A.xg + (int64_t)(K.m * L + l) * A.pkg;
+        constexpr int PK = tri_packed_size(RA);
+        for (int i = lane; i < PK; i += 64) Xl[i] = xs[i];
+    }
+    const bool shg = STAGE && A.shg;
+    if (shg) load_g_row_lds<RA>(gt, Gs, lane < T ? lane : 0, rs);
+    else load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
+    if (lane < T) {
+        mu_t = mu_s[lane * L + l];
+        scol[lane] = fma(w_s[lane * L + l], mu_t, ra_s[lane * L + l]);
+        if constexpr (STAGE) {
+            if (!shg) {
+#pragma unroll
+                for (int i = 0; i < RA; i += 2)
+                    if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt[i], gt[i + 1]};
+            }
+        }
+    }
+    tri_wave_sync();
+    const int j = lane & (RP - 1), ch = lane / RP;
+    // c = G' s
+    double acc = 0.0;
+    if (j < r) {
+        if constexpr (STAGE) {
+#pragma unroll 4
+            for (int t = ch; t < T; t += NCH) acc = fma(Gs[t * rs + j], scol[t], acc);
+        } else {
+#pragma unroll 4
+            for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * r + j], scol[t], acc);
+        }
+    }
+#pragma unroll
+    for (int o = RP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane < RA) vec2[lane] = acc;
+    tri_wave_sync();
+    // z = X c, sol = X' z   (lane = row, then lane = column)
+    double z = 0.0;
+    if (lane < RA) {
+        const double* Xi = Xl + tri_row_off(lane);
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < RA; q += 4) {
+            if (q <= lane) z0 = fma(Xi[q], vec2[q], z0);
+            if (q + 1 <= lane) z1 = fma(Xi[q + 1], vec2[q + 1], z1);
+            if (q + 2 <= lane) z2 = fma(Xi[q + 2], vec2[q + 2], z2);
+            if (q + 3 <= lane) z3 = fma(Xi[q + 3], vec2[q + 3], z3);
+        }
+        z = (z0 + z1) + (z2 + z3);
+    }
+    if (lane < RA) vec[lane] = z;
+    tri_wave_sync();
+    double sol = 0.0;
+    if (lane < RA) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < RA; q += 4) {
+            if (q >= lane) s0 = fma(Xl[tri_row_off(q) + lane], vec[q], s0);
+            if (q + 1 >= lane) s1 = fma(Xl[tri_row_off(q + 1) + lane], vec[q + 1], s1);
+            if (q + 2 >= lane) s2 = fma(Xl[tri_row_off(q + 2) + lane], vec[q + 2], s2);
+            if (q + 3 >= lane) s3 = fma(Xl[tri_row_off(q + 3) + lane], vec[q + 3], s3);
+        }
+        sol = (s0 + s1) + (s2 + s3);
+    }
+    if (lane < RA) vec2[lane] = sol;  // (c was consumed before the previous barrier)
+    tri_wave_sync();
+    if (lane < T) {
+        double s0 = -mu_t, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RA; i += 2)
+            if (i < rs) {
+                const double2 c2 = *reinterpret_cast<const double2*>(vec2 + i);
+                s0 = fma(gt[i], c2.x, s0);
+                s1 = fma(gt[i + 1], c2.y, s1);
+            }
+        double s = s0 + s1;
+        s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
+        mu_s[lane * L + l] = mu_t + s;  // (the last sweep's `dmu` comes from mean_task_last)
+    }
+}
+
+// Newton step on the posterior mean in the form of estep_fast.hip (mean_phase): u = G G'ra - mu, delta = u - G (I + H)^-1 G'W u.
+// u vanishes at the fixed point, so delta keeps its RELATIVE accuracy when the sweeps have converged: in the last sweep
+// of a call this form supplies the step handed back as `dmu` (core.py:96), while mu itself is advanced by mean_task as
+// in every other sweep (so that 10 + 15 sweeps still equal 25 bit for bit).  Writes dmu only.
+template <int RP, int RA, bool STAGE>
+__device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K, int lane) {
     constexpr int NCH = 64 / RP;
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
     const double* Gl = K.Gl;
@@ -496,7 +628,7 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     // STAGE (rank <= 16 in an all-rank-<=-16 launch): G, the residual and the curvature of this latent staged in LDS
     double gt[RA];
     double mu_t = 0.0;
-    double* Gs = K.tile;
+    double* Gs = K.Gs;
     double* racol = K.tile + K.gcap;
     double* wcol = racol + 64;
     {
@@ -505,14 +637,17 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
         for (int i = lane; i < PK; i += 64) Xl[i] = xs[i];
     }
     if constexpr (STAGE) {
-        load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
+        if (A.shg) load_g_row_lds<RA>(gt, Gs, lane < T ? lane : 0, rs);
+        else load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
         if (lane < T) {
             mu_t = mu_s[lane * L + l];
             racol[lane] = ra_s[lane * L + l];
             wcol[lane] = w_s[lane * L + l];
+            if (!A.shg) {
 #pragma unroll
-            for (int i = 0; i < RA; i += 2)
-                if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt[i], gt[i + 1]};
+                for (int i = 0; i < RA; i += 2)
+                    if (i < rs) *reinterpret_cast<double2*>(Gs + lane * rs + i) = double2{gt[i], gt[i + 1]};
+            }
         }
     }
     tri_wave_sync();
@@ -612,19 +747,36 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
             }
         double s = s0 + s1;
         s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
-        if (A.last) A.dmu[(K.r0 + lane) * L + l] = s;
-        mu_s[lane * L + l] = mu_t + s;
+        A.dmu[(K.r0 + lane) * L + l] = s;
     }
+    tri_wave_sync();
 }
 
 // MAXRA: largest register-array size compiled in (16: every latent of the launch has rank <= 16)
-template <int MAXRA, bool MEAN>
+// LASTSW (mean only): the last sweep of the call
+template <int MAXRA, bool MEAN, bool LASTSW = false>
 __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    double* lds_wave = smem + (int64_t)wid * (A.pkl + A.lds_g + 128 + (MEAN ? 192 : 0));
+    double* wave_base = smem;
+    if constexpr (MAXRA == 16) {
+        if (A.shg) {  // one latent per workgroup: its G (T, rs) staged once, zero-padded to the even stride
+            const int l = A.lat[blockIdx.x % A.n_lat];
+            const int pidx = A.unit_prior[0];
+            const int r = A.prior_rl[pidx * A.L + l], rs = (r + 1) & ~1;
+            const double* __restrict__ Gl = A.prior_base[pidx] + A.prior_goff[pidx * A.L + l];
+            for (int i = threadIdx.x; i < A.shg_T * rs; i += 256) {
+                const int t = i / rs, j = i - t * rs;
+                smem[i] = j < r ? Gl[t * r + j] : 0.0;
+            }
+            __syncthreads();
+            wave_base = smem + A.shg_cap;
+        }
+    }
+    double* lds_wave = wave_base + (int64_t)wid * (A.pkl + A.lds_g + 128 + (MEAN ? 192 : 0));
     Task K;
     if (!task_setup(A, K, lds_wave, lane)) return;
+    if (MAXRA == 16 && A.shg) K.Gs = smem;
     if constexpr (MEAN) {
         if (A.failg[K.m * A.L + K.l]) {  // singular system: zero update (core.py:92-94)
             if (lane == 0) atomicAdd(A.fail, 1);
@@ -633,13 +785,16 @@ __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
         }
     }
     if (K.r <= 16) {
+        if constexpr (MEAN && LASTSW) mean_task_last<16, 16, MAXRA == 16>(A, K, lane);
         if constexpr (MEAN) mean_task<16, 16, MAXRA == 16>(A, K, lane);
         else factor_task<16, 16, MAXRA == 16>(A, K, lane);
     } else if constexpr (MAXRA >= 24) {
         if (K.r <= 24) {
+            if constexpr (MEAN && LASTSW) mean_task_last<32, 24, false>(A, K, lane);
             if constexpr (MEAN) mean_task<32, 24, false>(A, K, lane);
             else factor_task<32, 24, false>(A, K, lane);
         } else if constexpr (MAXRA >= 32) {
+            if constexpr (MEAN && LASTSW) mean_task_last<32, 32, false>(A, K, lane);
             if constexpr (MEAN) mean_task<32, 32, false>(A, K, lane);
             else factor_task<32, 32, false>(A, K, lane);
         }
@@ -700,12 +855,13 @@ int run_pass(vlgp_ctx* ctx, const SplitArgs& A, int LT, int kind, const double* 
 int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     const int tasks = A.M * A.n_lat;
     if (tasks == 0) return VLGP_OK;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), blk(256);
-    const size_t lds = (size_t)4 * (A.pkl + A.lds_g + 128 + (mean ? 192 : 0)) * 8;
+    const dim3 grid(A.shg ? (unsigned)(((A.M + 3) / 4) * A.n_lat) : (unsigned)((tasks + 3) / 4)), blk(256);
+    static const int lds_pad = getenv("VLGP_LDS_PAD") ? atoi(getenv("VLGP_LDS_PAD")) : 0;  // occupancy experiments
+    const size_t lds = (size_t)(4 * (A.pkl + A.lds_g + 128 + (mean ? 192 : 0)) + (A.shg ? A.shg_cap : 0)) * 8 + (size_t)lds_pad;
     hipStream_t st = ctx->stream;
 #define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
     do {                                                                                                              \
-        auto fn = esplit_latent<RA, MEANV>;                                                                           \
+        auto fn = (MEANV && A.last) ? esplit_latent<RA, MEANV, MEANV> : esplit_latent<RA, MEANV>;                                                                           \
         if (lds > 64 * 1024)                                                                                          \
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                                        \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
@@ -726,6 +882,7 @@ struct LatentClasses {
     int n_hi = 0, hi[16];
     int maxra_hi = 16;
     int lds_g_lo = 256;
+    int single_T = 0;  // > 0: all units have this length (one prior): the rank <= 16 launch shares G per workgroup
 };
 
 int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
@@ -734,6 +891,7 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         for (int i = 0; i < C.n_hi; ++i) A.lat[i] = C.hi[i];
         A.pkl = tri_packed_size(C.maxra_hi <= 24 ? 24 : 32);
         A.lds_g = 256;
+        A.shg = 0;
         CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
     }
     if (C.n_lo) {
@@ -741,6 +899,16 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         for (int i = 0; i < C.n_lo; ++i) A.lat[i] = C.lo[i];
         A.pkl = tri_packed_size(16);
         A.lds_g = C.lds_g_lo;
+        A.shg = 0;
+        static const bool no_shg = getenv("VLGP_ESTEP_NO_SHARED_G") != nullptr;
+        if (C.single_T > 0 && !no_shg) {
+            // G once per workgroup (one latent x four units): 6.4 KB + 4 x 4.2 KB (factor) or 4 x 3.6 KB (mean) of LDS
+            // instead of 4 x 7.7 / 4 x 9.2 KB -- six / seven workgroups per CU instead of five / four
+            A.shg = 1;
+            A.shg_T = C.single_T;
+            A.shg_cap = C.lds_g_lo;
+            A.lds_g = mean ? 0 : 256;
+        }
         CHK(run_latent_class(ctx, A, 16, mean));
     }
     return VLGP_OK;
@@ -823,6 +991,8 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     C.lds_g_lo = (int)((gw_lo + 1) & ~1LL);  // staged G of a rank <= 16 latent (and the 16 x 16 staging tile)
     if (C.lds_g_lo < 256) C.lds_g_lo = 256;
     A.lds_g = 256; A.pkl = pkg; A.n_lat = 0;
+    A.shg = 0; A.shg_cap = 0; A.shg_T = 0;
+    if (need_prior && us.Tmin == us.Tmax) C.single_T = us.Tmax;
     A.do_v = 0; A.last = 0;
     *handled = 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
