@@ -59,6 +59,8 @@ struct SplitArgs {
     int shg;           // 1: every unit has the same prior; a workgroup = one latent x four units, G staged ONCE per
                        //    workgroup at the start of the LDS (shg_cap doubles) instead of once per wave
     int shg_cap, shg_T;
+    int shg_rk[16];            // shared-G launches: rank and compact factor of lat[i] (no table lookups per wave)
+    const double* shg_gl[16];
     int lat[16];       // their indices
 };
 
@@ -140,6 +142,15 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
         }
         yrow[q] = A.y + rr[q] * N;
         xbrow[q] = HASXB ? A.xb + rr[q] * N : nullptr;
+    }
+    // the residual pass subtracts from ya at the end: fetched here, by the wave that writes (a load after the channel
+    // loop is one more trip to memory in the life of a short wave)
+    double yav[RPL][LT];
+    if constexpr (KIND == SP_RES) {
+#pragma unroll
+        for (int q = 0; q < RPL; ++q)
+#pragma unroll
+            for (int l = 0; l < LT; ++l) yav[q][l] = (part == 0 && l < L) ? A.ya[rr[q] * L + l] : 0.0;
     }
     auto load_rec = [&](int i, double (&rv)[REC]) {
         const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)i * REC);
@@ -242,7 +253,7 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
             for (int l = 0; l < LT; ++l) {
                 if (l < L) {
                     if constexpr (KIND == SP_YA) A.ya[row * L + l] = acc[q][l];
-                    else if constexpr (KIND == SP_RES) A.ra[row * L + l] = A.ya[row * L + l] - acc[q][l];
+                    else if constexpr (KIND == SP_RES) A.ra[row * L + l] = yav[q][l] - acc[q][l];
                     else A.w[row * L + l] = acc[q][l] + A.wconst[l];
                 }
             }
@@ -269,7 +280,20 @@ __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* 
     if (A.shg) {
         K.m = 4 * (blockIdx.x / A.n_lat) + wid;
         if (K.m >= A.M) return false;
-        K.l = A.lat[blockIdx.x % A.n_lat];
+        const int li = blockIdx.x % A.n_lat;
+        K.l = A.lat[li];
+        K.r0 = A.off[K.m];
+        K.T = A.shg_T;
+        K.r = A.shg_rk[li];
+        K.rs = (K.r + 1) & ~1;
+        K.Gl = A.shg_gl[li];
+        K.Xl = lds_wave;
+        K.tile = K.Xl + A.pkl;
+        K.Gs = K.tile;
+        K.gcap = A.lds_g;
+        K.vec = K.tile + A.lds_g + 128;
+        K.u = K.vec + 128;
+        return true;
     } else {
         const int task = blockIdx.x * (blockDim.x >> 6) + wid;
         if (task >= A.M * A.n_lat) return false;
@@ -609,6 +633,114 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     }
 }
 
+// The same step for rank <= 16 without a branch: lane (i = lane & 15, g = lane >> 4) keeps X[i][4g .. 4g + 3] and
+// X[4g .. 4g + 3][i] in registers (straight from the packed global copy, zero outside the triangle), so that both
+// triangular products are four FMAs per lane and two cross-group adds; the time loop of c = G's is fully unrolled with
+// clamped addresses (s is zero beyond the unit).  The generic mean_task compiles its row <= lane predicates into ~150
+// branches and as many exec-mask updates per wave -- the launch was bound by instruction issue, not by arithmetic.
+// CHECK: read the failed-factor flag of the task here (else the caller has tested it).
+template <bool STAGE, bool CHECK>
+__device__ __forceinline__ void mean_task16(const SplitArgs& A, const Task& K, int lane) {
+    const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
+    const int failed = CHECK ? A.failg[K.m * L + l] : 0;
+    const double* __restrict__ Gl = K.Gl;
+    const double* w_s = A.w + K.r0 * L;
+    const double* ra_s = A.ra + K.r0 * L;
+    double* mu_s = A.mu + K.r0 * L;
+    double* vec = K.vec;
+    double* vec2 = vec + 64;
+    double* scol = K.u;
+    double* Gs = K.Gs;
+    const int i = lane & 15, g = lane >> 4;
+    const double* __restrict__ xs = A.xg + (int64_t)(K.m * L + l) * A.pkg;
+    double xr[4], xc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 4 * g + k;
+        const double vr_ = xs[tri_row_off(i) + (q <= i ? q : i)];  // X[i][q]
+        const double vc_ = xs[tri_row_off(q >= i ? q : i) + i];    // X[q][i]
+        xr[k] = q <= i ? vr_ : 0.0;
+        xc[k] = q >= i ? vc_ : 0.0;
+    }
+    const bool shg = STAGE && A.shg;
+    const int tt = lane < T ? lane : 0;
+    double mu_t = 0.0, st = 0.0;
+    if (lane < T) {
+        mu_t = mu_s[lane * L + l];
+        st = fma(w_s[lane * L + l], mu_t, ra_s[lane * L + l]);
+    }
+    scol[lane] = st;
+    if constexpr (STAGE) {
+        if (!shg) {  // (the row of G is read again from the staged copy at the end: not held across the chain)
+            double g0[16];
+            load_g_row<16>(g0, Gl, tt, r);
+            if (lane < T) {
+#pragma unroll
+                for (int q = 0; q < 16; q += 2)
+                    if (q < rs) *reinterpret_cast<double2*>(Gs + lane * rs + q) = double2{g0[q], g0[q + 1]};
+            }
+        }
+    }
+    tri_wave_sync();
+    // c = G' s: lane (column i, time chunk g) takes t = g, g + 4, ...
+    double c;
+    {
+        const int ncol = STAGE ? rs : r;
+        const int jj = i < ncol ? i : 0;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = g + 4 * k;
+            const int tc = t < T ? t : T - 1;
+            const double gv = STAGE ? Gs[tc * rs + jj] : Gl[tc * r + jj];
+            if (k & 1) a1 = fma(gv, scol[t], a1);
+            else a0 = fma(gv, scol[t], a0);
+        }
+        c = i < ncol ? a0 + a1 : 0.0;
+    }
+    c += __shfl_xor(c, 16, 64);
+    c += __shfl_xor(c, 32, 64);
+    if (lane < 16) vec2[lane] = c;
+    tri_wave_sync();
+    // z = X c, sol = X' z
+    double z;
+    {
+        const double2 c01 = *reinterpret_cast<const double2*>(vec2 + 4 * g);
+        const double2 c23 = *reinterpret_cast<const double2*>(vec2 + 4 * g + 2);
+        z = fma(xr[0], c01.x, fma(xr[1], c01.y, fma(xr[2], c23.x, xr[3] * c23.y)));
+    }
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    if (lane < 16) vec[lane] = z;
+    tri_wave_sync();
+    double sol;
+    {
+        const double2 z01 = *reinterpret_cast<const double2*>(vec + 4 * g);
+        const double2 z23 = *reinterpret_cast<const double2*>(vec + 4 * g + 2);
+        sol = fma(xc[0], z01.x, fma(xc[1], z01.y, fma(xc[2], z23.x, xc[3] * z23.y)));
+    }
+    sol += __shfl_xor(sol, 16, 64);
+    sol += __shfl_xor(sol, 32, 64);
+    if (lane < 16) vec2[lane] = sol;  // (c was consumed before the previous barrier)
+    double gt[16];
+    if constexpr (STAGE) load_g_row_lds<16>(gt, Gs, tt, rs);
+    else load_g_row<16>(gt, Gl, tt, r);
+    tri_wave_sync();
+    if (lane < T) {
+        double s0 = -mu_t, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const double2 c2 = *reinterpret_cast<const double2*>(vec2 + q);
+            s0 = fma(gt[q], c2.x, s0);
+            s1 = fma(gt[q + 1], c2.y, s1);
+        }
+        double s = s0 + s1;
+        s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
+        if (!failed) mu_s[lane * L + l] = mu_t + s;  // (the last sweep's `dmu` comes from mean_task_last)
+    }
+    if (CHECK && failed && lane == 0) atomicAdd(A.fail, 1);
+}
+
 // Newton step on the posterior mean in the form of estep_fast.hip (mean_phase): u = G G'ra - mu, delta = u - G (I + H)^-1 G'W u.
 // u vanishes at the fixed point, so delta keeps its RELATIVE accuracy when the sweeps have converged: in the last sweep
 // of a call this form supplies the step handed back as `dmu` (core.py:96), while mu itself is advanced by mean_task as
@@ -754,17 +886,18 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
 
 // MAXRA: largest register-array size compiled in (16: every latent of the launch has rank <= 16)
 // LASTSW (mean only): the last sweep of the call
+// (second launch bound = waves per SIMD: the rank <= 16 launches are bound by the number of resident waves --
+// measured 17 + 103 / n us (mean) and 28 + 124 / n us (factor) with n workgroups per CU)
 template <int MAXRA, bool MEAN, bool LASTSW = false>
-__global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
+__global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_latent(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double* wave_base = smem;
     if constexpr (MAXRA == 16) {
         if (A.shg) {  // one latent per workgroup: its G (T, rs) staged once, zero-padded to the even stride
-            const int l = A.lat[blockIdx.x % A.n_lat];
-            const int pidx = A.unit_prior[0];
-            const int r = A.prior_rl[pidx * A.L + l], rs = (r + 1) & ~1;
-            const double* __restrict__ Gl = A.prior_base[pidx] + A.prior_goff[pidx * A.L + l];
+            const int li = blockIdx.x % A.n_lat;
+            const int r = A.shg_rk[li], rs = (r + 1) & ~1;
+            const double* __restrict__ Gl = A.shg_gl[li];
             for (int i = threadIdx.x; i < A.shg_T * rs; i += 256) {
                 const int t = i / rs, j = i - t * rs;
                 smem[i] = j < r ? Gl[t * r + j] : 0.0;
@@ -778,7 +911,9 @@ __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     if (!task_setup(A, K, lds_wave, lane)) return;
     if (MAXRA == 16 && A.shg) K.Gs = smem;
     if constexpr (MEAN) {
-        if (A.failg[K.m * A.L + K.l]) {  // singular system: zero update (core.py:92-94)
+        // singular system: zero update (core.py:92-94).  The regular rank <= 16 sweeps read the flag with their other
+        // loads and apply it at the store (a test up front is one more dependent trip to memory per wave).
+        if ((LASTSW || K.r > 16) && A.failg[K.m * A.L + K.l]) {
             if (lane == 0) atomicAdd(A.fail, 1);
             if (A.last && lane < K.T) A.dmu[(K.r0 + lane) * A.L + K.l] = 0.0;
             return;
@@ -786,7 +921,7 @@ __global__ void __launch_bounds__(256) esplit_latent(SplitArgs A) {
     }
     if (K.r <= 16) {
         if constexpr (MEAN && LASTSW) mean_task_last<16, 16, MAXRA == 16>(A, K, lane);
-        if constexpr (MEAN) mean_task<16, 16, MAXRA == 16>(A, K, lane);
+        if constexpr (MEAN) mean_task16<MAXRA == 16, !LASTSW>(A, K, lane);
         else factor_task<16, 16, MAXRA == 16>(A, K, lane);
     } else if constexpr (MAXRA >= 24) {
         if (K.r <= 24) {
@@ -883,6 +1018,7 @@ struct LatentClasses {
     int maxra_hi = 16;
     int lds_g_lo = 256;
     int single_T = 0;  // > 0: all units have this length (one prior): the rank <= 16 launch shares G per workgroup
+    const Prior* single = nullptr;
 };
 
 int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
@@ -901,13 +1037,20 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         A.lds_g = C.lds_g_lo;
         A.shg = 0;
         static const bool no_shg = getenv("VLGP_ESTEP_NO_SHARED_G") != nullptr;
-        if (C.single_T > 0 && !no_shg) {
+        if (C.single_T > 0 && C.single && !no_shg) {
+            for (int i = 0; i < C.n_lo; ++i) {
+                A.shg_rk[i] = C.single->rl[C.lo[i]];
+                A.shg_gl[i] = C.single->d_compact + C.single->goff[C.lo[i]];
+            }
             // G once per workgroup (one latent x four units): 6.4 KB + 4 x 4.2 KB (factor) or 4 x 3.6 KB (mean) of LDS
             // instead of 4 x 7.7 / 4 x 9.2 KB -- six / seven workgroups per CU instead of five / four
             A.shg = 1;
             A.shg_T = C.single_T;
             A.shg_cap = C.lds_g_lo;
             A.lds_g = mean ? 0 : 256;
+            // factor: the packed X overwrites the 16 x 16 staging tile (dead after the elimination); the regular mean
+            // sweeps keep X in registers
+            if (!mean || !A.last) A.pkl = 0;
         }
         CHK(run_latent_class(ctx, A, 16, mean));
     }
@@ -992,7 +1135,11 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     if (C.lds_g_lo < 256) C.lds_g_lo = 256;
     A.lds_g = 256; A.pkl = pkg; A.n_lat = 0;
     A.shg = 0; A.shg_cap = 0; A.shg_T = 0;
-    if (need_prior && us.Tmin == us.Tmax) C.single_T = us.Tmax;
+    if (need_prior && us.Tmin == us.Tmax) {
+        C.single_T = us.Tmax;
+        for (auto& kv : ctx->priors)
+            if (kv.second.T == us.Tmax) C.single = &kv.second;
+    }
     A.do_v = 0; A.last = 0;
     *handled = 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
