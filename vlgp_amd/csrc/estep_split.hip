@@ -43,8 +43,10 @@ struct SplitArgs {
     const int64_t* prior_goff;
     const double* y;
     const double* xb;
-    double *mu, *v, *w, *dmu;
-    double *ra, *ya;   // (rows, L)
+    double *mu, *v, *w;  // LATENT-MAJOR working copies (L, ld) of the unit-set arrays: element (row, l) at [l ld + row]
+    double* dmu;         // the unit-set array itself, (rows, L)
+    int64_t ld;          // = rows
+    double *ra, *ya;     // (L, ld) as well
     double* xg;        // (M L, pkg): packed X = chol(I + G'WG)^-1 per (unit, latent)
     int pkg;           // stride of xg
     int pkl;           // doubles of LDS per wave for the packed X of this launch's rank class
@@ -104,6 +106,33 @@ esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double*
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// (rows, L) <-> (L, rows): the split kernels work on latent-major copies -- a wave whose lanes are rows (passes) or time
+// bins of one latent (latent kernels) then touches 8 contiguous bytes per lane instead of 8 of every 8 L (PMC: ~500
+// L1 line accesses per wave of the mean launch with the interleaved layout, most of them for 3 x 50 doubles).
+__global__ void __launch_bounds__(256)
+esplit_to_lm(int L, int64_t rows, const double* __restrict__ a0, const double* __restrict__ a1,
+             const double* __restrict__ a2, double* b0, double* b1, double* b2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over rows * L, latent-major index
+    if (i >= rows * L) return;
+    const int64_t l = i / rows, row = i - l * rows;
+    const int64_t src = row * L + l;
+    b0[i] = a0[src];
+    b1[i] = a1[src];
+    b2[i] = a2[src];
+}
+__global__ void __launch_bounds__(256)
+esplit_from_lm(int L, int64_t rows, const double* __restrict__ b0, const double* __restrict__ b1,
+               const double* __restrict__ b2, double* a0, double* a1, double* a2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over rows * L, row-major index
+    if (i >= rows * L) return;
+    const int64_t row = i / L, l = i - row * L;
+    const int64_t src = l * rows + row;
+    a0[i] = b0[src];
+    a1[i] = b1[src];
+    a2[i] = b2[src];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // CS: the channels of one row group are split over CS waves of the workgroup (a lone wave walking all N channels
 // is a chain of N dependent record loads + exponentials: measured 35 us at two waves per SIMD and 41 us at four --
 // latency, not throughput); the partial sums meet in LDS and are added in wave order (deterministic).
@@ -136,8 +165,8 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             const bool use = l < L && KIND != SP_YA;
-            mr[q][l] = use ? A.mu[rr[q] * L + l] : 0.0;
-            vr[q][l] = use ? A.v[rr[q] * L + l] : 0.0;
+            mr[q][l] = use ? A.mu[(int64_t)l * A.ld + rr[q]] : 0.0;
+            vr[q][l] = use ? A.v[(int64_t)l * A.ld + rr[q]] : 0.0;
             acc[q][l] = 0.0;
         }
         yrow[q] = A.y + rr[q] * N;
@@ -150,7 +179,7 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
 #pragma unroll
         for (int q = 0; q < RPL; ++q)
 #pragma unroll
-            for (int l = 0; l < LT; ++l) yav[q][l] = (part == 0 && l < L) ? A.ya[rr[q] * L + l] : 0.0;
+            for (int l = 0; l < LT; ++l) yav[q][l] = (part == 0 && l < L) ? A.ya[(int64_t)l * A.ld + rr[q]] : 0.0;
     }
     auto load_rec = [&](int i, double (&rv)[REC]) {
         const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)i * REC);
@@ -252,9 +281,9 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
 #pragma unroll
             for (int l = 0; l < LT; ++l) {
                 if (l < L) {
-                    if constexpr (KIND == SP_YA) A.ya[row * L + l] = acc[q][l];
-                    else if constexpr (KIND == SP_RES) A.ra[row * L + l] = yav[q][l] - acc[q][l];
-                    else A.w[row * L + l] = acc[q][l] + A.wconst[l];
+                    if constexpr (KIND == SP_YA) A.ya[(int64_t)l * A.ld + row] = acc[q][l];
+                    else if constexpr (KIND == SP_RES) A.ra[(int64_t)l * A.ld + row] = yav[q][l] - acc[q][l];
+                    else A.w[(int64_t)l * A.ld + row] = acc[q][l] + A.wconst[l];
                 }
             }
         }
@@ -388,8 +417,8 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
     const double* __restrict__ Gl = K.Gl;
     double* Xl = K.Xl;
-    const double* w_s = A.w + K.r0 * L;
-    double* v_s = A.v + K.r0 * L;
+    const double* w_s = A.w + (int64_t)l * A.ld + K.r0;
+    double* v_s = A.v + (int64_t)l * A.ld + K.r0;
     const int j = lane & (RP - 1);
     bool ok;
     const int col = lane & 15, kq = lane >> 4;
@@ -398,7 +427,7 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
         if constexpr (STAGE) {
             // one round trip to global memory: every lane fetches its row of G and its curvature, then the build
             // reads them back from LDS in the (column, time-chunk) layout of the matrix instruction
-            const double wt = lane < T ? w_s[lane * L + l] : 0.0;
+            const double wt = lane < T ? w_s[lane] : 0.0;
             double* Gs = K.Gs;  // (T, rs); per wave, the staging tile of the result reuses it afterwards
             double* wcol = K.tile + K.gcap;
             if (!A.shg) {
@@ -429,7 +458,7 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
                 double g = 0.0, wg = 0.0;
                 if (cin && t < T) {
                     g = Gl[t * r + col];
-                    wg = w_s[t * L + l] * g;
+                    wg = w_s[t] * g;
                 }
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(wg, g, c, 0, 0, 0);
             }
@@ -466,7 +495,7 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
                 const int t = t0 + kq;
                 double ga = 0.0, gb = 0.0;
                 if (t < T) {
-                    if (ca < r) ga = w_s[t * L + l] * Gl[t * r + ca];
+                    if (ca < r) ga = w_s[t] * Gl[t * r + ca];
                     if (cb < r) gb = Gl[t * r + cb];
                 }
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, gb, c, 0, 0, 0);
@@ -517,7 +546,7 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
                 vv = fma(z, z, vv);
             }
         }
-        v_s[lane * L + l] = vv;
+        v_s[lane] = vv;
     }
     // X -> global for the mean update of the next sweep
     {
@@ -543,9 +572,9 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
     const double* Gl = K.Gl;
     double* Xl = K.Xl;
-    const double* w_s = A.w + K.r0 * L;
-    const double* ra_s = A.ra + K.r0 * L;
-    double* mu_s = A.mu + K.r0 * L;
+    const double* w_s = A.w + (int64_t)l * A.ld + K.r0;
+    const double* ra_s = A.ra + (int64_t)l * A.ld + K.r0;
+    double* mu_s = A.mu + (int64_t)l * A.ld + K.r0;
     double* vec = K.vec;
     double* vec2 = vec + 64;
     double* scol = K.u;  // s = ra + w mu, one entry per row
@@ -561,8 +590,8 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     if (shg) load_g_row_lds<RA>(gt, Gs, lane < T ? lane : 0, rs);
     else load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
     if (lane < T) {
-        mu_t = mu_s[lane * L + l];
-        scol[lane] = fma(w_s[lane * L + l], mu_t, ra_s[lane * L + l]);
+        mu_t = mu_s[lane];
+        scol[lane] = fma(w_s[lane], mu_t, ra_s[lane]);
         if constexpr (STAGE) {
             if (!shg) {
 #pragma unroll
@@ -629,7 +658,7 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
             }
         double s = s0 + s1;
         s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
-        mu_s[lane * L + l] = mu_t + s;  // (the last sweep's `dmu` comes from mean_task_last)
+        mu_s[lane] = mu_t + s;  // (the last sweep's `dmu` comes from mean_task_last)
     }
 }
 
@@ -644,9 +673,9 @@ __device__ __forceinline__ void mean_task16(const SplitArgs& A, const Task& K, i
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
     const int failed = CHECK ? A.failg[K.m * L + l] : 0;
     const double* __restrict__ Gl = K.Gl;
-    const double* w_s = A.w + K.r0 * L;
-    const double* ra_s = A.ra + K.r0 * L;
-    double* mu_s = A.mu + K.r0 * L;
+    const double* w_s = A.w + (int64_t)l * A.ld + K.r0;
+    const double* ra_s = A.ra + (int64_t)l * A.ld + K.r0;
+    double* mu_s = A.mu + (int64_t)l * A.ld + K.r0;
     double* vec = K.vec;
     double* vec2 = vec + 64;
     double* scol = K.u;
@@ -666,8 +695,8 @@ __device__ __forceinline__ void mean_task16(const SplitArgs& A, const Task& K, i
     const int tt = lane < T ? lane : 0;
     double mu_t = 0.0, st = 0.0;
     if (lane < T) {
-        mu_t = mu_s[lane * L + l];
-        st = fma(w_s[lane * L + l], mu_t, ra_s[lane * L + l]);
+        mu_t = mu_s[lane];
+        st = fma(w_s[lane], mu_t, ra_s[lane]);
     }
     scol[lane] = st;
     if constexpr (STAGE) {
@@ -736,7 +765,7 @@ __device__ __forceinline__ void mean_task16(const SplitArgs& A, const Task& K, i
         }
         double s = s0 + s1;
         s = fmin(fmax(s, -A.dmu_bound), A.dmu_bound);
-        if (!failed) mu_s[lane * L + l] = mu_t + s;  // (the last sweep's `dmu` comes from mean_task_last)
+        if (!failed) mu_s[lane] = mu_t + s;  // (the last sweep's `dmu` comes from mean_task_last)
     }
     if (CHECK && failed && lane == 0) atomicAdd(A.fail, 1);
 }
@@ -751,9 +780,9 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
     const int L = A.L, l = K.l, T = K.T, r = K.r, rs = K.rs;
     const double* Gl = K.Gl;
     double* Xl = K.Xl;
-    const double* w_s = A.w + K.r0 * L;
-    const double* ra_s = A.ra + K.r0 * L;
-    double* mu_s = A.mu + K.r0 * L;
+    const double* w_s = A.w + (int64_t)l * A.ld + K.r0;
+    const double* ra_s = A.ra + (int64_t)l * A.ld + K.r0;
+    double* mu_s = A.mu + (int64_t)l * A.ld + K.r0;
     double* vec = K.vec;
     double* vec2 = vec + 64;
     double* u = K.u;
@@ -772,9 +801,9 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
         if (A.shg) load_g_row_lds<RA>(gt, Gs, lane < T ? lane : 0, rs);
         else load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
         if (lane < T) {
-            mu_t = mu_s[lane * L + l];
-            racol[lane] = ra_s[lane * L + l];
-            wcol[lane] = w_s[lane * L + l];
+            mu_t = mu_s[lane];
+            racol[lane] = ra_s[lane];
+            wcol[lane] = w_s[lane];
             if (!A.shg) {
 #pragma unroll
                 for (int i = 0; i < RA; i += 2)
@@ -792,7 +821,7 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
             for (int t = ch; t < T; t += NCH) acc = fma(Gs[t * rs + j], racol[t], acc);
         } else {
 #pragma unroll 4
-            for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * r + j], ra_s[t * L + l], acc);
+            for (int t = ch; t < T; t += NCH) acc = fma(Gl[t * r + j], ra_s[t], acc);
         }
     }
 #pragma unroll
@@ -804,7 +833,7 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
     {
         if constexpr (!STAGE) {
             load_g_row<RA>(gt, Gl, lane < T ? lane : 0, r);
-            if (lane < T) mu_t = mu_s[lane * L + l];
+            if (lane < T) mu_t = mu_s[lane];
         }
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -829,7 +858,7 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
             for (int t = ch; t < T; t += NCH) acc = fma(wcol[t] * Gs[t * rs + j], u[t], acc);
         } else {
 #pragma unroll 4
-            for (int t = ch; t < T; t += NCH) acc = fma(w_s[t * L + l] * Gl[t * r + j], u[t], acc);
+            for (int t = ch; t < T; t += NCH) acc = fma(w_s[t] * Gl[t * r + j], u[t], acc);
         }
     }
 #pragma unroll
@@ -1098,7 +1127,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     const int pkg = tri_packed_size(maxra);
     // scratch of the set: ra | ya | xg | failg(int) ; records + wconst in ctx->d_ecols
     const int64_t nRL = us.rows * L;
-    const int64_t need = 2 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8;
+    const int64_t need = 5 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8;
     if (us.scratch_len < need) {
         if (us.d_scratch) HIPCHK(ctx, hipFree(us.d_scratch));
         us.d_scratch = nullptr;
@@ -1118,8 +1147,15 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.N = N; A.L = L; A.M = us.M; A.rows = us.rows;
     A.off = E.off; A.unit_prior = E.unit_prior; A.prior_base = E.prior_base; A.prior_rl = E.prior_rl;
     A.prior_goff = E.prior_goff;
-    A.y = E.y; A.xb = E.xb; A.mu = E.mu; A.v = E.v; A.w = E.w; A.dmu = E.dmu;
-    A.ra = us.d_scratch; A.ya = A.ra + nRL; A.xg = A.ya + nRL; A.pkg = pkg;
+    A.y = E.y; A.xb = E.xb; A.dmu = E.dmu;
+    A.ld = us.rows;
+    A.ra = us.d_scratch; A.ya = A.ra + nRL; A.mu = A.ya + nRL; A.v = A.mu + nRL; A.w = A.v + nRL;
+    A.xg = A.w + nRL; A.pkg = pkg;
+    {
+        const unsigned nb = (unsigned)((nRL + 255) / 256);
+        hipLaunchKernelGGL(esplit_to_lm, dim3(nb), dim3(256), 0, ctx->stream, L, us.rows, E.mu, E.v, E.w, A.mu, A.v, A.w);
+        HIPCHK(ctx, hipGetLastError());
+    }
     A.failg = reinterpret_cast<int*>(A.xg + (int64_t)us.M * L * pkg);
     A.fail = E.fail;
     A.wconst = wconst;
@@ -1182,6 +1218,11 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             rc = run_latent(ctx, A, C, false);
             if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_FACTOR, (double)us.M * L);
         }
+    }
+    if (rc == VLGP_OK) {
+        const unsigned nb = (unsigned)((nRL + 255) / 256);
+        hipLaunchKernelGGL(esplit_from_lm, dim3(nb), dim3(256), 0, ctx->stream, L, us.rows, A.mu, A.v, A.w, E.mu, E.v, E.w);
+        if (hipGetLastError() != hipSuccess) rc = vlgp_fail(ctx, VLGP_ERR_HIP, "esplit_from_lm launch failed");
     }
     vlgp_prof_end(ctx, kind, (double)us.M * (E.n_iter > 0 ? E.n_iter : 1));
     return rc;
