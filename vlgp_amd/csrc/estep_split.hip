@@ -952,8 +952,13 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_
         if constexpr (MEAN && LASTSW) mean_task_last<16, 16, MAXRA == 16>(A, K, lane);
         if constexpr (MEAN) mean_task16<MAXRA == 16, !LASTSW>(A, K, lane);
         else factor_task<16, 16, MAXRA == 16>(A, K, lane);
-    } else if constexpr (MAXRA >= 24) {
-        if (K.r <= 24) {
+    } else if constexpr (MAXRA >= 20) {
+        if (K.r <= 20) {  // ranks 17 .. 20: a latent whose omega drifts up usually stops here (cubic work: 0.58 of 24)
+            if constexpr (MEAN && LASTSW) mean_task_last<32, 20, false>(A, K, lane);
+            if constexpr (MEAN) mean_task<32, 20, false>(A, K, lane);
+            else factor_task<32, 20, false>(A, K, lane);
+        } else if constexpr (MAXRA < 24) {
+        } else if (K.r <= 24) {
             if constexpr (MEAN && LASTSW) mean_task_last<32, 24, false>(A, K, lane);
             if constexpr (MEAN) mean_task<32, 24, false>(A, K, lane);
             else factor_task<32, 24, false>(A, K, lane);
@@ -1032,6 +1037,7 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
         hipLaunchKernelGGL(fn, grid, blk, lds, st, A);                                                                \
     } while (0)
     if (maxra == 16) { if (mean) ESPLIT_LAUNCH(16, true); else ESPLIT_LAUNCH(16, false); }
+    else if (maxra == 20) { if (mean) ESPLIT_LAUNCH(20, true); else ESPLIT_LAUNCH(20, false); }
     else if (maxra == 24) { if (mean) ESPLIT_LAUNCH(24, true); else ESPLIT_LAUNCH(24, false); }
     else { if (mean) ESPLIT_LAUNCH(32, true); else ESPLIT_LAUNCH(32, false); }
 #undef ESPLIT_LAUNCH
@@ -1054,7 +1060,7 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
     if (C.n_hi) {  // the long tasks first
         A.n_lat = C.n_hi;
         for (int i = 0; i < C.n_hi; ++i) A.lat[i] = C.hi[i];
-        A.pkl = tri_packed_size(C.maxra_hi <= 24 ? 24 : 32);
+        A.pkl = tri_packed_size(C.maxra_hi <= 20 ? 20 : (C.maxra_hi <= 24 ? 24 : 32));
         A.lds_g = 256;
         A.shg = 0;
         CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
@@ -1121,7 +1127,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         }
     }
     if (rmax > 32) return VLGP_OK;
-    const int maxra = rmax <= 16 ? 16 : (rmax <= 24 ? 24 : 32);
+    const int maxra = rmax <= 16 ? 16 : (rmax <= 20 ? 20 : (rmax <= 24 ? 24 : 32));
     const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : 10));
     const int REC = (2 * LT + 3 + 1) & ~1;
     const int pkg = tri_packed_size(maxra);
