@@ -525,6 +525,8 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->mstream) (void)hipStreamSynchronize(ctx->mstream);
+    if (ctx->m_graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(ctx->m_graph_exec));
+    ctx->m_graph_exec = nullptr;
     ctx->m_pending = false;
     prof_drain(ctx);
     hx_close((HxComm*)ctx->hx);

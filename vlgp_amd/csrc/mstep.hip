@@ -633,6 +633,29 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     double *d_prep = W + o_prep, *d_stats = W + o_stats, *d_lat = W + o_lat, *d_s1 = W + o_s1,
            *d_mean = W + o_mean, *d_part = W + o_part;
     unsigned* d_ticket = reinterpret_cast<unsigned*>(W + o_tick);
+
+    // Single rank, no per-launch timing: record the whole sequence once and replay it (see ctx.h).
+    static const bool no_graph = getenv("VLGP_NO_MGRAPH") != nullptr;
+    const bool use_graph = ctx->world == 1 && !ctx->prof_on && !no_graph;
+    std::vector<double> key;
+    if (use_graph) {
+        auto pk = [&](const void* p_) { key.push_back((double)(uintptr_t)p_); };
+        pk(us.y); pk(us.x_ones ? nullptr : us.x); pk(us.mu); pk(us.v); pk(W); pk(ctx->d_a); pk(ctx->d_b);
+        pk(ctx->d_noise); pk(ctx->d_da); pk(ctx->d_db); pk(ctx->d_fail_m); pk(ctx->d_gauss);
+        for (double v_ : {(double)us.rows, (double)N, (double)L, (double)P, (double)ctx->n_gauss, (double)n_iter,
+                          (double)use_hessian, eps, lr, da_bound, db_bound})
+            key.push_back(v_);
+        if (ctx->m_graph_exec && key == ctx->m_graph_key) {
+            HIPCHK(ctx, hipGraphLaunch(static_cast<hipGraphExec_t>(ctx->m_graph_exec), st));
+            return VLGP_OK;
+        }
+        if (ctx->m_graph_exec) {
+            (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(ctx->m_graph_exec));
+            ctx->m_graph_exec = nullptr;
+        }
+        HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    }
+    auto enqueue = [&]() -> int {
     HIPCHK(ctx, hipMemsetAsync(d_ticket, 0, sizeof(double) * 2, st));
 
     MArgs A;
@@ -701,5 +724,23 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
         hipLaunchKernelGGL(mstep_solve_kernel, dim3((N + 63) / 64), dim3(64), 0, st, S);
         HIPCHK(ctx, hipGetLastError());
     }
+    return VLGP_OK;
+    };
+    const int rc = enqueue();
+    if (!use_graph) return rc;
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &graph);  // always leave capture mode, whatever enqueue() said
+    if (rc != VLGP_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    HIPCHK(ctx, ec);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIPCHK(ctx, ei);
+    ctx->m_graph_exec = exec;
+    ctx->m_graph_key = key;
+    HIPCHK(ctx, hipGraphLaunch(exec, st));
     return VLGP_OK;
 }
