@@ -87,7 +87,13 @@ def pmc_traffic(kernel_key):
             except Exception:
                 pass
         _PMC_CACHE.setdefault("_", {})
-    return _PMC_CACHE.get(kernel_key, {}).get("hbm_bytes_per_launch")
+    hit = _PMC_CACHE.get(kernel_key)
+    if hit is None and kernel_key.endswith("*"):  # "name<5, 1, false*": the first kernel whose name starts like that
+        for k in sorted(_PMC_CACHE):
+            if k.startswith(kernel_key[:-1]):
+                hit = _PMC_CACHE[k]
+                break
+    return (hit or {}).get("hbm_bytes_per_launch")
 
 
 def host_info():
@@ -300,23 +306,25 @@ def main():
         kernels["esplit_pass<%d>" % LT] = entry(
             n_p, ms_p, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_p / n_p,
             flops_per_launch_executed=fl, sampled="one residual and one curvature pass per E-step call",
-            per_step_ms=ms_p / n_p * 2 * sweeps, pmc_key="esplit_pass<%d, 1, false>" % LT,
-            note="lane <-> row, all channels per lane; the count leaves out the exp (about as many flops again)")
+            per_step_ms=ms_p / n_p * 2 * sweeps, pmc_key="esplit_pass<%d, 1, false*" % LT,
+            note="lane <-> row, the channels of a 64-row group split over four waves; the count leaves out the exp "
+                 "(12 fp64 operations per (row, channel) with the table, about as many flops again)")
         n_f, ms_f, u_f = prof["estep_factor"]
         if n_f:
             fl = float(np.mean([5.0 * T * r * r + 2.0 / 3.0 * r ** 3 for r in rk_mean])) * u_f / n_f
             kernels["esplit_latent<factor>"] = entry(
                 n_f, ms_f, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_f / n_f,
                 flops_per_launch_executed=fl, sampled="one launch per E-step call",
-                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_latent<%d, false>" % ra_typ,
-                note="one wave per (unit, latent): I + G'WG (MFMA), factor + inverse, variance; latency-bound chains")
+                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_latent<%d, false*" % ra_typ,
+                note="one wave per (unit, latent): I + G'WG (MFMA), factor + inverse, variance; bound by vector "
+                     "instruction issue (PMC: ~900 VALU instructions + 13 MFMA per wave, ~85 % of the issue slots)")
         n_u, ms_u, u_u = prof["estep_mean"]
         if n_u:
             fl = float(np.mean([8.0 * T * r for r in rk_mean])) * u_u / n_u
             kernels["esplit_latent<mean>"] = entry(
                 n_u, ms_u, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_u / n_u,
                 flops_per_launch_executed=fl, sampled="one launch per E-step call",
-                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_latent<%d, true>" % ra_typ)
+                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_latent<%d, true*" % ra_typ)
     n_m, ms_m, u_m = prof["mstep"]
     if n_m:
         fl = work["mstep_flops_per_row"] * u_m / n_m
@@ -325,7 +333,7 @@ def main():
             flops_per_launch_executed=fl,
             bytes_per_launch_streamed=work["mstep_bytes_per_row_kernel"] * u_m / n_m,
             bytes_per_launch_survey_count=work["mstep_bytes_per_row_survey"] * u_m / n_m,
-            pmc_key="mstep_accum<%d, 1, 1>" % LT, per_step_ms=ms_m / k_steps,
+            pmc_key="mstep_accum<%d, 1, 1*" % LT, per_step_ms=ms_m / k_steps,
             avg_ms_overlapped=(prof_live["mstep"][1] / prof_live["mstep"][0]) if prof_live["mstep"][0] else None,
             note="compute-bound (exp + FMA per (row, channel)); y is read once per M-step by the PREP pass, "
                  "each Newton launch streams only mu, v")
