@@ -411,6 +411,55 @@ __device__ __forceinline__ bool wave_chol_aug16(double (&a)[16], int lane, int r
     return ok;
 }
 
+// Ranks 17 .. 32: the same augmented elimination over the whole wave -- lanes 0..31 hold the rows of H, lanes 32..63
+// the unit rows, RA register columns per lane; lane 32 + c ends up with column c of X = L^-1 (X[i][c] in a[i]).
+// Ld: RA rows x RA doubles of LDS.  (The LDS row kernels of wave_tri.h that this replaces, factor then a separate
+// triangular inverse with every pivot row broadcast from LDS, took 3.5x as long per task.)
+template <int RA>
+__device__ __forceinline__ bool wave_chol_aug32(double (&a)[RA], int lane, int r, double* Ld) {
+#pragma unroll
+    for (int k = 0; k < RA; ++k) {
+        if (k < r) {
+            if (k > 0) {
+                const double lv = tri_readlane(a[k - 1], k);
+                a[k] = fma(-a[k - 1], lv, a[k]);
+            }
+            const double d = tri_readlane(a[k], k);
+            double y = __builtin_amdgcn_rsq(d);
+            if (k + 1 < RA && k >= 1) {  // column k + 1 <- columns 0 .. k - 1
+                const double* row = Ld + (k + 1) * RA;
+                double a0 = a[k + 1], a1 = 0.0;
+#pragma unroll
+                for (int m = 0; m + 1 < k; m += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(row + m);
+                    a0 = fma(-a[m], v.x, a0);
+                    a1 = fma(-a[m + 1], v.y, a1);
+                }
+                if (k & 1) a0 = fma(-a[k - 1], row[k - 1], a0);
+                a[k + 1] = a0 + a1;
+                asm volatile("" : "+v"(a[k + 1]));
+            }
+            {   // one third-order step: y (1 + e / 2 + 3 e^2 / 8), e = 1 - d y^2 (v_rsq_f64 starts at ~2^-26)
+                const double e = fma(-d * y, y, 1.0);
+                y = fma(y * e, fma(0.375, e, 0.5), y);
+            }
+            a[k] *= y;
+            asm volatile("" : "+v"(a[k]));
+            if (k + 1 < RA) {
+                if (lane < RA) Ld[lane * RA + k] = a[k];  // (rows RA .. 31 are never pivot rows)
+                tri_wave_order();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // a pivot that is not positive and finite leaves NaN / inf on the diagonal of X (lane 32 + c, a[c])
+    bool fin = true;
+#pragma unroll
+    for (int c = 0; c < RA; ++c)
+        if (lane == 32 + c && c < r) fin = a[c] > 0.0 && a[c] < 1e300;
+    return __builtin_amdgcn_ballot_w64(!fin) == 0;
+}
+
 // factor I + G'WG, invert, optionally refresh v (estep_fast.hip factor_phase, one latent)
 template <int RP, int RA, bool STAGE>
 __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, int lane) {
@@ -486,41 +535,69 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
                 if (i >= lane - 16) Xl[tri_row_off(i) + lane - 16] = i < r ? a[i] : (i == lane - 16 ? 1.0 : 0.0);
         }
     } else {
+        // H = G'WG on the matrix pipe: the lower block triangle of the 32 x 32 matrix, staged (with the mirror image of
+        // the off-diagonal tile) as RA rows of stride RA + 2 in LDS
+        constexpr int LDH = RA + 2;
+        double* ht = K.tile;
+        {
+            // all operands first (up to 48 independent loads in flight per lane), then the 39 matrix instructions: with
+            // a load in front of every instruction the build was a chain of 39 trips to L2
+            double g0[16], g1[16], wv[16];  // G[t][col], G[t][16 + col], w[t] at t = 4 k + kq
 #pragma unroll
-        for (int tile = 0; tile < 3; ++tile) {  // lower block triangle of the 32 x 32 matrix
-            const int bi = tile == 0 ? 0 : 1, bj = tile == 2 ? 1 : 0;
-            const int ca = 16 * bi + col, cb = 16 * bj + col;
-            double4_t c = {0.0, 0.0, 0.0, 0.0};
-            for (int t0 = 0; t0 < T; t0 += 4) {
-                const int t = t0 + kq;
-                double ga = 0.0, gb = 0.0;
-                if (t < T) {
-                    if (ca < r) ga = w_s[t] * Gl[t * r + ca];
-                    if (cb < r) gb = Gl[t * r + cb];
-                }
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, gb, c, 0, 0, 0);
+            for (int k = 0; k < 16; ++k) {
+                const int t = 4 * k + kq;
+                const bool in = t < T;
+                const int tc = in ? t : 0;
+                const double wt = w_s[tc];
+                const double ga = Gl[tc * r + (col < r ? col : 0)];
+                const double gb = Gl[tc * r + (16 + col < r ? 16 + col : 0)];
+                wv[k] = in ? wt : 0.0;
+                g0[k] = (in && col < r) ? ga : 0.0;
+                g1[k] = (in && 16 + col < r) ? gb : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = 16 * bi + kq + 4 * q;
-                if (cb <= row && row < RA) Xl[tri_row_off(row) + cb] = c[q] + (cb == row ? 1.0 : 0.0);
+            for (int tile = 0; tile < 3; ++tile) {
+                const int bi = tile == 0 ? 0 : 1, bj = tile == 2 ? 1 : 0;
+                const int cb = 16 * bj + col;
+                double4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (4 * k < T) {
+                        const double opa = wv[k] * (bi ? g1[k] : g0[k]);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(opa, bj ? g1[k] : g0[k], c, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * bi + kq + 4 * q;
+                    if (row < RA && cb < RA) {
+                        ht[row * LDH + cb] = c[q];
+                        if (tile == 1) ht[cb * LDH + row] = c[q];
+                    }
+                }
             }
         }
         tri_wave_sync();
-        __builtin_amdgcn_sched_barrier(0);
+        double a[RA];  // lanes 0..31: rows of I + G'WG; lanes 32..63: unit rows
         {
-            double rr[RA];
-            ok = wave_chol_rows<RA>(rr, Xl, lane);
-        }
-        {
-            double x[RA];
-            wave_tri_inverse_cols<RA>(Xl, x, lane);
-            tri_wave_sync();
-            if (lane < RA) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+            const int jr = lane & 31;
+            const double* hrow = ht + (jr < RA ? jr : 0) * LDH;
 #pragma unroll
-                for (int i = 0; i < RA; ++i)
-                    if (i >= lane) Xl[tri_row_off(i) + lane] = x[i];
+            for (int i = 0; i < RA; i += 2) {
+                const double2 h2 = *reinterpret_cast<const double2*>(hrow + i);
+                a[i] = (lane < 32 ? h2.x : 0.0) + (i == jr ? 1.0 : 0.0);
+                a[i + 1] = (lane < 32 ? h2.y : 0.0) + (i + 1 == jr ? 1.0 : 0.0);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) asm volatile("" : "+v"(a[i]));
+        tri_wave_order();
+        ok = wave_chol_aug32<RA>(a, lane, r, K.tile);
+        tri_wave_order();
+        if (lane >= 32 && lane < 32 + RA) {  // X row-major packed in LDS: X[i][c], i >= c = lane - 32
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                if (i >= lane - 32) Xl[tri_row_off(i) + lane - 32] = i < r ? a[i] : (i == lane - 32 ? 1.0 : 0.0);
         }
     }
     tri_wave_sync();
@@ -1063,6 +1140,10 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         A.pkl = tri_packed_size(C.maxra_hi <= 20 ? 20 : (C.maxra_hi <= 24 ? 24 : 32));
         A.lds_g = 256;
         A.shg = 0;
+        if (!mean) {  // factor: staging tile of H, then the multiplier rows (RA x (RA + 2) doubles); X overwrites it
+            A.lds_g = C.maxra_hi * (C.maxra_hi + 2);
+            A.pkl = 0;
+        }
         CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
     }
     if (C.n_lo) {
