@@ -106,15 +106,28 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
         double* bufA = buf;
         double* bufX = buf + (TP - col0) * LDB;
         // ---- 1. Schur terms of this panel from the result registers -> LDS ----
+        // N and M accumulate the NEGATIVE Schur terms (neg:[0,1,0] on the matrix instruction is free), and the unit
+        // diagonals are planted here, four entries per lane: the diagonal block of A gets diag(one) - N, the rows
+        // col0 .. col0 + 15 of X' get I.  The row assembly below is then one FMA (A) and a plain load (X') per entry
+        // instead of compare + select + subtract on top (6 of 11 vector operations per column pair).
         if (k > 0) {
 #pragma unroll
             for (int bi = k; bi < NB; ++bi)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) bufA[(16 * (bi - k) + g + 4 * p) * LDB + c] = N[bi][k][p];
+                for (int p = 0; p < 4; ++p) {
+                    double val = N[bi][k][p];
+                    if (bi == k) {
+                        const double one = KMODE ? (col0 + c < tr_k ? 0.0 : 1.0) : 1.0;
+                        val += (g + 4 * p == c) ? one : 0.0;
+                    }
+                    bufA[(16 * (bi - k) + g + 4 * p) * LDB + c] = val;
+                }
 #pragma unroll
             for (int i = 0; i < k; ++i)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) bufX[(16 * i + g + 4 * p) * LDB + c] = M[i][k][p];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) bufX[(col0 + g + 4 * p) * LDB + c] = (g + 4 * p == c) ? 1.0 : 0.0;
             tri_wave_sync();
         }
         // ---- 2. one row per lane: ra = row (col0 + lane) of A - N, rx = row `lane` of I - M ----
@@ -129,7 +142,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
             // subexpressions of all panels, computed once at the top and kept in ~40 registers to the end
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const double* pm = lane < col0 ? bufX + lane * LDB : zrow;  // rows of X' at / below the panel have no M terms
+            const double* pm = lane < col0 + 16 ? bufX + lane * LDB : zrow;  // (k > 0) -M, I on the diagonal block rows, nothing below
             const double* pk = kvm + 63 + lane;  // kvm[63 + lane - q] = K[|i - (col0 + q)|], jitter included at distance 0
 #pragma unroll
             for (int q = 0; q < 16; q += 2) {
@@ -139,19 +152,26 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     nv = *reinterpret_cast<const double2*>(pn + q);
                     mv = *reinterpret_cast<const double2*>(pm + q);
                 }
-                // A = diag(one) + S K S: the unit diagonal rides in the FMA's addend
-                ra[q] = fma(si * sj.x, pk[-q], (ln == q ? one : 0.0) - nv.x);
-                ra[q + 1] = fma(si * sj.y, pk[-q - 1], (ln == q + 1 ? one : 0.0) - nv.y);
-                rx[q] = (ln == col0 + q ? 1.0 : 0.0) - mv.x;
-                rx[q + 1] = (ln == col0 + q + 1 ? 1.0 : 0.0) - mv.y;
+                // A = diag(one) + S K S - N: the addend comes ready from LDS (first panel: the unit diagonal by select)
+                if (k > 0) {
+                    ra[q] = fma(si * sj.x, pk[-q], nv.x);
+                    ra[q + 1] = fma(si * sj.y, pk[-q - 1], nv.y);
+                    rx[q] = mv.x;
+                    rx[q + 1] = mv.y;
+                } else {
+                    ra[q] = fma(si * sj.x, pk[-q], (ln == q ? one : 0.0));
+                    ra[q + 1] = fma(si * sj.y, pk[-q - 1], (ln == q + 1 ? one : 0.0));
+                    rx[q] = (ln == q ? 1.0 : 0.0);
+                    rx[q + 1] = (ln == q + 1 ? 1.0 : 0.0);
+                }
             }
             if (last) {
 #pragma unroll
                 for (int t = 0; t < E; ++t) {  // tail columns: N from ntail[t][row], M from mt[t]
                     const double sj = sv[TB + t];
                     const double nv = ntail[t * 64 + (i < 64 ? i : 63)];
-                    ra[16 + t] = fma(si * sj, pk[-16 - t], (ln == 16 + t ? one : 0.0) - nv);
-                    rx[16 + t] = (ln == TB + t ? 1.0 : 0.0) - mt[t];
+                    ra[16 + t] = fma(si * sj, pk[-16 - t], (ln == 16 + t ? one : 0.0) + nv);  // ntail, mt hold -N, -M
+                    rx[16 + t] = (ln == TB + t ? 1.0 : 0.0) + mt[t];
                 }
             }
         }
@@ -249,11 +269,11 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     m0 = fma(rx[q], l2.x, m0);
                     m1 = fma(rx[q + 1], l2.y, m1);
                 }
-                mt[t] += (lane < nX) ? m0 + m1 : 0.0;
+                mt[t] -= (lane < nX) ? m0 + m1 : 0.0;
                 asm volatile("" : "+v"(mt[t]));  // evaluate now (else the dot product waits, operands and all, for the last panel)
                 if (lane >= 16 && lane < rowsA) {
                     double* pn = ntail + t * 64 + col0 + lane;
-                    *pn = (k > 0 ? *pn : 0.0) + (n0 + n1);
+                    *pn = (k > 0 ? *pn : 0.0) - (n0 + n1);
                 }
             }
         }
@@ -286,10 +306,10 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int bi = k + 1; bi < NB; ++bi)
-                    N[bi][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[k + 1][kk], N[bi][k + 1], 0, 0, 0);
+                    N[bi][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[k + 1][kk], N[bi][k + 1], 0, 0, 2);
 #pragma unroll
                 for (int i = 0; i <= k; ++i)
-                    M[i][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[k + 1][kk], M[i][k + 1], 0, 0, 0);
+                    M[i][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[k + 1][kk], M[i][k + 1], 0, 0, 2);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -297,10 +317,10 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                 for (int bj = k + 2; bj < NB; ++bj) {
 #pragma unroll
                     for (int bi = bj; bi < NB; ++bi)
-                        N[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[bj][kk], N[bi][bj], 0, 0, 0);
+                        N[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[bj][kk], N[bi][bj], 0, 0, 2);
 #pragma unroll
                     for (int i = 0; i <= k; ++i)
-                        M[i][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[bj][kk], M[i][bj], 0, 0, 0);
+                        M[i][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[bj][kk], M[i][bj], 0, 0, 2);
                 }
             }
         }
