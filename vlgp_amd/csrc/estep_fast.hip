@@ -595,7 +595,7 @@ int launch_estep_fast(vlgp_ctx* ctx, UnitSet& us, EstepArgs A, int* handled) {
     A.lds_gsz = (int)gsz;
     A.lds_T = Tc;
     A.lds_scr = (int)scr;
-    if (!ctx->d_ecols) HIPCHK(ctx, hipMalloc(&ctx->d_ecols, sizeof(double) * ((size_t)N * 34 + 32)));
+    if (!ctx->d_ecols) HIPCHK(ctx, hipMalloc(&ctx->d_ecols, sizeof(double) * ((size_t)N * 50 + 32)));
     A.cols_g = ctx->d_ecols;
     A.wconst_g = ctx->d_ecols + (int64_t)N * 34;
     hipLaunchKernelGGL(estep_cols_kernel, dim3(1), dim3(256), 0, ctx->stream, N, L, LT, ctx->d_a, ctx->d_b, ctx->d_noise,
