@@ -1119,12 +1119,17 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
 
 // The round on the matrix pipe (hstep_mfma.h): one wave per segment, NW waves per block.  Blocks [0, n_eval) are
 // the K blocks as in hstep_round_lean (all NW waves share the trace phase).
-template <int T, int NW>
-__global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hstep_round_mfma(HRoundArgs R) {
+// ONESET (T = 50 only): the one-register-set task routine hstep_task_mfma50 (buffer row = lane); else the two-set routine.
+template <int T, int NW, bool ONESET = false>
+__global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3) : 2) : 1) hstep_round_mfma(HRoundArgs R) {
+    static_assert(!ONESET || T == 50, "the one-set routine is written for 50 = 3 x 16 + 2");
     using G = HmGeom<T>;
     constexpr int LDK = T | 2;                  // row stride of K^-1 in LDS: 2 mod 4 -> conflict-free operand reads
-    constexpr int KBLK = G::TASK + T * LDK;     // wave 0's task buffer | K^-1
-    constexpr int LDSN = NW * G::TASK > KBLK ? NW * G::TASK : KBLK;
+    constexpr int TASKW = ONESET ? HmGeom50::TASK : G::TASK;           // per-wave task buffer
+    constexpr int SHR = ONESET ? HmGeom50::SHARED : 0;                // per-workgroup tables (one-set layout)
+    constexpr int KBLK = TASKW + T * LDK + SHR;  // wave 0's task buffer | K^-1 (| tables)
+    constexpr int LDSN = NW * TASKW + SHR > KBLK ? NW * TASKW + SHR : KBLK;
+    static_assert(!ONESET || LDSN * 8 + 128 <= 40960, "four workgroups per CU");
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
     __shared__ double part[NW][2];
     __shared__ int s_last;
@@ -1135,10 +1140,19 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hste
         // then every wave takes block rows of the two products against the second moments of this latent.
         const int e = blockIdx.x;
         double* buf = lds;
-        double* Kl = lds + G::TASK;
+        double* Kl = lds + TASKW;
+        double* kvs = lds + LDSN - SHR;               // one-set layout: shared tables at the end of the block's LDS
+        double* dks = kvs + HmGeom50::KVN;
         if (wid == 0) {
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
-            {
+            if constexpr (ONESET) {
+                const double d = lane * A.dt, d2 = d * d;
+                const double kk = sigmasq * exp(-omega * d2);
+                if (lane < HmGeom50::SVN) buf[HmGeom50::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
+                if (lane < T) kvs[17 + lane] = kk + (lane == 0 ? eps : 0.0);
+                if (lane >= 1 && lane <= 17) kvs[17 - lane] = kk;
+                if (lane < HmGeom50::DKN) dks[lane] = -kk * d2 * omega;
+            } else {
                 const double d = lane * A.dt, d2 = d * d;
                 const double kk = sigmasq * exp(-omega * d2);
                 buf[G::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
@@ -1149,7 +1163,8 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hste
             }
             tri_wave_sync();
             double logdet, unused;
-            hstep_task_mfma<T, true>(buf, eps, lane, logdet, unused, A.Tr, Kl, LDK);
+            if constexpr (ONESET) hstep_task_mfma50<true>(buf, kvs, dks, eps, lane, logdet, unused, A.Tr, Kl, LDK);
+            else hstep_task_mfma<T, true>(buf, eps, lane, logdet, unused, A.Tr, Kl, LDK);
             if (lane == 0) {
                 A.scal[4 * e + 0] = logdet;
                 A.scal[4 * e + 1] = 0.0;
@@ -1159,8 +1174,8 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hste
         }
         __syncthreads();
         double quad, gq;
-        hstep_kblock_products<T>(Kl, LDK, R.mom + (int64_t)A.latent[e] * T * T, buf + G::O_DKV, A.Tr, lane, wid, NW,
-                                 quad, gq);
+        hstep_kblock_products<T>(Kl, LDK, R.mom + (int64_t)A.latent[e] * T * T, ONESET ? dks : buf + G::O_DKV, A.Tr, lane,
+                                 wid, NW, quad, gq);
         for (int o = 32; o > 0; o >>= 1) {
             quad += __shfl_xor(quad, o, 64);
             gq += __shfl_xor(gq, o, 64);
@@ -1186,11 +1201,21 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hste
         const int seg = bx * NW + wid;
         double tr = 0.0, cs = 0.0;
         if (seg < A.M) {
-            double* buf = lds + wid * G::TASK;
+            double* buf = lds + wid * TASKW;
+            double* kvs = lds + LDSN - SHR;  // one-set layout: every wave of the block writes the same table values
+            double* dks = kvs + HmGeom50::KVN;
             const int l = A.latent[e];
             const int64_t r0row = A.off[seg];
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
-            {
+            if constexpr (ONESET) {
+                const double w = lane < A.Tr ? A.w[(r0row + lane) * A.L + l] : 0.0;  // rows >= Tr: identity padding
+                const double d = lane * A.dt, d2 = d * d;
+                const double kk = sigmasq * exp(-omega * d2);
+                if (lane < HmGeom50::SVN) buf[HmGeom50::O_SV + lane] = sqrt(w);
+                if (lane < T) kvs[17 + lane] = kk + (lane == 0 ? eps : 0.0);
+                if (lane >= 1 && lane <= 17) kvs[17 - lane] = kk;
+                if (lane < HmGeom50::DKN) dks[lane] = -kk * d2 * omega;
+            } else {
                 const double w = lane < A.Tr ? A.w[(r0row + lane) * A.L + l] : 0.0;  // rows >= Tr: identity padding
                 const double d = lane * A.dt, d2 = d * d;
                 const double kk = sigmasq * exp(-omega * d2);
@@ -1201,7 +1226,9 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? 3 : 2) : 1) hste
                 if (lane < 32) buf[G::O_Z + lane] = 0.0;
             }
             tri_wave_sync();
-            const bool ok = hstep_task_mfma<T>(buf, eps, lane, tr, cs);
+            bool ok;
+            if constexpr (ONESET) ok = hstep_task_mfma50<false>(buf, kvs, dks, eps, lane, tr, cs);
+            else ok = hstep_task_mfma<T>(buf, eps, lane, tr, cs);
             if (!ok) { tr = nan(""); cs = nan(""); }  // failed factorisation: propagates into ll, dll
             for (int o = 32; o > 0; o >>= 1) {
                 tr += __shfl_xor(tr, o, 64);
@@ -1371,6 +1398,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool padded = T == 50 && getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
             const bool lean = getenv("VLGP_HSTEP_LEAN") != nullptr;                 // register-row kernel (round 1)
             const bool mfma = !padded && !lean;
+            static const bool twoset = getenv("VLGP_HSTEP_TWOSET") != nullptr;  // two-register-set task routine at window <= 50
             R.n_eval = n_eval; R.nb = mfma ? (M + MFMA_NW - 1) / MFMA_NW : (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
@@ -1384,8 +1412,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else if (lean)
                 hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
-            else if (TC == 50)
+            else if (TC == 50 && twoset)
                 hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
+                                   ctx->stream, R);
+            else if (TC == 50)
+                hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW, true>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
                                    ctx->stream, R);
             else
                 hipLaunchKernelGGL((hstep_round_mfma<64, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,

@@ -407,6 +407,389 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// TP = 50, ONE register set: buffer row = lane.
+//
+// In panel k (columns col0 = 16 k ...) the elimination touches the rows of A at and below the diagonal block
+// (nA = 50 - col0 of them) and the rows of X' = L^-T that have entries in these columns (col0 + W).  That is 66 rows
+// (68 in the last, 18-wide, panel) and the routine above gives the two kinds a register set each, every vector
+// instruction of the elimination issued twice.  But the last rows of the diagonal block of X' are trivial -- row
+// col0 + 15 is (0 .. 0, y15), row col0 + 14 is (0 .. 0, y14, -y14 y15 L[15][14]) -- so 64 lanes are enough:
+//     lane < nA:   row col0 + lane of A                       (rows of the panel buffer 0 .. nA - 1)
+//     lane >= nA:  row lane - nA of X' (the 16 k rows of the earlier blocks, then rows 0 .. 13 of this block:
+//                  unit rows on entry)                        (rows nA .. 63 of the panel buffer)
+//     "special" rows col0 + 14 .. col0 + W - 1 of X': a few wave-uniform operations from the reciprocal pivots and
+//                  the multipliers L[j][m], j > m >= 14, after the elimination (rows 64, 65 of the panel buffer).
+// The row a lane holds moves 16 lanes down per panel for BOTH kinds, so the panel buffer is simply indexed by the lane,
+// and the tail-column accumulators (columns 48, 49 of N for the rows of A, of M for the rows of X') ride along in two
+// registers per lane, moved 16 lanes down between panels (no LDS tables).  Half the elimination FMAs, half the panel
+// assembly, 36 registers fewer than the two-set routine; same matrix instructions.
+//
+// LDS: 10 KB per segment so that FOUR workgroups of four waves share a CU (the round is bound by the latency of its
+// dependent chains: PMC, profiles/r2): per wave the panel buffer (66 x 18) and sqrt(w) (52); per workgroup -- all its
+// segments belong to one evaluation -- the first column of K at distances -17 .. 49 (kvs[17 + d], jitter at 0) and of
+// dK (52).  The 2 x 16 transposition scratch of the tail accumulators aliases rows 64, 65 of the panel buffer (written
+// after the elimination, the scratch is read before it).
+struct HmGeom50 {
+    static constexpr int LDB = 18, ROWS = 66;
+    static constexpr int O_SV = ROWS * LDB;  // 1188
+    static constexpr int SVN = 52;
+    static constexpr int TASK = O_SV + SVN;  // 1240 doubles per wave
+    static constexpr int KVN = 68, DKN = 52; // shared per workgroup
+    static constexpr int SHARED = KVN + DKN;
+};
+
+template <bool KMODE = false>
+__device__ __forceinline__ bool hstep_task_mfma50(double* buf, const double* kvs, const double* dkv, double eps, int lane,
+                                                  double& tr, double& cs, int tr_k = 0, double* kl = nullptr, int ldk = 0) {
+    constexpr int TP = 50;
+    using G = HmGeom<TP>;
+    constexpr int NB = G::NB, E = G::E, LDB = G::LDB, WL = G::WL, TB = 16 * NB;
+    static_assert(NB == 3 && E == 2 && LDB == 18 && WL == 18 && HmGeom50::LDB == LDB, "written for 50 = 3 x 16 + 2");
+    const double* sv = buf + HmGeom50::O_SV;
+    double* zs = buf + 64 * LDB;  // 2 x 16: tail-column accumulators of the rows of the diagonal block, as rows
+    const int c = lane & 15, g = lane >> 4;
+    hm_d4 N[NB][NB], M[NB][NB], P[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            N[i][j] = hm_d4{0.0, 0.0, 0.0, 0.0};
+            M[i][j] = hm_d4{0.0, 0.0, 0.0, 0.0};
+            P[i][j] = hm_d4{0.0, 0.0, 0.0, 0.0};
+        }
+    double tl[E] = {0.0, 0.0};  // minus the tail columns (48, 49) of N (lanes of A) / of M (lanes of X') for this lane's row
+    double r[WL];
+    double xs[4][4];  // special rows of the last panel: xs[a][b] = X'[46 + a][46 + b], b >= a
+    double logdet = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int col0 = 16 * k;
+        const int W = G::width(k);
+        const bool last = k == NB - 1;
+        const int nA = TP - col0;  // lanes of A; X' row of lane >= nA: lane - nA
+        double* bufA = buf;
+        double* bufX = buf + nA * LDB;
+        // ---- 1. Schur terms of this panel from the result registers -> LDS (negative, unit diagonals planted) ----
+        if (k > 0) {
+#pragma unroll
+            for (int bi = k; bi < NB; ++bi)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    double val = N[bi][k][p];
+                    if (bi == k) {
+                        const double one = KMODE ? (col0 + c < tr_k ? 0.0 : 1.0) : 1.0;
+                        val += (g + 4 * p == c) ? one : 0.0;
+                    }
+                    bufA[(16 * (bi - k) + g + 4 * p) * LDB + c] = val;
+                }
+#pragma unroll
+            for (int i = 0; i < k; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) bufX[(16 * i + g + 4 * p) * LDB + c] = M[i][k][p];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) bufX[(col0 + g + 4 * p) * LDB + c] = (g + 4 * p == c) ? 1.0 : 0.0;
+            // the tail rows of A read their row of N from the tail-column accumulators of the rows col0 .. col0 + 15
+            if (lane < 16) {
+                zs[lane] = tl[0];
+                zs[16 + lane] = tl[1];
+            }
+            tri_wave_sync();
+        }
+        // ---- 2. one row per lane ----
+        {
+            const bool isA = lane < nA;
+            const int i = col0 + lane;  // row of A (lanes of A)
+            const double si = isA ? sv[i] : 0.0;  // lanes of X': r = addend exactly (table values are finite)
+            int ln = lane;  // opaque per panel (see the two-set routine)
+            asm volatile("" : "+v"(ln));
+            const double* pk = kvs + 17 + (lane < TP ? lane : TP - 1);  // pk[-q] = K[|i - (col0 + q)|], jitter at distance 0
+            const double* pr = (lane >= TB - col0 && lane < nA) ? zs + (lane - (TB - col0)) * 16 : buf + lane * LDB;
+            // first panel: unit entry by select (rows of A: diag(one); lanes >= 50: unit rows 0 .. 13 of X')
+            const int upos = ln < nA ? ln : ln - nA;
+            const double uval = KMODE ? ((isA && i < tr_k) ? 0.0 : 1.0) : 1.0;
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const double2 sj = *reinterpret_cast<const double2*>(sv + col0 + q);
+                if (k > 0) {
+                    const double2 av = *reinterpret_cast<const double2*>(pr + q);
+                    r[q] = fma(si * sj.x, pk[-q], av.x);
+                    r[q + 1] = fma(si * sj.y, pk[-q - 1], av.y);
+                } else {
+                    r[q] = fma(si * sj.x, pk[-q], (upos == q ? uval : 0.0));
+                    r[q + 1] = fma(si * sj.y, pk[-q - 1], (upos == q + 1 ? uval : 0.0));
+                }
+            }
+            if (last) {
+#pragma unroll
+                for (int t = 0; t < E; ++t) {  // tail columns: -N (rows of A, + the unit diagonal) / -M (rows of X') from tl
+                    const double sj = sv[TB + t];
+                    r[16 + t] = fma(si * sj, pk[-16 - t], (ln == 16 + t ? uval : 0.0) + tl[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WL; ++q)
+            if (q < W) asm volatile("" : "+v"(r[q]));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. elimination of the panel (lazy updates one step ahead, multipliers from the LDS copy of the finished
+        // columns of the diagonal block = rows 0 .. W - 1 of the panel buffer) ----
+        double ysp[4] = {0.0, 0.0, 0.0, 0.0};  // reciprocal pivots of columns 14 ..
+        {
+            double* Ld = buf;
+            constexpr int LDD = LDB;
+            double yprod = 1.0;
+#pragma unroll
+            for (int j = 0; j < WL; ++j) {
+                if (j < W) {
+                    if (j > 0) {
+                        const double lv = tri_readlane(r[j - 1], j);
+                        r[j] = fma(-r[j - 1], lv, r[j]);
+                    }
+                    const double d = tri_readlane(r[j], j);
+                    double y = __builtin_amdgcn_rsq(d);
+                    if (j + 1 < W && j >= 1) {  // column j + 1 <- columns 0 .. j - 1
+                        const double* row = Ld + (j + 1) * LDD;
+                        double a0 = r[j + 1], a1 = 0.0;
+#pragma unroll
+                        for (int m = 0; m + 1 < j; m += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(row + m);
+                            a0 = fma(-r[m], v.x, a0);
+                            a1 = fma(-r[m + 1], v.y, a1);
+                        }
+                        if (j & 1) a0 = fma(-r[j - 1], row[j - 1], a0);
+                        r[j + 1] = a0 + a1;
+                        asm volatile("" : "+v"(r[j + 1]));
+                    }
+                    {
+                        const double e = fma(-d * y, y, 1.0);
+                        y = fma(y * e, fma(0.375, e, 0.5), y);
+                    }
+                    r[j] *= y;
+                    if (j >= 14) ysp[j - 14] = y;
+                    if (KMODE) {
+                        yprod *= y;
+                        asm volatile("" : "+v"(yprod));
+                    }
+                    asm volatile("" : "+v"(r[j]));
+                    if (j + 1 < W) {
+                        if (lane < W) Ld[lane * LDD + j] = r[j];
+                        tri_wave_order();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (KMODE) logdet -= log(yprod);
+        }
+        // ---- 3b. the special rows of X' (wave-uniform): row 14 + a of this block, columns 14 + b, b >= a ----
+        //     x[a][a] = y_a,   x[a][b] = -y_b sum_{a <= m < b} x[a][m] L[14 + b][14 + m]
+        double sp[4][4];
+        {
+            const int NS = W - 14;  // 2, or 4 in the last panel
+            double lm[4][4];        // lm[b][m] = L[14 + b][14 + m], m < b (columns <= W - 2 of the LDS copy)
+#pragma unroll
+            for (int b = 1; b < 4; ++b)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) lm[b][m] = (b < NS && m < b) ? buf[(14 + b) * LDB + 14 + m] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    sp[a][b] = 0.0;
+                    if (a < NS && b < NS && b >= a) {
+                        if (b == a) {
+                            sp[a][b] = ysp[a];
+                        } else {
+                            double s = 0.0;
+#pragma unroll
+                            for (int m = a; m < b; ++m) s = fma(sp[a][m], lm[b][m], s);
+                            sp[a][b] = -ysp[b] * s;
+                        }
+                    }
+                }
+            if (last) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) xs[a][b] = sp[a][b];
+            }
+        }
+        tri_wave_order();
+        // ---- 4. finished rows back to LDS: row of the panel buffer = lane (rows of A below the diagonal block, rows of
+        // X'); the special rows go to rows 64, 65, lane <-> column ----
+        if (lane >= (last ? nA : 16)) {
+            double* pw = buf + lane * LDB;
+#pragma unroll
+            for (int q = 0; q + 1 < WL; q += 2)
+                if (q < W) *reinterpret_cast<double2*>(pw + q) = double2{r[q], r[q + 1]};
+        }
+        if (lane < W) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b >= a && 14 + b < W) v = (lane == 14 + b) ? sp[a][b] : v;
+                buf[(64 + a) * LDB + lane] = v;
+            }
+        }
+        tri_wave_sync();
+        // ---- 5. tail columns of the Schur terms: dot products with the tail rows of L (broadcast from LDS) ----
+        if (!last) {
+#pragma unroll
+            for (int t = 0; t < E; ++t) {
+                const double* lt = bufA + (TB + t - col0) * LDB;
+                double d0 = 0.0, d1 = 0.0;
+                double2 l2 = double2{0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    l2 = *reinterpret_cast<const double2*>(lt + q);
+                    d0 = fma(r[q], l2.x, d0);
+                    d1 = fma(r[q + 1], l2.y, d1);
+                }
+                tl[t] -= d0 + d1;
+                // rows col0 + 14, col0 + 15 of X' (l2 = L[tail][14], L[tail][15] now)
+                const double m14 = fma(sp[0][0], l2.x, sp[0][1] * l2.y);
+                const double m15 = sp[1][1] * l2.y;
+                // the row of a lane moves 16 lanes down for the next panel; the special rows arrive at lanes 48, 49, new
+                // unit rows (no history) above them
+                double nx = __shfl_down(tl[t], 16, 64);
+                nx = lane >= 50 ? 0.0 : nx;
+                nx = lane == 48 ? -m14 : nx;
+                nx = lane == 49 ? -m15 : nx;
+                tl[t] = nx;
+                asm volatile("" : "+v"(tl[t]));
+            }
+        }
+        constexpr int MAXCH = (WL + 3) / 4;
+        double opL[NB][4], opX[NB][MAXCH];
+        const int nch = G::chunks(k);
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) opL[bi][kk] = (bi > k) ? bufA[(16 * (bi - k) + c) * LDB + 4 * kk + g] : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < MAXCH; ++kk) {
+                opX[bi][kk] = 0.0;
+                if (bi <= k && kk < nch) {
+                    if (4 * kk + 4 <= W) {
+                        opX[bi][kk] = bufX[(16 * bi + c) * LDB + 4 * kk + g];
+                    } else {
+                        const bool in = 4 * kk + g < W;
+                        const double v = bufX[(16 * bi + c) * LDB + (in ? 4 * kk + g : 0)];
+                        opX[bi][kk] = in ? v : 0.0;
+                    }
+                }
+            }
+        }
+        tri_wave_order();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 6. rank-W updates on the matrix pipe; what the next panel needs goes first ----
+        if (!last) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int bi = k + 1; bi < NB; ++bi)
+                    N[bi][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[k + 1][kk], N[bi][k + 1], 0, 0, 2);
+#pragma unroll
+                for (int i = 0; i <= k; ++i)
+                    M[i][k + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[k + 1][kk], M[i][k + 1], 0, 0, 2);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int bj = k + 2; bj < NB; ++bj) {
+#pragma unroll
+                    for (int bi = bj; bi < NB; ++bi)
+                        N[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opL[bi][kk], opL[bj][kk], N[bi][bj], 0, 0, 2);
+#pragma unroll
+                    for (int i = 0; i <= k; ++i)
+                        M[i][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opL[bj][kk], M[i][bj], 0, 0, 2);
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < MAXCH; ++kk) {
+            if (kk < nch) {
+#pragma unroll
+                for (int i = 0; i <= k; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j)
+                        P[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opX[i][kk], opX[j][kk], P[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- tail columns of A^-1: (A^-1)[rho][48 + t] = sum_{u >= t} X'[rho][48 + u] X'[48 + t][48 + u].  Lanes >= 18 hold
+    // the rows rho = lane - 18 of X' (r[16], r[17] = columns 48, 49); lanes 0 .. 3 stand in for the special rows 46 .. 49 ----
+    const bool xrow = lane >= 18 || lane < 4;
+    const int rho = lane >= 18 ? lane - 18 : 46 + lane;
+    double x48 = r[16], x49 = r[17];
+    if (lane < 18) {
+        x48 = lane == 0 ? xs[0][2] : (lane == 1 ? xs[1][2] : (lane == 2 ? xs[2][2] : 0.0));
+        x49 = lane == 0 ? xs[0][3] : (lane == 1 ? xs[1][3] : (lane == 2 ? xs[2][3] : xs[3][3]));
+    }
+    const double pt[E] = {fma(x48, xs[2][2], x49 * xs[2][3]), x49 * xs[3][3]};
+    if constexpr (KMODE) {
+#pragma unroll
+        for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+            for (int bi = bj; bi < NB; ++bi)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int i = 16 * bi + g + 4 * p, j = 16 * bj + c;
+                    kl[i * ldk + j] = P[bi][bj][p];
+                    if (bi != bj) kl[j * ldk + i] = P[bi][bj][p];
+                }
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            if (xrow) {
+                kl[rho * ldk + TB + t] = pt[t];
+                kl[(TB + t) * ldk + rho] = pt[t];
+            }
+        }
+        tr = logdet;
+        cs = 0.0;
+        return true;
+    }
+    tr = 0.0;
+    cs = 0.0;
+    double cd = 0.0;
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj) {
+        const double sj = sv[16 * bj + c];
+#pragma unroll
+        for (int bi = bj; bi < NB; ++bi) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int il = g + 4 * p;
+                const int i = 16 * bi + il;
+                const int dd = i - (16 * bj + c);
+                const double wgt = (sv[i] * sj) * dkv[dd < 0 ? -dd : dd];
+                if (bi == bj) {
+                    cd = fma(P[bi][bj][p], wgt, cd);
+                    tr += (il == c) ? P[bi][bj][p] : 0.0;
+                } else {
+                    cs = fma(P[bi][bj][p], wgt, cs);
+                }
+            }
+        }
+    }
+    {
+        const double si = sv[rho];
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const int dd = TB + t - rho;
+            const double wgt = (si * sv[TB + t]) * dkv[dd > 0 ? dd : 0];
+            if (xrow && rho < TB + t) cs = fma(pt[t], wgt, cs);
+            if (xrow && rho == TB + t) tr += pt[t];
+        }
+    }
+    cs = fma(2.0, cs, cd);
+    return true;
+}
+
+
 // The traces of the K block against the second moments C = sum_i mu_i mu_i' of one latent, on the matrix pipe:
 //     quad = tr(K^-1 C),   gq = tr(K^-1 dK K^-1 C) = <C K^-1, K^-1 dK>_F
 // with K^-1 in LDS (`kl`, full symmetric, stride ldk = 2 mod 4), C in global memory (TP x TP, zero beyond the rows
