@@ -734,12 +734,27 @@ extern "C" int vlgp_get_params(vlgp_ctx* ctx, double* a, double* b, double* nois
     NEED_CTX(ctx);
     CHK(vlgp_join_m(ctx));
     const int N = ctx->N, L = ctx->L, P = ctx->P;
-    if (a) HIPCHK(ctx, hipMemcpyAsync(a, ctx->d_a, sizeof(double) * L * N, hipMemcpyDeviceToHost, ctx->stream));
-    if (b) HIPCHK(ctx, hipMemcpyAsync(b, ctx->d_b, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
-    if (noise) HIPCHK(ctx, hipMemcpyAsync(noise, ctx->d_noise, sizeof(double) * N, hipMemcpyDeviceToHost, ctx->stream));
-    if (da) HIPCHK(ctx, hipMemcpyAsync(da, ctx->d_da, sizeof(double) * L * N, hipMemcpyDeviceToHost, ctx->stream));
-    if (db) HIPCHK(ctx, hipMemcpyAsync(db, ctx->d_db, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    // five small copies into pageable memory are five synchronous staged transfers (~90 us per EM iteration): gather
+    // them in the pinned buffer with truly asynchronous copies, one synchronisation, then hand them out
+    double* dst[5] = {a, b, noise, da, db};
+    const double* src[5] = {ctx->d_a, ctx->d_b, ctx->d_noise, ctx->d_da, ctx->d_db};
+    const size_t len[5] = {(size_t)L * N, (size_t)P * N, (size_t)N, (size_t)L * N, (size_t)P * N};
+    size_t total = 0;
+    for (int i = 0; i < 5; ++i) total += dst[i] ? len[i] : 0;
+    CHK(vlgp_ensure_pinned(ctx, (int64_t)total + 8));
+    size_t o = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (!dst[i]) continue;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned + o, src[i], sizeof(double) * len[i], hipMemcpyDeviceToHost, ctx->stream));
+        o += len[i];
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    o = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (!dst[i]) continue;
+        memcpy(dst[i], ctx->h_pinned + o, sizeof(double) * len[i]);
+        o += len[i];
+    }
     return VLGP_OK;
 }
 

@@ -47,6 +47,7 @@ class Engine:
     """One GPU, one handle (include/vlgp_hip.h)."""
 
     def __init__(self, n_channels, n_latents, xdim, rank, gauss_mask=None, device=0):
+        self._hbuf = None
         self.lib = _lib.load()
         self.N, self.L, self.P, self.R = int(n_channels), int(n_latents), int(xdim), int(rank)
         mask = np.zeros(self.N, dtype=np.uint8) if gauss_mask is None else \
@@ -227,13 +228,17 @@ class Engine:
 
     def hstep_objective(self, set_id, window, dt, latents, logp):
         """Batched (ll, dll) for evaluations (latents[e], logp[e, :3])."""
-        latents = np.ascontiguousarray(latents, dtype=np.int32)
-        logp = _f64(logp).reshape(len(latents), 3)
-        ll = np.empty(len(latents))
-        dll = np.empty((len(latents), 3))
-        self._ck(self.lib.vlgp_hstep_objective(self.h, set_id, int(window), float(dt), len(latents),
-                                               iptr(latents), dptr(logp), dptr(ll), dptr(dll)))
-        return ll, dll
+        n = len(latents)
+        hb = self._hbuf
+        if hb is None or hb[0] < n:  # persistent argument buffers: this is called ~40 times per EM iteration
+            cap = max(16, n)
+            arrs = (np.zeros(cap, dtype=np.int32), np.zeros((cap, 3)), np.zeros(cap), np.zeros((cap, 3)))
+            hb = self._hbuf = (cap, arrs, (iptr(arrs[0]), dptr(arrs[1]), dptr(arrs[2]), dptr(arrs[3])))
+        (lat, lp, ll, dll), ptrs = hb[1], hb[2]
+        lat[:n] = latents
+        lp[:n] = np.reshape(logp, (n, 3))
+        self._ck(self.lib.vlgp_hstep_objective(self.h, set_id, int(window), float(dt), n, *ptrs))
+        return ll[:n].copy(), dll[:n].copy()
 
     def project_latent(self, set_id, proj, shift):
         """mu = y @ proj - shift on the device for every row of the set; returns the column sums of y."""
