@@ -383,7 +383,17 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
                             [0.3, 1e-2, 5e-5]]))
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
-        lean = eng.hstep_objective(0, T, 1.0, lat, logp)
+        lean = eng.hstep_objective(0, T, 1.0, lat, logp)  # the default: matrix-pipe round, one register set
+        assert np.array_equal(lean[0], eng.hstep_objective(0, T, 1.0, lat, logp)[0])  # repeatable bit for bit
+        monkeypatch.setenv("VLGP_HSTEP_TWOSET", "1")   # two-register-set task routine (three waves per SIMD)
+        twoset = eng.hstep_objective(0, T, 1.0, lat, logp)
+        monkeypatch.delenv("VLGP_HSTEP_TWOSET")
+        monkeypatch.setenv("VLGP_HSTEP_LEAN", "1")     # round-1 register-row kernel
+        round1 = eng.hstep_objective(0, T, 1.0, lat, logp)
+        monkeypatch.delenv("VLGP_HSTEP_LEAN")
+        for other in (twoset, round1):
+            assert relerr(other[0], lean[0]) < 1e-11
+            assert relerr(other[1][:, 1], lean[1][:, 1]) < 1e-10
         monkeypatch.setenv("VLGP_HSTEP_PADDED", "1")
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)

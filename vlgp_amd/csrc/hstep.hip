@@ -1398,7 +1398,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool padded = T == 50 && getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
             const bool lean = getenv("VLGP_HSTEP_LEAN") != nullptr;                 // register-row kernel (round 1)
             const bool mfma = !padded && !lean;
-            static const bool twoset = getenv("VLGP_HSTEP_TWOSET") != nullptr;  // two-register-set task routine at window <= 50
+            const bool twoset = getenv("VLGP_HSTEP_TWOSET") != nullptr;  // two-register-set task routine at window <= 50
             R.n_eval = n_eval; R.nb = mfma ? (M + MFMA_NW - 1) / MFMA_NW : (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
