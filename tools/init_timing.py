@@ -1,6 +1,6 @@
 import os, sys, time, copy
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vlgp_amd import synth, engine as E
 from vlgp_amd.preprocess import get_config, get_params, initialize, fill_params, fill_trials
 from vlgp_amd.api import _segments, SET_TRIALS
