@@ -130,29 +130,33 @@ class _Lbfgsb:
         self.nfev = 0
         self.nit = 0
         self.done = False
+        # the call's arguments either side of f (the one scalar that changes): bound once, this runs ~2 x per evaluation
+        self._head = (self.MAXCOR, self.x, self.lo, self.hi, self.nbd)
+        self._tail = (self.g, self.factr, self.GTOL, self.wa, self.iwa, self.task, self.lsave, self.isave, self.dsave,
+                      self.MAXLS, self.ln_task)
 
     def advance(self):
         """Run until the routine asks for (f, g) at self.x or terminates.
         Returns True when an evaluation is wanted."""
+        task = self.task
         while not self.done:
-            self.setulb(self.MAXCOR, self.x, self.lo, self.hi, self.nbd, self.f, self.g, self.factr,
-                        self.GTOL, self.wa, self.iwa, self.task, self.lsave, self.isave, self.dsave,
-                        self.MAXLS, self.ln_task)
-            if self.task[0] == 3:
+            self.setulb(*self._head, self.f, *self._tail)
+            t0 = task[0]
+            if t0 == 3:
                 return True
-            if self.task[0] == 1:  # new iterate accepted
+            if t0 == 1:  # new iterate accepted
                 self.nit += 1
                 if self.nit >= self.MAXITER:
-                    self.task[0], self.task[1] = 5, 504
+                    task[0], task[1] = 5, 504
                 elif self.nfev > self.MAXFUN:
-                    self.task[0], self.task[1] = 5, 502
+                    task[0], task[1] = 5, 502
             else:
                 self.done = True
         return False
 
     def feed(self, f, g):
         self.f = float(f)
-        self.g = np.array(g, dtype=np.float64)
+        self.g[:] = g  # in place: setulb reads the array bound in _tail
         self.nfev += 1
 
 
@@ -181,11 +185,15 @@ def lockstep_minimize(batch_fn, x0s, log_bounds):
     if setulb is None:
         return _lockstep_threads(batch_fn, x0s, log_bounds)
     runs = [_Lbfgsb(setulb, x0, log_bounds) for x0 in x0s]
+    X = np.empty((len(runs), runs[0].x.size))
     while True:
         want = [k for k, r in enumerate(runs) if not r.done and r.advance()]
         if not want:
             break
-        f, G = batch_fn(want, np.stack([runs[k].x for k in want]))
+        n = len(want)
+        for i, k in enumerate(want):
+            X[i] = runs[k].x
+        f, G = batch_fn(want, X[:n])
         for i, k in enumerate(want):
             runs[k].feed(f[i], G[i])
     return [r.x.copy() for r in runs]
