@@ -342,14 +342,20 @@ def main():
     n_h, ms_h, u_h = prof["hstep"]
     if n_h:
         fl = work["hstep_flops_per_seg_eval"] * u_h / n_h
-        hname = "hstep_round_lean<50>" if os.environ.get("VLGP_HSTEP_LEAN") else "hstep_round_mfma<%d, 4>" % (50 if T <= 50 else 64)
+        if os.environ.get("VLGP_HSTEP_LEAN"):
+            hname = "hstep_round_lean<50>"
+        elif T <= 50:  # the instantiation that runs: one register set unless the two-set routine is forced
+            hname = "hstep_round_mfma<50, 4>" if os.environ.get("VLGP_HSTEP_TWOSET") else "hstep_round_mfma<50, 4, true>"
+        else:
+            hname = "hstep_round_mfma<64, 4>"
         kernels[hname] = entry(
             n_h, ms_h, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_h / n_h,
             flops_per_launch_executed=fl, bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_h / n_h,
             pmc_key=hname, per_step_ms=ms_h / k_steps,
             avg_ms_overlapped=(prof_live["hstep"][1] / prof_live["hstep"][0]) if prof_live["hstep"][0] else None,
             note="algorithmic count M (T^3 + 4 T^2) per evaluation (SURVEY 8d); the matrix-pipe kernel issues 78 "
-                 "v_mfma_f64_16x16x4 = 160 kflop per segment plus the panel eliminations")
+                 "v_mfma_f64_16x16x4 = 160 kflop per segment plus the panel eliminations; latency-bound: launch time = "
+                 "generations of 4096 resident waves x wave lifetime (~30 us)")
     n_p, ms_p, u_p = prof["prior"]
     if n_p:
         kernels["ichol_exact_kernel"] = {"launches": n_p, "avg_ms": ms_p / n_p, "total_ms": ms_p,
