@@ -210,3 +210,29 @@ def test_save_load_round_trip(tmp_path):
     assert set(arrs) == {"a", "omega"} and np.array_equal(arrs["omega"], result["params"]["omega"])
     with pytest.raises(FileNotFoundError):
         load(tmp_path / "missing.npy")
+
+
+def test_blas_thread_limit_only_lowers():
+    """preprocess._few_blas_threads caps OpenBLAS for the factor analysis but must never RAISE the thread count: under
+    torchrun (OMP_NUM_THREADS=1) an OpenBLAS sized for one thread crashes when asked for eight (seen on the MI355X
+    hosts: SIGSEGV in numpy.linalg inside bench.py --gpus 2)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = ("import numpy as np\n"
+            "from threadpoolctl import threadpool_info\n"
+            "from vlgp_amd.preprocess import _few_blas_threads\n"
+            "n = lambda: max([m['num_threads'] for m in threadpool_info() if m.get('user_api') == 'blas'] or [1])\n"
+            "before = n()\n"
+            "with _few_blas_threads(8):\n"
+            "    inside = n()\n"
+            "    np.linalg.svd(np.random.default_rng(0).standard_normal((60, 40)))\n"
+            "assert inside <= before and inside <= 8, (before, inside)\n"
+            "assert n() == before\n"
+            "print('ok', before, inside)\n")
+    for env_threads in ("1", "4"):
+        env = dict(os.environ, OMP_NUM_THREADS=env_threads, OPENBLAS_NUM_THREADS=env_threads)
+        done = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0 and "ok" in done.stdout, done.stderr[-1500:]

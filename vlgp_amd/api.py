@@ -40,6 +40,11 @@ def _segments(trials, window, eng):
             segs.append({k: tr[k][sl] for k in ("y", "x", "mu", "w", "v")})
             starts.append(row0 + int(s))
         row0 += T
+    # the per-segment dmu buffers fill_trials would otherwise allocate one by one (4000 at C3): views of one block
+    if segs:
+        block = np.zeros((len(segs), window, segs[0]["mu"].shape[1]))
+        for i, sg in enumerate(segs):
+            sg["dmu"] = block[i]
     eng.cut(SET_TRIALS, SET_SEGMENTS, np.asarray(starts, dtype=np.int64), window)
     return E.DeviceTrials(segs, eng, SET_SEGMENTS, parent_set=SET_TRIALS)
 

@@ -63,13 +63,18 @@ def _few_blas_threads(limit=8):
     hardware thread (256 on the MI355X hosts), which is no faster -- and the idle workers then spin for ~100 ms,
     during which everything else the process does (the 160 MB concatenation and upload of y that follow) runs 5-10x
     slower: measured 82-130 ms instead of 25 ms for the upload at C3."""
-    try:
-        from threadpoolctl import threadpool_limits
+    import contextlib
 
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+
+        now = [m.get("num_threads", 1) for m in threadpool_info() if m.get("user_api") == "blas"]
+        # only ever LOWER the count: an OpenBLAS that started with OMP_NUM_THREADS=1 (torchrun exports that) has
+        # buffers for one thread and crashes when asked for more
+        if not now or max(now) <= limit:
+            return contextlib.nullcontext()
         return threadpool_limits(limits=limit, user_api="blas")
     except Exception:  # threadpoolctl is optional
-        import contextlib
-
         return contextlib.nullcontext()
 
 
