@@ -588,33 +588,41 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
         constexpr int LDH = RA + 2;
         double* ht = K.tile;
         {
-            // all operands first (up to 48 independent loads in flight per lane), then the 39 matrix instructions: with
-            // a load in front of every instruction the build was a chain of 39 trips to L2
-            double g0[16], g1[16], wv[16];  // G[t][col], G[t][16 + col], w[t] at t = 4 k + kq
+            // operands in two batches of eight time chunks (24 independent loads in flight per lane, then 24 matrix
+            // instructions on three independent accumulators): with a load in front of every instruction the build was a
+            // chain of 39 trips to L2; with all 48 operands loaded first the kernel needed 148 registers (three waves
+            // per SIMD: the 4000 tasks of one latent at C3 ran as two generations)
+            double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0;  // tiles (0, 0), (1, 0), (1, 1)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int t = 4 * k + kq;
-                const bool in = t < T;
-                const int tc = in ? t : 0;
-                const double wt = w_s[tc];
-                const double ga = Gl[tc * r + (col < r ? col : 0)];
-                const double gb = Gl[tc * r + (16 + col < r ? 16 + col : 0)];
-                wv[k] = in ? wt : 0.0;
-                g0[k] = (in && col < r) ? ga : 0.0;
-                g1[k] = (in && 16 + col < r) ? gb : 0.0;
+            for (int half = 0; half < 2; ++half) {
+                double g0[8], g1[8], wv[8];  // G[t][col], G[t][16 + col], w[t] at t = 4 k + kq
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int t = 4 * (8 * half + kk) + kq;
+                    const bool in = t < T;
+                    const int tc = in ? t : 0;
+                    const double wt = w_s[tc];
+                    const double ga = Gl[tc * r + (col < r ? col : 0)];
+                    const double gb = Gl[tc * r + (16 + col < r ? 16 + col : 0)];
+                    wv[kk] = in ? wt : 0.0;
+                    g0[kk] = (in && col < r) ? ga : 0.0;
+                    g1[kk] = (in && 16 + col < r) ? gb : 0.0;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    if (4 * (8 * half + kk) < T) {
+                        const double w0 = wv[kk] * g0[kk], w1 = wv[kk] * g1[kk];
+                        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, g0[kk], c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, g0[kk], c1, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, g1[kk], c2, 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
             for (int tile = 0; tile < 3; ++tile) {
                 const int bi = tile == 0 ? 0 : 1, bj = tile == 2 ? 1 : 0;
                 const int cb = 16 * bj + col;
-                double4_t c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (4 * k < T) {
-                        const double opa = wv[k] * (bi ? g1[k] : g0[k]);
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(opa, bj ? g1[k] : g0[k], c, 0, 0, 0);
-                    }
-                }
+                const double4_t c = tile == 0 ? c0 : (tile == 1 ? c1 : c2);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = 16 * bi + kq + 4 * q;
