@@ -18,7 +18,7 @@ from conftest import ROOT, relerr
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, tmp, q, inject):
+def _worker(rank, world, tmp, q, inject, workload="C1", iters=3):
     os.environ.update({"VLGP_COMM_TRANSPORT": "shm", "RANK": str(rank), "WORLD_SIZE": str(world),
                        "LOCAL_RANK": "0", "MASTER_PORT": "29999", "VLGP_RENDEZVOUS_DIR": tmp})
     sys.path.insert(0, ROOT)
@@ -29,14 +29,14 @@ def _worker(rank, world, tmp, q, inject):
 
     comm = Comm.from_env() if world > 1 else None
     if inject:
-        trials, a0, b0, dims = bench.build_inputs("C1")
+        trials, a0, b0, dims = bench.build_inputs(workload)
         kw = dict(a=a0.copy(), b=b0.copy())
     else:  # nothing injected: the pooled factor-analysis initialisation (ranks seed differently on purpose)
         trials = synth.make_trials(10, 200, 20, 3, seed=0)
         dims, kw = (10, 200, 20, 3), {}
         np.random.seed(4 + 3 * rank)
     mine = comm.shard(trials) if comm else trials
-    sess = FitSession(mine, dims[3], device=0, comm=comm, verbose=False, max_iter=3, min_iter=3, **kw)
+    sess = FitSession(mine, dims[3], device=0, comm=comm, verbose=False, max_iter=iters, min_iter=iters, **kw)
     assert sess.eng.transport == ("shm" if world > 1 else "none")
     sess.run()
     res = sess.finish()
@@ -68,7 +68,7 @@ PARAM_TOL = 1e-5  # a, b, noise, posterior means: sharded against unsharded fit
 OMEGA_TOL = 1e-4  # omega: limited by L-BFGS-B's own stopping rule (ftol = 2.2e-9), see the first test
 
 
-def _run_worlds(worlds, inject):
+def _run_worlds(worlds, inject, workload="C1", iters=3):
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
@@ -76,7 +76,7 @@ def _run_worlds(worlds, inject):
     for world in worlds:
         q = ctx.Queue()
         with tempfile.TemporaryDirectory() as tmp:
-            procs = [ctx.Process(target=_worker, args=(r, world, tmp, q, inject)) for r in range(world)]
+            procs = [ctx.Process(target=_worker, args=(r, world, tmp, q, inject, workload, iters)) for r in range(world)]
             for p in procs:
                 p.start()
             res = sorted(_collect(q, procs), key=lambda r: r[0])
@@ -85,6 +85,22 @@ def _run_worlds(worlds, inject):
                 assert p.exitcode == 0
         out[world] = res
     return out
+
+
+def test_c4_full_size_two_ranks_match_single_process():
+    """BASELINE configs[3] at full size (200 x 1000 x 100, 5 latents, 4000 segments) split over two ranks -- on one GPU,
+    through the shared-memory transport -- against the single-process fit: two EM iterations with the H-step on
+    (sharded M-step statistics, host-side exchange of every H-step round's sums, replicated solves)."""
+    out = _run_worlds((1, 2), inject=True, workload="C3", iters=2)
+    one, rs = out[1][0], out[2]
+    for i in (1, 2, 3, 4):
+        assert np.array_equal(rs[0][i], rs[1][i])           # replicated parameters: bit-identical on both ranks
+    for i in (1, 2, 3):
+        assert relerr(rs[0][i], one[i]) < PARAM_TOL, i
+    assert relerr(rs[0][4], one[4]) < OMEGA_TOL
+    assert [len(r[5]) for r in rs] == [100, 100] and sum((r[5] for r in rs), []) == one[5]
+    assert relerr(np.concatenate([r[6] for r in rs]), one[6]) < PARAM_TOL
+    assert all(r[7] == 2 for r in rs)
 
 
 def test_ranks_on_one_gpu_match_single_process():
