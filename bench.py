@@ -397,6 +397,16 @@ def main():
                    "transport": transport, "rccl_ranks": world if transport == "rccl" else 0},
         "ms_per_e_step": phase_ms["e"], "ms_per_m_step": phase_ms["m"], "ms_per_h_step": phase_ms["h"],
         "roofline": roofline, "kernels": kernels,
+        # the H-step beyond its kernel: dependent L-BFGS-B rounds of the timed region, their kernel time at the stand-alone
+        # launch average, and what is left (launch + mailbox + host optimiser step per round, prior rebuild, M-step lane)
+        "h_step": (lambda n_live, ms_live, ms_alone: {
+            "rounds_per_step": n_live / args.steps,
+            "kernel_ms_per_step_at_standalone_avg": n_live / args.steps * ms_alone,
+            # event-bracketed in the timed region, i.e. sharing the chip with the M-step lane's launches
+            "kernel_ms_per_step_beside_m_step": ms_live / args.steps,
+            "non_kernel_ms_per_step": phase_ms["h"] - ms_live / args.steps,
+            "non_kernel_us_per_round": 1e3 * (phase_ms["h"] - ms_live / args.steps) / max(n_live / args.steps, 1e-9),
+        })(prof_live["hstep"][0], prof_live["hstep"][1], (prof["hstep"][1] / prof["hstep"][0]) if prof["hstep"][0] else 0.0),
         "effective_rank": ranks_used, "effective_rank_per_step": ranks_per_step, "omega_final": omega,
     }
     if not args.no_cpu_baseline and world == 1:
