@@ -22,7 +22,9 @@ def _worker(rank, world, port, tmp, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    td.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+
+    td.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     try:
         uid = exchange_unique_id(rank, world, lambda: bytes(range(128)), path=os.path.join(tmp, "uid"))
         assert uid == bytes(range(128))
@@ -51,17 +53,49 @@ def _worker(rank, world, port, tmp, q):
         td.destroy_process_group()
 
 
+def _free_port():
+    """A port nobody listens on right now (a pid-derived one can collide with a leftover of a killed run)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _collect(q, procs, limit=900.0):
+    """One result per worker.  The first `import torch` after the image's pages left the cache takes minutes, so the
+    limit is generous; a worker that DIED fails the test at once instead of waiting it out."""
+    import queue
+    import time
+
+    got, t0 = [], time.time()
+    while len(got) < len(procs):
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > limit:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("worker exit codes %r after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
+    return got
+
+
+
 def test_two_rank_mstep_protocol_and_rendezvous():
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import torch  # noqa: F401  (pages the libraries in ONCE, here, before two workers import them side by side)
+
+    port = _free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
         for p in procs:
             p.start()
-        res = [q.get(timeout=240) for _ in procs]
+        res = _collect(q, procs)
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
@@ -84,7 +118,9 @@ def _init_worker(rank, world, port, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    td.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+
+    td.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     try:
         class Pool:  # what an attached Engine offers: in-place sum over ranks of a float64 array
             def __init__(self):
@@ -116,11 +152,13 @@ def test_two_rank_pooled_initialisation_matches_single_process():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    import torch  # noqa: F401  (see above)
+
+    port = _free_port()
     procs = [ctx.Process(target=_init_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    res = sorted(_collect(q, procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
