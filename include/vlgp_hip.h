@@ -241,6 +241,15 @@ int vlgp_debug_phase_clock(vlgp_ctx* ctx, int on, uint64_t out[8]);
  * reference's NumPy (vlgp/math.py:113-119): kind 0 out = exp(a) as np.exp computes it, 1 out = sqrt(a),
  * 2 out = a / b, 3 out = fma(a, b, out).  Host arrays of n doubles; b may be NULL for kinds 0, 1. */
 int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const double* b, double* out);
+/* Which implementation ran the most recent vlgp_estep / vlgp_update_w / vlgp_update_v of this handle (the
+ * reference has one serial loop, vlgp/core.py:123-126; the library picks a kernel family by set shape, and the
+ * parity tests assert that the family they mean to check is the one that ran). */
+#define VLGP_PATH_ESTEP_NONE 0
+#define VLGP_PATH_ESTEP_SPLIT 1    /* chip-wide launches per phase (many short units) */
+#define VLGP_PATH_ESTEP_FAST 2     /* persistent workgroup per unit, register-resident factors */
+#define VLGP_PATH_ESTEP_LONG 3     /* long units (T > 64), one workgroup per trial */
+#define VLGP_PATH_ESTEP_GENERIC 4  /* generic kernels (rank > 50 slots, L > 10, ...) */
+int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
 
 #ifdef __cplusplus
 }

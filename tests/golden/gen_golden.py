@@ -373,6 +373,92 @@ def gen_vem_c2():
          y_checksum=np.array([float(np.concatenate([t["y"] for t in trials0]).sum())]))
 
 
+def gen_vem_c3():
+    """BASELINE.json configs[2] (the headline) at full size: 200 trials x 1000 bins x 100 channels, 5 latents ->
+    4000 segments; two EM iterations of the real reference with every default (H-step on), from injected a, b, mu
+    (vlgp/core.py:269-359).  About a quarter of an hour of one core in the development container."""
+    n_trials, n_bins, N, L = synth.CONFIGS["C3"]
+    trials0 = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    rng = np.random.default_rng(31)
+    a0 = 0.3 * rng.standard_normal((L, N))
+    b0 = np.log(np.maximum(np.mean(np.concatenate([t["y"] for t in trials0]), axis=0, keepdims=True), 1e-8))
+    mu0 = [0.2 * rng.standard_normal((n_bins, L)) for _ in trials0]
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy()} for t, m in zip(trials0, mu0)]
+    cfg = get_config(max_iter=2, min_iter=2)
+    params = get_params(trials, L, a=a0.copy(), b=b0.copy(), omega_bound=cfg["omega_bound"])
+    for tr in trials:
+        tr["x"] = np.ones((n_bins, 1, N))
+        tr["w"] = np.zeros((n_bins, L))
+        tr["v"] = np.zeros((n_bins, L))
+    fill_params(params)
+    fill_trials(trials)
+    gp.make_cholesky(trials, params, cfg)
+    core.update_w(trials, params, cfg)
+    core.update_v(trials, params, cfg)
+    segs = cut_trials(trials, params, cfg)
+    gp.make_cholesky(segs, params, cfg)
+    fill_trials(segs)
+    pick = np.arange(0, len(segs), 20)
+    traj = {"mu": [], "a": [], "b": [], "omega": [], "seg_mu": []}
+
+    def spy(tr_, p_, c_):
+        traj["mu"].append(sl.norm(np.concatenate([s["mu"] for s in tr_])))
+        traj["a"].append(sl.norm(p_["a"]))
+        traj["b"].append(sl.norm(p_["b"]))
+        traj["omega"].append(np.array(p_["omega"]))
+        traj["seg_mu"].append(np.stack([tr_[i]["mu"] for i in pick[::4]]))
+        print("  iteration done", len(traj["mu"]), flush=True)
+
+    cfg["callbacks"] = [spy]
+    core.vem(segs, params, cfg)
+    save("vem_c3", norm_mu=np.array(traj["mu"]), norm_a=np.array(traj["a"]), norm_b=np.array(traj["b"]),
+         omega=np.array(traj["omega"]), a=params["a"], b=params["b"], noise=params["noise"],
+         it=cfg["runtime"]["it"], pick=pick, seg_mu_it1=traj["seg_mu"][0],
+         seg_mu=np.stack([segs[i]["mu"] for i in pick]),
+         seg_v=np.stack([segs[i]["v"] for i in pick]), seg_w=np.stack([segs[i]["w"] for i in pick]),
+         y_checksum=np.array([float(np.concatenate([t["y"] for t in trials0]).sum())]))
+
+
+def _describe(d):
+    """key -> [type name, dtype or None, shape or None] of a returned dict."""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, np.ndarray):
+            out[k] = ["ndarray", str(v.dtype), list(v.shape)]
+        else:
+            out[k] = [type(v).__name__, None, None]
+    return out
+
+
+def gen_result():
+    """What `fit` hands back and what `util.save` writes (vlgp/api.py:18-76, vlgp/util.py:181-190): the key sets /
+    value types of trials[0], params, config and config["runtime"] as JSON, and the reference's own result files
+    (.npy: one pickled object; .npz: the three top-level keys) for `vlgp_amd.load` to read."""
+    import json
+
+    from vlgp import util as ref_util
+
+    trials0 = synth.make_trials(4, 100, 8, 2, seed=3)
+    trials = [{"ID": t["ID"], "y": t["y"].copy()} for t in trials0]
+    np.random.seed(9)
+    res = ref_api.fit(trials, 2, max_iter=2, min_iter=2)
+    keys = {"trial": _describe(res["trials"][0]), "params": _describe(res["params"]),
+            "config": _describe(res["config"]), "runtime": _describe(res["config"]["runtime"]),
+            "initial": sorted(res["params"]["initial"].keys()),
+            "cholesky_keys": sorted(int(k) for k in res["params"]["cholesky"].keys()),
+            "top": sorted(res.keys()), "trials_type": type(res["trials"]).__name__}
+    with open(os.path.join(HERE, "fit_keys.json"), "w") as f:
+        json.dump(keys, f, indent=1, sort_keys=True)
+    # the bound scikit-learn method in params["transform"] (preprocess.py:21) would drag a pickled estimator into
+    # the file; the stored result keeps everything else exactly as util.save writes it
+    res["params"]["transform"] = None
+    res["params"]["initial"]["transform"] = None
+    ref_util.save(res, os.path.join(HERE, "ref_result"), ext="npy")
+    ref_util.save(res, os.path.join(HERE, "ref_result"), ext="npz")
+    for ext in ("npy", "npz"):
+        print("ref_result.%s %7.1f KB" % (ext, os.path.getsize(os.path.join(HERE, "ref_result." + ext)) / 1024))
+
+
 def gen_init():
     """preprocess.initialize on C1 (FactorAnalysis on the seeded 10 % subsample)."""
     from vlgp.preprocess import initialize

@@ -106,7 +106,8 @@ def test_hstep_objective_retry_when_K_does_not_factor(V):
             cholesky(O.se_kernel(t, s2, om, eps)[0], lower=True)
 
 
-def test_exp_clamp_at_ten_in_e_and_m_step(V):
+@pytest.mark.parametrize("split", [False, True])
+def test_exp_clamp_at_ten_in_e_and_m_step(V, split, monkeypatch):
     """math.trunc_exp = exp(min(x, 10)) (vlgp/math.py:24-38): loadings large enough that eta + v a^2 / 2 passes
     10 on a good part of the (bin, channel) pairs -- E-step (25 sweeps) and M-step (3 Newton iterations)."""
     rng = np.random.default_rng(9)
@@ -131,7 +132,11 @@ def test_exp_clamp_at_ten_in_e_and_m_step(V):
               "likelihood": np.array(["poisson"] * N), "cholesky": {T: G}, "gp_noise": 1e-4, "dt": 1}
     want = [O.estep_unit(u["y"], u["x"], u["mu"], u["v"], u["w"], a, b, noise, gauss, G, 25) for u in units]
     mine = [{k: np.array(val) for k, val in u.items()} for u in units]
+    if split:  # the table-driven exp of the split E-step's passes has its own clamp
+        monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
     V.estep(mine, params, V.get_config())
+    from vlgp_amd import engine as E
+    assert E.TRACE["estep"] == ("split" if split else "fast")
     for u, wv in zip(mine, want):
         for k, arr in zip(("mu", "v", "w"), wv):
             # curvatures up to e^10 a^2: the reference's v = rowsum(G o (G - G H + G H M)) cancels at cond(I + H) ~ 1e5

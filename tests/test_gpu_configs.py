@@ -129,7 +129,8 @@ def test_c3_hstep_objective_all_segments_vs_oracle_and_additivity(V, c3_state):
 
 
 # ------------------------------------------------------------------ C5: ragged, 200 mixed channels, 10 latents
-def test_c5_full_channel_count_ragged_trials_vs_oracle(V):
+@pytest.mark.parametrize("split", [False, True])
+def test_c5_full_channel_count_ragged_trials_vs_oracle(V, split, monkeypatch):
     """BASELINE.json configs[4] at its full channel / latent count (150 Poisson + 50 Gaussian channels, ten
     latents) on 20 ragged trials of 500 ... 2000 bins (the 500-trial job is the 8-GPU configuration; one EM
     iteration of the oracle on 20 trials already takes a minute): two EM iterations against the oracle through
@@ -138,6 +139,8 @@ def test_c5_full_channel_count_ragged_trials_vs_oracle(V):
     from vlgp_amd import synth
     from vlgp_amd.api import SET_SEGMENTS, FitSession
 
+    if split:  # 20 trials = ~500 segments sit below the size threshold: force the kernels the 500-trial job runs
+        monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
     rng = np.random.default_rng(12)
     lengths = [int(50 * k) for k in rng.integers(10, 41, 20)]
     L, N, n_gauss = 10, 200, 50
@@ -187,3 +190,103 @@ def test_c5_full_channel_count_ragged_trials_vs_oracle(V):
     for tg, tr in zip(got["trials"], stage):
         for k in ("mu", "v", "w"):
             assert relerr(tg[k], tr[k]) < TRAJ, (k, tr["y"].shape[0])
+
+
+def test_c5_full_size_500_ragged_trials(V):
+    """BASELINE.json configs[4] at its REAL size on one GPU: 500 trials of 500 ... 2000 bins (multiples of the
+    window), 150 Poisson + 50 Gaussian channels, ten latents -> ~12.9 k segments, ~640 k bins.  Two EM iterations
+    with every default through FitSession, then every stage at full size against the oracle from the state the
+    fit left on the device: the split E-step (L = 10, mixed likelihood) on 100 random segments, one Newton
+    iteration of the M-step over ALL rows, the H-step objective over ALL segments, the final full-length
+    inference of 10 trials; plus the size-independent bounds 0 <= v <= diag(GG')."""
+    from vlgp_amd import synth
+    from vlgp_amd.api import SET_SEGMENTS, FitSession
+
+    n_trials, N, L, n_gauss, T = 500, 200, 10, 50, 50
+    lengths = (50 * np.random.default_rng(0).integers(10, 41, n_trials)).tolist()
+    trials = synth.make_trials(n_trials, 2000, N, L, seed=0, n_gauss=n_gauss, lengths=lengths)
+    lik = ["poisson"] * (N - n_gauss) + ["gaussian"] * n_gauss
+    gauss = np.array([k == "gaussian" for k in lik])
+    np.random.seed(0)
+    sess = FitSession(trials, L, verbose=False, lik=lik, max_iter=2, min_iter=2)
+    try:
+        eng, sid = sess.eng, sess.segs.set_id
+        sess.run()
+        assert eng.last_estep_path == "split"   # the E-step of the EM loop ran on the chip-wide launch sequence
+        assert len(sess.segs) == sum(lengths) // T
+        p = sess.params
+        a, b, noise = np.array(p["a"]), np.array(p["b"]), np.array(p["noise"])
+        omega, sigma = np.array(p["omega"]), np.array(p["sigma"])
+        G = eng.get_prior(T)
+        for l in range(L):  # the factor the next E-step uses is the reference's, bit for bit
+            assert np.array_equal(G[l], O.ichol_gauss(T, omega[l], 50) * sigma[l])
+        sess.segs.pull(("mu", "v", "w"))
+        segs = list(sess.segs)
+        M = len(segs)
+        rng = np.random.default_rng(3)
+
+        # ---- H-step objective: all segments, three latents
+        lat = np.array([0, 4, 9], dtype=np.int32)
+        logp = np.log(np.array([[sigma[l] ** 2, omega[l] * 1.1, p["gp_noise"]] for l in lat]))
+        ll, dll = eng.hstep_objective(sid, T, 1.0, lat, logp)
+        mu_all = np.stack([s["mu"] for s in segs])
+        w_all = np.stack([s["w"] for s in segs])
+        tgrid = np.arange(T) * 1.0
+        for e, l in enumerate(lat):
+            want_ll, want_dll = O.gp_objective(logp[e], tgrid, mu_all[:, :, l].T, w_all[:, :, l].T)
+            assert abs(ll[e] - want_ll) <= STAGE * abs(want_ll), l
+            assert abs(dll[e, 1] - want_dll[1]) <= STAGE * max(abs(want_dll[1]), 1e-3 * abs(want_ll)), l
+
+        # ---- M-step: one Newton iteration over all rows
+        cat = lambda k: np.concatenate([s[k] for s in segs], axis=0)
+        y_all, v_all2 = cat("y"), cat("v")
+        rows = y_all.shape[0]
+        x_all = np.broadcast_to(np.ones((1, 1, 1)), (rows, 1, N))
+        want = O.mstep_arrays(y_all, x_all, mu_all.reshape(rows, L), v_all2, a.copy(), b.copy(), gauss, 1)
+        eng.mstep(sid, 1)
+        a1, b1, noise1, _, _ = eng.get_params()
+        eng.set_params(a, b, noise)
+        assert relerr(a1, want[0]) < STAGE and relerr(b1, want[1]) < STAGE and relerr(noise1, want[4]) < STAGE
+        del y_all, x_all, want
+
+        # ---- E-step: three more sweeps on the device, 100 random segments against the oracle
+        eng.estep(sid, 3)
+        assert eng.last_estep_path == "split"
+        got = eng.download(sid)
+        sh = lambda arr: arr.reshape(M, T, L)
+        ones = np.ones((T, 1, N))
+        for m in rng.choice(M, 100, replace=False):
+            s = segs[m]
+            ref = O.estep_unit(s["y"], ones, s["mu"], s["v"], s["w"], a, b, noise, gauss, G, 3)
+            for k, r in zip(("mu", "v", "w", "dmu"), ref):
+                assert relerr(sh(got[k])[m], r) < STAGE, (k, m)
+        vmax = np.einsum("ltr,ltr->tl", G, G)
+        v_dev = sh(got["v"])
+        assert v_dev.min() >= 0 and np.all(v_dev <= vmax[None] * (1 + 1e-12))
+        del got, mu_all, w_all
+
+        # ---- final stage of fit (api.py:66-71): full-length inference, 10 trials against the oracle
+        eng.merge(SET_SEGMENTS)
+        sess.dev_trials.pull(("mu", "v", "w"))
+        pick = rng.choice(n_trials, 10, replace=False)
+        after_vem = {int(i): {k: trials[i][k].copy() for k in ("mu", "v", "w")} for i in pick}
+        res = sess.finish()
+    finally:
+        sess.close()
+    cfg = O.make_config(max_iter=2, min_iter=2)
+    p2 = O.make_params([trials[i] for i in pick], L, a=a.copy(), b=b.copy(), lik=lik)
+    for k, val in (("a", a), ("b", b), ("noise", noise), ("omega", omega), ("sigma", sigma)):
+        p2[k] = np.array(val)
+    stage = [{"y": trials[i]["y"], "x": np.ones((trials[i]["y"].shape[0], 1, N)),
+              "dmu": np.zeros_like(after_vem[int(i)]["mu"]), **{k: after_vem[int(i)][k].copy() for k in ("mu", "v", "w")}}
+             for i in pick]
+    O.make_cholesky(stage, p2, cfg)
+    O.update_w(stage, p2, cfg)
+    O.update_v(stage, p2, cfg)
+    O.infer(stage, p2, cfg)
+    for i, tr in zip(pick, stage):
+        for k in ("mu", "v", "w"):
+            assert relerr(res["trials"][i][k], tr[k]) < TRAJ, (k, int(i))
+        Tn = tr["y"].shape[0]
+        for l in range(L):
+            assert np.array_equal(res["params"]["cholesky"][Tn][l], p2["cholesky"][Tn][l]), (Tn, l)

@@ -27,6 +27,31 @@ def V():
     return vlgp_amd
 
 
+@pytest.fixture(params=["default", "split"])
+def estep_path(request, monkeypatch):
+    """Both dispatch paths of the short-unit E-step, every run: the size-based default (persistent kernels on
+    fixture-sized sets) and the split E-step (estep_split.hip: the chip-wide launch sequence that takes over at
+    >= 512 units / 64 k rows -- the kernels the headline number is made of) forced onto the same inputs.
+    VLGP_ESTEP_SPLIT is read per call by launch_estep_split."""
+    if request.param == "split":
+        monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
+    else:
+        monkeypatch.delenv("VLGP_ESTEP_SPLIT", raising=False)
+    return request.param
+
+
+def _ran(V, path, *calls):
+    """The kernel family the seam call(s) just used is the one the parametrisation means to test."""
+    from vlgp_amd import engine as E
+
+    for c in calls:
+        got = E.TRACE.get(c)
+        if path == "split":
+            assert got == "split", (c, got)
+        else:
+            assert got in ("fast", "generic", "long", "split"), (c, got)
+
+
 def _params(g, L, N, P=1, rank=50, chol=None):
     lik = np.where(g["gauss"], "gaussian", "poisson")
     return {"ydim": N, "zdim": L, "xdim": P, "rank": rank, "a": g["a"].copy(), "b": g["b"].copy(),
@@ -127,7 +152,7 @@ def test_ichol_device_vs_oracle_bitwise(V):
 
 # ------------------------------------------------------------------ E-step
 @pytest.mark.parametrize("tag", ["pois", "mixed"])
-def test_update_w_v_golden(V, golden, tag):
+def test_update_w_v_golden(V, golden, tag, estep_path):
     g = golden("estep_" + tag)
     units = [{"y": g["y0"][m].copy(), "x": g["x0"][m].copy(), "mu": g["mu0"][m].copy()}
              for m in range(4)]
@@ -135,6 +160,7 @@ def test_update_w_v_golden(V, golden, tag):
     cfg = V.get_config()
     V.update_w(units, params, cfg)
     V.update_v(units, params, cfg)
+    _ran(V, estep_path, "update_w", "update_v")
     for m in range(4):
         assert relerr(units[m]["w"], g["w_stage"][m]) < STAGE
         assert relerr(units[m]["v"], g["v_stage"][m]) < STAGE
@@ -143,7 +169,7 @@ def test_update_w_v_golden(V, golden, tag):
 @pytest.mark.parametrize("tag", ["pois", "mixed"])
 @pytest.mark.parametrize("method", ["VB", "MAP"])
 @pytest.mark.parametrize("n_it", [1, 25])
-def test_estep_golden(V, golden, tag, method, n_it):
+def test_estep_golden(V, golden, tag, method, n_it, estep_path):
     g = golden("estep_" + tag)
     units = _units(g)
     for u in units:
@@ -152,6 +178,7 @@ def test_estep_golden(V, golden, tag, method, n_it):
     cfg = V.get_config(method=method, Eniter=n_it)
     mu_id = [id(u["mu"]) for u in units]
     V.estep(units, params, cfg)
+    _ran(V, estep_path, "estep")
     for m in range(4):
         assert id(units[m]["mu"]) == mu_id[m]  # mu updated in place, as the reference does
         for k in ("mu", "v", "w"):
@@ -220,8 +247,10 @@ def _random_problem(rng, lengths, N, L, P, n_gauss, rank=50):
     dict(lengths=[1000, 1000], N=30, L=5, P=1, g=6),     # full-length trials: rank-exhausted prior (r = 50)
     dict(lengths=[65, 128, 1200], N=18, L=8, P=1, g=0),  # long-unit kernel, eight latents, just above 64 bins
 ])
-def test_estep_random_vs_oracle(V, case):
+def test_estep_random_vs_oracle(V, case, estep_path):
     import zlib
+    if estep_path == "split" and max(case["lengths"]) > 64:
+        pytest.skip("the split E-step is the short-unit path (T <= 64); long units have one path")
     rng = np.random.default_rng(zlib.crc32(str(sorted(case.items())).encode()))
     units, params, gauss = _random_problem(rng, case["lengths"], case["N"], case["L"], case["P"], case["g"])
     cfg = V.get_config(Eniter=4)
@@ -229,15 +258,17 @@ def test_estep_random_vs_oracle(V, case):
                          params["noise"], gauss, params["cholesky"][u["y"].shape[0]], 4)
             for u in units]
     V.estep(units, params, cfg)
+    _ran(V, estep_path, "estep")
     for u, ref in zip(units, want):
         for k, r in zip(("mu", "v", "w", "dmu"), ref):
             assert relerr(u[k], r) < STAGE, (k, u["y"].shape)
 
 
-@pytest.mark.parametrize("omega,lo,hi", [(2e-2, 17, 24), (4.5e-2, 25, 32)])
-def test_estep_mid_rank_buckets_vs_oracle(V, omega, lo, hi):
-    """Effective ranks 17..24 and 25..32 take their own instantiations of the fast E-step kernel
-    (register arrays of 24 / 32 entries): pin both against the oracle."""
+@pytest.mark.parametrize("omega,lo,hi", [(1.6e-2, 17, 20), (3e-2, 21, 24), (4.5e-2, 25, 32)])
+def test_estep_mid_rank_buckets_vs_oracle(V, omega, lo, hi, estep_path):
+    """Effective ranks 17..20, 21..24 and 25..32 take their own instantiations (persistent kernel: register
+    arrays of 24 / 32 entries; split E-step: the rank classes 20 / 24 / 32 of the augmented elimination): pin
+    each against the oracle."""
     rng = np.random.default_rng(12)
     units, params, gauss = _random_problem(rng, [50] * 6, 30, 5, 1, 4)
     params["omega"] = np.full(5, omega)
@@ -251,12 +282,13 @@ def test_estep_mid_rank_buckets_vs_oracle(V, omega, lo, hi):
     want = [O.estep_unit(u["y"], u["x"], u["mu"], u["v"], u["w"], params["a"], params["b"], params["noise"],
                          gauss, params["cholesky"][50], 5) for u in units]
     V.estep(units, params, V.get_config(Eniter=5))
+    _ran(V, estep_path, "estep")
     for u, ref in zip(units, want):
         for k, r in zip(("mu", "v", "w", "dmu"), ref):
             assert relerr(u[k], r) < STAGE, k
 
 
-def test_estep_singular_system_zeroes_update(V):
+def test_estep_singular_system_zeroes_update(V, estep_path):
     # a NaN curvature makes I + G'WG non-factorisable: the reference logs and
     # applies a zero update for that latent (core.py:92-94); other latents move
     rng = np.random.default_rng(3)
@@ -265,6 +297,7 @@ def test_estep_singular_system_zeroes_update(V):
     mu0 = units[1]["mu"].copy()
     v0 = units[1]["v"].copy()
     V.estep(units, params, V.get_config(Eniter=1))
+    _ran(V, estep_path, "estep")
     assert np.array_equal(units[1]["mu"][:, 1], mu0[:, 1])
     assert np.array_equal(units[1]["dmu"][:, 1], np.zeros(50))
     assert not np.array_equal(units[1]["mu"][:, 0], mu0[:, 0])
@@ -586,6 +619,7 @@ def test_headline_size_properties(V):
             eng.update_v(0)
             for n in splits:
                 eng.estep(0, n)
+                assert eng.last_estep_path == "split"  # 4000 units / 200 k rows: the split E-step by size
             out = eng.download(0)
             G = eng.get_prior(50)
         return out, G
@@ -602,17 +636,77 @@ def test_headline_size_properties(V):
     vmax = np.einsum("ltr,ltr->tl", G, G)
     v = one["v"].reshape(4000, 50, L)
     assert v.min() >= 0 and np.all(v <= vmax[None] * (1 + 1e-12))
-    # spot-check a few segments of the full-size run against the oracle
-    chol = {50: G}
-    w0 = O.curvature_unit(y[7], np.ones((50, 1, N)), mu[7], np.zeros((50, L)), a, b, np.ones(N), np.zeros(N, bool))
-    for i in (0, 1999, 3999):
-        w0 = O.curvature_unit(y[i], np.ones((50, 1, N)), mu[i], np.zeros((50, L)), a, b, np.ones(N),
-                              np.zeros(N, bool))
+    # 200 random segments of the full-size run against the oracle (the run above went through the split E-step)
+    ones, nz, ng = np.ones((50, 1, N)), np.ones(N), np.zeros(N, bool)
+    for i in np.random.default_rng(5).choice(4000, 200, replace=False):
+        w0 = O.curvature_unit(y[i], ones, mu[i], np.zeros((50, L)), a, b, nz, ng)
         v0, _ = O.variance_unit(w0, np.zeros((50, L)), G)
-        ref = O.estep_unit(y[i], np.ones((50, 1, N)), mu[i], v0, w0, a, b, np.ones(N), np.zeros(N, bool), G, 25)
-        for k, r in zip(("mu", "v", "w"), ref):
+        ref = O.estep_unit(y[i], ones, mu[i], v0, w0, a, b, nz, ng, G, 25)
+        for k, r in zip(("mu", "v", "w", "dmu"), ref):
             assert relerr(one[k].reshape(4000, 50, L)[i], r) < STAGE, (k, i)
-    del chol
+
+
+@pytest.mark.parametrize("case", [
+    # regressors (x != 1 -> the HASXB passes), Gaussian channels, MAP (no variance update: the LASTSW variants), L = 8
+    dict(M=1400, N=40, L=8, P=2, g=8, vb=False, n_it=4, omega=None),
+    # N > 128 (lane-per-row y pass), three latents, mixed, one latent in each rank class 20 / 24 / 32
+    dict(M=1320, N=130, L=3, P=1, g=5, vb=True, n_it=5, omega=[1.6e-2, 3e-2, 4.5e-2]),
+    # ten latents, mixed likelihood (C5's shape), ranks <= 16 and one above
+    dict(M=1311, N=24, L=10, P=1, g=6, vb=True, n_it=3, omega=[2e-3, 5e-3, 8e-3, 1e-3, 3e-3, 1.1e-2, 6e-3, 4e-3, 2e-2, 9e-4]),
+    # all Gaussian, history-like regressors
+    dict(M=1300, N=16, L=5, P=3, g=16, vb=True, n_it=3, omega=None),
+])
+def test_split_estep_at_dispatch_size_vs_oracle(V, case):
+    """Sets at and above the size where the split E-step takes over BY ITSELF (>= 512 units and >= 64 k rows, no
+    environment switch): update_w, update_v and the E-step of every unit on the device, 60 random units against the
+    oracle (core.infer_single_trial, vlgp/core.py:22-120; update_w/update_v :419-471)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr(sorted((k, str(v)) for k, v in case.items())).encode()))
+    M, N, L, P, T = case["M"], case["N"], case["L"], case["P"], 50
+    a = 0.4 * rng.standard_normal((L, N))
+    b = np.log(0.3) + 0.2 * rng.standard_normal((P, N))
+    if P > 1:
+        b[1:] *= 0.3
+    noise = 0.5 + rng.random(N)
+    gauss = np.zeros(N, dtype=bool)
+    gauss[rng.choice(N, case["g"], replace=False)] = True
+    omega = np.array(case["omega"]) if case["omega"] else 10 ** rng.uniform(-3.2, -1.9, size=L)
+    sigma = 0.8 + 0.4 * rng.random(L)
+    phase = rng.random((M, L)) * 6
+    tt = np.linspace(0, 1, T)
+    z = np.sin(tt[None, :, None] * (2 + np.arange(L))[None, None, :] * np.pi + phase[:, None, :])  # (M, T, L)
+    x = np.ones((M, T, P, N))
+    if P > 1:
+        x[:, :, 1:, :] = 0.3 * rng.standard_normal((M, T, P - 1, N))
+    eta = z @ a + np.einsum("mtpn,pn->mtn", x, b)
+    y = rng.poisson(np.exp(np.minimum(eta, 3))).astype(float)
+    y[:, :, gauss] = eta[:, :, gauss] + 0.7 * rng.standard_normal((M, T, int(gauss.sum())))
+    mu = z + 0.3 * rng.standard_normal((M, T, L))
+    with V.Engine(N, L, P, 50, gauss) as eng:
+        eng.set_params(a, b, noise)
+        eng.upload(0, [{"y": y[m], "x": x[m], "mu": mu[m], "v": np.zeros((T, L)), "w": np.zeros((T, L))} for m in range(M)])
+        eng.build_prior([T], omega, sigma)
+        G = eng.get_prior(T)
+        eng.update_w(0)
+        assert eng.last_estep_path == "split"
+        eng.update_v(0, case["vb"])
+        st0 = eng.download(0, keys=("v", "w"))
+        eng.estep(0, case["n_it"], vb=case["vb"])
+        assert eng.last_estep_path == "split"
+        got = eng.download(0)
+    for l in range(L):
+        assert np.array_equal(G[l], O.ichol_gauss(T, omega[l], 50) * sigma[l])
+    sh = lambda arr: arr.reshape(M, T, L)
+    for m in rng.choice(M, 60, replace=False):
+        w0 = O.curvature_unit(y[m], x[m], mu[m], np.zeros((T, L)), a, b, noise, gauss)
+        assert relerr(sh(st0["w"])[m], w0) < STAGE
+        v0 = O.variance_unit(w0, np.zeros((T, L)), G)[0] if case["vb"] else np.zeros((T, L))
+        assert relerr(sh(st0["v"])[m], v0) < STAGE or not case["vb"]
+        ref = O.estep_unit(y[m], x[m], mu[m], v0, w0, a, b, noise, gauss, G, case["n_it"], vb=case["vb"])
+        for k, r in zip(("mu", "v", "w", "dmu"), ref):
+            if k == "v" and not case["vb"]:
+                continue
+            assert relerr(sh(got[k])[m], r) < STAGE, (k, m)
 
 
 # ------------------------------------------------------------------ RCCL plumbing on one GPU
@@ -643,7 +737,7 @@ def test_single_rank_rccl_allreduce_is_identity(V, golden, monkeypatch):
 
 
 # ------------------------------------------------------------------ C5-like: ragged trials, mixed likelihood, ten latents
-def test_c5_like_ragged_mixed_ten_latents(V):
+def test_c5_like_ragged_mixed_ten_latents(V, estep_path):
     """BASELINE.json configs[4] in miniature: unequal trial lengths (multiples of the window), Poisson +
     Gaussian channels, ten latents.  Exercises the generic E-step kernels (L > 8), long units whose ten
     rank-50 factors do not fit LDS, the mixed-likelihood M-step and a ten-latent H-step, against the oracle

@@ -212,6 +212,31 @@ def test_save_load_round_trip(tmp_path):
         load(tmp_path / "missing.npy")
 
 
+def test_load_reads_the_references_own_result_files():
+    """tests/golden/ref_result.{npy,npz} were written by the REFERENCE's util.save (vlgp/util.py:181-190, gen_golden.py:
+    gen_result) from a real fit: `vlgp_amd.load` hands back the same dict from either format."""
+    from conftest import GOLDEN
+
+    from vlgp_amd import util as U
+
+    one = U.load(os.path.join(GOLDEN, "ref_result.npy"))
+    two = U.load(os.path.join(GOLDEN, "ref_result.npz"))
+    for res in (one, two):
+        assert sorted(res.keys()) == ["config", "params", "trials"]
+        assert len(res["trials"]) == 4 and res["trials"][0]["y"].shape == (100, 8)
+        assert res["params"]["a"].shape == (2, 8) and set(res["params"]["cholesky"]) == {100}
+        assert res["config"]["runtime"]["it"] == 2 and res["config"]["window"] == 50
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert np.array_equal(one["params"][k], two["params"][k])
+    for t1, t2 in zip(one["trials"], two["trials"]):
+        for k in ("y", "mu", "v", "w", "dmu", "x"):
+            assert np.array_equal(t1[k], t2[k])
+    with pytest.raises(FileNotFoundError):
+        U.load(os.path.join(GOLDEN, "no_such_result.npy"))
+    with pytest.raises(NotImplementedError):
+        U.load(os.path.join(GOLDEN, "gen_golden.py"))
+
+
 def test_blas_thread_limit_only_lowers():
     """preprocess._few_blas_threads caps OpenBLAS for the factor analysis but must never RAISE the thread count: under
     torchrun (OMP_NUM_THREADS=1) an OpenBLAS sized for one thread crashes when asked for eight (seen on the MI355X

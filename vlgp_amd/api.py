@@ -115,7 +115,14 @@ class FitSession:
                 fill_trials(self.segs)
             else:
                 self.segs = self.dev_trials
-            snapshot = {k: v for k, v in params.items() if k not in ("cholesky", "transform")}
+            # params["initial"] = deepcopy(params) (api.py:60): every key, the segment-length factors included.  The
+            # resident factor is downloaded for it only when a window is set (one (L, window, rank) array); without
+            # a window it would be every full-length factor, which stays on the device until someone asks
+            snapshot = {k: v for k, v in params.items() if k != "cholesky"}
+            chol = params["cholesky"]
+            if isinstance(chol, E._LazyPrior):
+                chol = chol.materialize() if window else dict()
+            snapshot["cholesky"] = chol
             params["initial"] = copy.deepcopy(snapshot)
             E._push_params(eng, params)
         except Exception:

@@ -122,6 +122,8 @@ struct vlgp_ctx {
     void* hx = nullptr;           // host-side exchange segment for the H-step round sums (single node)
     int rank = 0, world = 1;
 
+    int last_estep_path = 0;      // VLGP_PATH_ESTEP_* of the most recent E-step / update_w / update_v launch
+
     std::string err;
 };
 

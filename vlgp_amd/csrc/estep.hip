@@ -464,21 +464,21 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     {
         int handled = 0;
         CHK(launch_estep_split(ctx, us, A, &handled));
-        if (handled) return VLGP_OK;
+        if (handled) { ctx->last_estep_path = VLGP_PATH_ESTEP_SPLIT; return VLGP_OK; }
     }
 
     // FAST: register-resident factorisations (estep_fast.hip); declines when it does not apply
     {
         int handled = 0;
         CHK(launch_estep_fast(ctx, us, A, &handled));
-        if (handled) return VLGP_OK;
+        if (handled) { ctx->last_estep_path = VLGP_PATH_ESTEP_FAST; return VLGP_OK; }
     }
 
     // LONG units: all waves on the per-latent phases, MFMA builds (estep_long.hip)
     if (us.Tmax > 64) {
         int handled = 0;
         CHK(launch_estep_long(ctx, us, A, &handled));
-        if (handled) return VLGP_OK;
+        if (handled) { ctx->last_estep_path = VLGP_PATH_ESTEP_LONG; return VLGP_OK; }
     }
 
     // SMALL: whole unit state lives in LDS
@@ -487,6 +487,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     if (us.Tmax <= 256 && small_d * 8 <= LDS_MAX) {
         const int nthr = nw_s * 64;
         A.rg = pick_rg(us.Tmax, N, nthr);
+        ctx->last_estep_path = VLGP_PATH_ESTEP_GENERIC;
         vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_GENERIC);
         int rc = launch_l<true>(ctx, A, us.M, nthr, (size_t)small_d * 8);
         vlgp_prof_end(ctx, VLGP_PROF_ESTEP_GENERIC, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));
@@ -497,7 +498,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     {
         int handled = 0;
         CHK(launch_estep_long(ctx, us, A, &handled));
-        if (handled) return VLGP_OK;
+        if (handled) { ctx->last_estep_path = VLGP_PATH_ESTEP_LONG; return VLGP_OK; }
     }
 
     // LONG: unit state in HBM/L2, factors in LDS when they fit
@@ -520,6 +521,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     A.scratch = us.d_scratch;
     if (lc_total) A.lc_global = us.d_scratch + need;
     A.rg = 64;
+    ctx->last_estep_path = VLGP_PATH_ESTEP_GENERIC;
     vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_GENERIC);
     int rc = launch_l<false>(ctx, A, us.M, nthr, (size_t)long_d * 8);
     vlgp_prof_end(ctx, VLGP_PROF_ESTEP_GENERIC, (double)us.M * (A.n_iter > 0 ? A.n_iter : 1));

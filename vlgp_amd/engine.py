@@ -31,6 +31,11 @@ __all__ = ["Engine", "DeviceTrials", "estep", "mstep", "hstep", "update_w", "upd
            "make_cholesky", "infer", "vem", "constrain_loading", "constrain_latent", "VlgpError"]
 
 
+# which kernel family ran the most recent seam call on a temporary engine (the engine is gone by the time the
+# caller could ask it): "estep" / "update_w" / "update_v" -> one of _lib.ESTEP_PATHS.  Read by the parity tests.
+TRACE = {}
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -312,6 +317,13 @@ class Engine:
         self._ck(self.lib.vlgp_debug_phase_clock(self.h, int(bool(on)), out))
         return [int(v) for v in out]
 
+    @property
+    def last_estep_path(self):
+        """Kernel family of the most recent E-step / update_w / update_v: one of _lib.ESTEP_PATHS."""
+        p = C.c_int(0)
+        self._ck(self.lib.vlgp_debug_last_estep_path(self.h, C.byref(p)))
+        return _lib.ESTEP_PATHS[p.value]
+
     def profile_get(self, kind):
         n, ms, units = C.c_int64(0), C.c_double(0), C.c_double(0)
         self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms), C.byref(units)))
@@ -484,6 +496,7 @@ def update_w(trials, params, config=None):
             tr.setdefault("v", np.zeros_like(tr["mu"]))
     with _Bound(trials, params, need_prior=False, pull=("w",)) as (eng, sid):
         eng.update_w(sid)
+        TRACE["update_w"] = eng.last_estep_path
 
 
 def update_v(trials, params, config):
@@ -492,6 +505,7 @@ def update_v(trials, params, config):
         return
     with _Bound(trials, params, pull=("v",)) as (eng, sid):
         bad = eng.update_v(sid, True, count=not isinstance(trials, DeviceTrials))
+        TRACE["update_v"] = eng.last_estep_path
         if bad:
             logger.error("Singular I + G'WG in %d unit-latent pairs", bad)
 
@@ -503,6 +517,7 @@ def estep(trials, params, config):
     with _Bound(trials, params) as (eng, sid):
         bad = eng.estep(sid, config["Eniter"], config["dmu_bound"], config["method"] == "VB",
                         count=not isinstance(trials, DeviceTrials))
+        TRACE["estep"] = eng.last_estep_path
         if bad:
             logger.error("%d posterior updates hit a singular system and were zeroed", bad)
 
