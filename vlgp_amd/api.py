@@ -245,8 +245,12 @@ def sample_posterior(trial, params, nsamples, reg=1e-6, rng=None, device=0):
     nbins, nfactors = mu.shape
     G = np.ascontiguousarray(params["cholesky"][nbins], dtype=float)
     R = G.shape[-1]
-    normal = (rng.standard_normal if hasattr(rng, "standard_normal") else rng.normal) if rng is not None \
-        else np.random.standard_normal
+    if rng is None:
+        normal = np.random.standard_normal
+    elif hasattr(rng, "standard_normal"):
+        normal = rng.standard_normal
+    else:  # anything with normal(loc, scale, size)
+        normal = lambda shape: rng.normal(size=shape)
     eps = np.zeros((nfactors, R, int(nsamples)))
     for l in range(nfactors):
         nz = np.flatnonzero(np.any(G[l] != 0.0, axis=0))  # columns ichol_gauss left at zero carry nothing
@@ -257,10 +261,19 @@ def sample_posterior(trial, params, nsamples, reg=1e-6, rng=None, device=0):
 
     from ._lib import dptr
 
-    with E.Engine(2, nfactors, 1, R, device=device) as eng:
-        bad = C.c_int(0)
-        eng._ck(eng.lib.vlgp_sample_posterior(eng.h, nbins, dptr(mu), dptr(w), dptr(G), int(nsamples), dptr(eps),
-                                              dptr(out), C.byref(bad)))
-        if bad.value:
-            logger.error("I + G'WG was not positive definite for %d latent(s): their draws equal the mean", bad.value)
+    # the latents are independent: more than a handle holds (16) go through in groups
+    for l0 in range(0, nfactors, 16):
+        sl = slice(l0, min(l0 + 16, nfactors))
+        nl = sl.stop - sl.start
+        mu_c, w_c, G_c, eps_c = (np.ascontiguousarray(arr) for arr in (mu[:, sl], w[:, sl], G[sl], eps[sl]))
+        out_c = out if nl == nfactors else np.empty((int(nsamples), nbins, nl))
+        with E.Engine(2, nl, 1, R, device=device) as eng:
+            bad = C.c_int(0)
+            eng._ck(eng.lib.vlgp_sample_posterior(eng.h, nbins, dptr(mu_c), dptr(w_c), dptr(G_c), int(nsamples),
+                                                  dptr(eps_c), dptr(out_c), C.byref(bad)))
+            if bad.value:
+                logger.error("I + G'WG was not positive definite for %d latent(s): their draws equal the mean",
+                             bad.value)
+        if out_c is not out:
+            out[:, :, sl] = out_c
     return out

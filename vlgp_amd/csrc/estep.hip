@@ -22,6 +22,7 @@
 #include "ctx.h"
 
 #include "estep_args.h"
+#include "fast_exp.h"
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) estep_kernel(EstepArgs A) 
                         eta = fma(mr[l], al[l], eta);
                         lin = fma(vr[l], aq[l], lin);
                     }
-                    const double pois = exp(fmin(fma(0.5, lin, eta), 10.0));
+                    const double pois = exp(clamp10(fma(0.5, lin, eta)));
                     if constexpr (KIND == PASS_RES) {
                         const double mval = g ? eta * cnn : pois;
 #pragma unroll

@@ -152,7 +152,7 @@ estep_fast_kernel(EstepArgs A, const double* __restrict__ cols_g) {
                 eta = fma(mr[l], rv[l], eta);
                 lin = fma(vr[l], rv[LT + l], lin);
             }
-            const double rate = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+            const double rate = fast_exp(clamp10(fma(0.5, lin, eta)));
 #pragma unroll
             for (int l = 0; l < LT; ++l) acc[l] = fma(rate, rv[KIND == FP_RES ? l : LT + l], acc[l]);
         };

@@ -163,12 +163,12 @@ __global__ void __launch_bounds__(NTL, 2) estep_long_kernel(EstepArgs A) {
                             lin = fma(vr[q][l], aq[l], lin);
                         }
                         if constexpr (KIND == LPASS_RES) {
-                            const double pois = fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+                            const double pois = fast_exp(clamp10(fma(0.5, lin, eta)));
                             const double mval = g ? eta * cnn : pois;
 #pragma unroll
                             for (int l = 0; l < LT; ++l) acc[q][l] = fma(mval, al[l], acc[q][l]);
                         } else {
-                            const double rate = g ? 0.0 : fast_exp(fmin(fma(0.5, lin, eta), 10.0));
+                            const double rate = g ? 0.0 : fast_exp(clamp10(fma(0.5, lin, eta)));
 #pragma unroll
                             for (int l = 0; l < LT; ++l) acc[q][l] = fma(rate, aq[l], acc[q][l]);
                         }

@@ -273,7 +273,7 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
                     eta = fma(mr[q][l], rv[l], eta);
                     lin = fma(vr[q][l], rv[LT + l], lin);
                 }
-                const double rate = fast_exp_tab(fmin(fma(0.5, lin, eta), 10.0), etab);
+                const double rate = fast_exp_tab(clamp10(fma(0.5, lin, eta)), etab);
 #pragma unroll
                 for (int l = 0; l < LT; ++l) acc[q][l] = fma(rate, rv[KIND == SP_RES ? l : LT + l], acc[q][l]);
             }

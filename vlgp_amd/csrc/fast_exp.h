@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// min(x, 10) as np.minimum computes it (vlgp/math.py:24-38): a NaN stays a NaN (fmin would return 10)
+__device__ __forceinline__ double clamp10(double x) { return x > 10.0 ? 10.0 : x; }
+
 // exp(x) for x <= 10 (callers clamp): Cody-Waite reduction by ln 2, degree-13
 // Taylor polynomial on |r| <= ln2/2 (truncation 4e-18), one ldexp.  < 2 ulp.
 __device__ __forceinline__ double fast_exp(double x) {

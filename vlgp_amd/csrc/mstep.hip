@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
                     lin = fma(vr[l], al2[l], lin);
                 }
                 if constexpr (KIND == K_NEWTON) {
-                    const double rate = fast_exp_tab(fmin(fma(0.5, lin, eta), 10.0), etab);
+                    const double rate = fast_exp_tab(clamp10(fma(0.5, lin, eta)), etab);
                     double mt[LT], q[LT];
 #pragma unroll
                     for (int l = 0; l < LT; ++l) {
@@ -444,30 +444,134 @@ __global__ void __launch_bounds__(64) mstep_solve_kernel(SolveArgs A) {
     if (n < A.N) mstep_solve_channel(A, n);
 }
 
+// Newton update of one Poisson channel with the dimensions known at compile time and no regressors besides the
+// constant one (P == 1): H, g live in registers (the generic routine's dynamically indexed arrays live in scratch
+// memory: ~100 dependent scratch round trips per 5 x 5 system).  Same arithmetic, same order as
+// mstep_solve_channel / chol_solve_small.
+template <int LT>
+__device__ void mstep_solve_poisson_fixed(const SolveArgs& A, int n) {
+    const int N = A.N;
+    const double* MtY = A.prep;
+    const double* XtY = A.prep + (int64_t)LT * N;
+    const double* g1 = A.stats;
+    const double* Hs = g1 + (int64_t)LT * N;
+    const double* rv = Hs + (int64_t)tri(LT) * N;
+    const double* gb = rv + (int64_t)LT * N;
+    const double* Hb = gb + (int64_t)N;
+    double H[LT][LT], g[LT], gs[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) g[l] = MtY[(int64_t)l * N + n] - g1[(int64_t)l * N + n];
+    bool newton = A.use_hessian != 0;
+    if (newton) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j, ++k) H[i][j] = Hs[(int64_t)k * N + n];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            H[l][l] += rv[(int64_t)l * N + n] + A.eps;
+            gs[l] = g[l];
+        }
+        bool ok = true;
+#pragma unroll
+        for (int k2 = 0; k2 < LT; ++k2) {
+            double sd = H[k2][k2];
+#pragma unroll
+            for (int i = 0; i < k2; ++i) sd -= H[k2][i] * H[k2][i];
+            ok = ok && (sd > 0.0) && (sd < 1e300);
+            const double r = sqrt(sd);
+            H[k2][k2] = r;
+#pragma unroll
+            for (int j = k2 + 1; j < LT; ++j) {
+                double t = H[j][k2];
+#pragma unroll
+                for (int i = 0; i < k2; ++i) t -= H[j][i] * H[k2][i];
+                H[j][k2] = t / r;
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < LT; ++i) {
+                double t = gs[i];
+#pragma unroll
+                for (int j = 0; j < i; ++j) t -= H[i][j] * gs[j];
+                gs[i] = t / H[i][i];
+            }
+#pragma unroll
+            for (int i = LT - 1; i >= 0; --i) {
+                double t = gs[i];
+#pragma unroll
+                for (int j = i + 1; j < LT; ++j) t -= H[j][i] * gs[j];
+                gs[i] = t / H[i][i];
+            }
+#pragma unroll
+            for (int l = 0; l < LT; ++l) g[l] = gs[l];
+        } else {
+            newton = false;
+            atomicAdd(A.fail, 1);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        double st = newton ? g[l] : A.lr * g[l];
+        st = fmin(fmax(st, -A.da_bound), A.da_bound);
+        A.da[(int64_t)l * N + n] = st;
+        A.a[(int64_t)l * N + n] += st;
+    }
+    // bias (uses the same, un-refreshed rate: core.py:205); 1 x 1 system
+    double gbv = XtY[n] - gb[n];
+    newton = A.use_hessian != 0;
+    if (newton) {
+        const double hb = Hb[n] + A.eps;
+        if ((hb > 0.0) && (hb < 1e300)) {
+            const double r = sqrt(hb);
+            gbv = (gbv / r) / r;
+        } else {
+            newton = false;
+            atomicAdd(A.fail, 1);
+        }
+    }
+    double st = newton ? gbv : A.lr * gbv;
+    st = fmin(fmax(st, -A.db_bound), A.db_bound);
+    A.db[n] = st;
+    A.b[n] += st;
+}
+
 // Single rank: the fixed-order sum of the partials and the per-channel solves in ONE launch -- every block sums its
-// 64 outputs as sum_partials_kernel does, the block that draws the last ticket then runs the solves (one launch
-// boundary and the latency of a 2-wave launch less per Newton iteration).
-__global__ void __launch_bounds__(512) mstep_sum_solve_kernel(const double* partial, int G, int64_t K, double* out,
-                                                              unsigned* ticket, SolveArgs A) {
-    __shared__ double red[8][64];
+// 32 outputs, the block that draws the last ticket then runs the solves (one launch boundary and the latency of a
+// 2-wave launch less per Newton iteration).  Sixteen row slices per output, eight independent loads in flight per
+// thread (the first version walked its 64 rows two at a time: 32 dependent trips to L2 / MALL per launch, 42 us for
+// 11 MB of partials at C3); FIXED is the number of latents when the register-resident solve applies, 0 otherwise.
+#define MS_OUT 32
+#define MS_SL 16
+template <int FIXED>
+__global__ void __launch_bounds__(512) mstep_sum_solve_kernel(const double* __restrict__ partial, int G, int64_t K,
+                                                              double* __restrict__ out, unsigned* ticket, SolveArgs A) {
+    __shared__ double red[MS_SL][MS_OUT];
     __shared__ int s_last;
-    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + o;
-    double s0 = 0.0, s1 = 0.0;
+    const int o = threadIdx.x & (MS_OUT - 1), sl = threadIdx.x / MS_OUT;
+    const int64_t i = (int64_t)blockIdx.x * MS_OUT + o;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
     if (i < K) {
         int g = sl;
-        for (; g + 8 < G; g += 16) {
-            s0 += partial[(int64_t)g * K + i];
-            s1 += partial[(int64_t)(g + 8) * K + i];
+        for (; g + 7 * MS_SL < G; g += 8 * MS_SL) {
+            double ld[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ld[q] = partial[(int64_t)(g + q * MS_SL) * K + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += ld[q];
         }
-        if (g < G) s0 += partial[(int64_t)g * K + i];
+        for (int q = 0; g < G; g += MS_SL, ++q) acc[q] += partial[(int64_t)g * K + i];
     }
-    red[sl][o] = s0 + s1;
+    red[sl][o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (sl == 0 && i < K) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += red[q][o];
+        for (int q = 0; q < MS_SL; ++q) t += red[q][o];
         out[i] = t;
     }
     __syncthreads();
@@ -484,7 +588,15 @@ __global__ void __launch_bounds__(512) mstep_sum_solve_kernel(const double* part
         *ticket = 0;  // the next launch is stream-ordered after this one
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < A.N; n += 512) mstep_solve_channel(A, n);
+    for (int n = threadIdx.x; n < A.N; n += 512) {
+        if constexpr (FIXED > 0) {
+            if (!A.gauss[n]) {
+                mstep_solve_poisson_fixed<FIXED>(A, n);
+                continue;
+            }
+        }
+        mstep_solve_channel(A, n);
+    }
 }
 
 __global__ void noise_mean_kernel(int N, double count, const double* s1, double* mean) {
@@ -640,7 +752,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     std::vector<double> key;
     if (use_graph) {
         auto pk = [&](const void* p_) { key.push_back((double)(uintptr_t)p_); };
-        pk(us.y); pk(us.x_ones ? nullptr : us.x); pk(us.mu); pk(us.v); pk(W); pk(ctx->d_a); pk(ctx->d_b);
+        pk(us.y); pk(us.x_ones ? nullptr : us.x); pk(us.mu); pk(us.v); pk(us.w); pk(us.dmu); pk(W); pk(ctx->d_a); pk(ctx->d_b);
         pk(ctx->d_noise); pk(ctx->d_da); pk(ctx->d_db); pk(ctx->d_fail_m); pk(ctx->d_gauss);
         for (double v_ : {(double)us.rows, (double)N, (double)L, (double)P, (double)ctx->n_gauss, (double)n_iter,
                           (double)use_hessian, eps, lr, da_bound, db_bound})
@@ -714,8 +826,13 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
             CHK(rc);
             if (ctx->world == 1) {  // no all-reduce between the sum and the solves: one launch for both
                 const int64_t n = (int64_t)Kn * N;
-                hipLaunchKernelGGL(mstep_sum_solve_kernel, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, st, d_part,
-                                   g.G, n, d_stats, d_ticket, S);
+                const dim3 sg((unsigned)((n + MS_OUT - 1) / MS_OUT));
+                const int fixed = P == 1 ? L : 0;  // register-resident solve for the usual latent counts, no regressors
+                if (fixed == 3) hipLaunchKernelGGL(mstep_sum_solve_kernel<3>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
+                else if (fixed == 5) hipLaunchKernelGGL(mstep_sum_solve_kernel<5>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
+                else if (fixed == 8) hipLaunchKernelGGL(mstep_sum_solve_kernel<8>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
+                else if (fixed == 10) hipLaunchKernelGGL(mstep_sum_solve_kernel<10>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
+                else hipLaunchKernelGGL(mstep_sum_solve_kernel<0>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
                 HIPCHK(ctx, hipGetLastError());
                 continue;
             }

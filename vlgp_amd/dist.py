@@ -37,7 +37,7 @@ def _rendezvous_path():
     Every rank of one torchrun launch shares the agent as parent process and the master port; the
     parent's start time (``/proc/<ppid>/stat``) tells a recycled pid from the original, so a file left
     behind by a crashed earlier launch is never mistaken for this one's.  The files live in a per-user
-    directory of mode 0700 (nobody else can pre-create them)."""
+    directory of mode 0700 that this uid owns (checked: a directory somebody else pre-created is refused)."""
     ppid = os.getppid()
     born = "0"
     try:
@@ -50,10 +50,15 @@ def _rendezvous_path():
     if not base:
         base = os.path.join("/tmp", "vlgp_%d" % os.getuid())
         os.makedirs(base, mode=0o700, exist_ok=True)
-        try:
+        st = os.lstat(base)  # somebody else may have created it first: refuse anything that is not ours alone
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+            raise RuntimeError("rendezvous directory %s is not a directory owned by uid %d; set VLGP_RENDEZVOUS_DIR"
+                               % (base, os.getuid()))
+        if _stat.S_IMODE(st.st_mode) != 0o700:
             os.chmod(base, 0o700)
-        except OSError:
-            pass
+            if _stat.S_IMODE(os.lstat(base).st_mode) != 0o700:
+                raise RuntimeError("rendezvous directory %s must have mode 0700" % base)
     return os.path.join(base, "vlgp_rccl_%s.id" % tag)
 
 

@@ -296,7 +296,8 @@ class Engine:
 
     def allreduce_host(self, arr):
         """In-place sum over ranks of a float64 host array (no-op on one GPU)."""
-        assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]):
+            raise TypeError("allreduce_host needs a C-contiguous float64 array (the buffer is summed in place as doubles)")
         self._ck(self.lib.vlgp_comm_allreduce_host(self.h, dptr(arr), arr.size))
         return arr
 

@@ -131,7 +131,7 @@ def initialize(trials, params, config, defer_latent=False, pool=None):
             params["a"] = a
         need_b = params.get("b") is None
         if need_b and not defer:
-            colsum = np.sum(y, axis=0, keepdims=True)
+            colsum = np.sum(y, axis=0, keepdims=True, dtype=np.float64)  # integer counts must not reach the all-reduce as int64
             if pooled:
                 pool.allreduce_host(colsum)
             params["b"] = np.log(np.maximum(colsum / rows, config["eps"])) if pooled else \
