@@ -82,7 +82,7 @@ def pmc_traffic(kernel_key):
     else profiles/r1: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, plus WRITE_SIZE; separate
     passes).  None when no measurement is on file for that exact kernel name."""
     if not _PMC_CACHE:
-        for rnd in ("r1", "r2"):  # later rounds override
+        for rnd in ("r1", "r2", "r3"):  # later rounds override
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
                     _PMC_CACHE.update(json.load(f))
@@ -157,7 +157,7 @@ def cpu_baseline(name, budget_trials):
         "e_step_ms_full": 1e3 * e1 * scale,
     }
     if nproc > 1:
-        half = max(budget_trials // 2, 1)
+        half = max(min(budget_trials // 2, 6), 1)   # a side note (50 x 50 matrices do not thread): kept short
         pern, _, walln, _, _ = _oracle_em_iteration(name, half, nproc)
         out["all_threads"] = {"value": 1.0 / (pern * n_trials / float(half)), "unit": "EM it/s", "cores": nproc,
                               "sample": "same on the first %d trials with %d BLAS threads; %.0fs wall" % (half, nproc, walln)}
@@ -171,7 +171,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trials", type=int, default=12)
+    ap.add_argument("--allow-shm", action="store_true",
+                    help="tests only: accept the host shared-memory transport (several ranks on ONE GPU); a multi-GPU "
+                         "line is otherwise printed only when RCCL carries every rank")
+    ap.add_argument("--cpu-trials", type=int, default=25,
+                    help="trials of the workload the CPU baseline (oracle) runs: 25 of 200 = one eighth of C3, ~25 s")
     ap.add_argument("--kernel-steps", type=int, default=6,
                     help="extra EM iterations after the timed region, M-step serialised, for the per-kernel timings")
     args = ap.parse_args()
@@ -188,6 +192,9 @@ def main():
     device = getattr(comm, "local_rank", 0) if world > 1 else 0
     device = int(os.environ.get("VLGP_DEVICE", device))  # tests: several ranks on one GPU (shm transport)
 
+    if world > 1 and os.environ.get("VLGP_COMM_TRANSPORT", "") == "shm" and not args.allow_shm:
+        raise SystemExit("bench.py --gpus %d: VLGP_COMM_TRANSPORT=shm is the one-GPU test transport; a multi-GPU number "
+                         "must come from RCCL (pass --allow-shm in tests)" % args.gpus)
     trials, a0, b0, (n_trials, n_bins, N, L) = build_inputs(args.workload)
     mine = comm.shard(trials)
     total_iters = args.warmup + args.steps
@@ -214,6 +221,9 @@ def main():
     times[rank] = elapsed
     eng.allreduce_host(times)
     elapsed = float(times.max())
+    per_rank_ms = (1e3 * times / args.steps).tolist()   # a straggler shows here
+    if world > 1 and not (eng.transport == "rccl" or args.allow_shm):
+        raise SystemExit("bench.py --gpus %d: transport is %r, not rccl: no line printed" % (args.gpus, eng.transport))
 
     kinds = (("estep", _lib.PROF_ESTEP), ("mstep", _lib.PROF_MSTEP), ("hstep", _lib.PROF_HSTEP),
              ("prior", _lib.PROF_PRIOR), ("estep_ra16", _lib.PROF_ESTEP_RA16), ("estep_ra24", _lib.PROF_ESTEP_RA24),
@@ -381,7 +391,10 @@ def main():
                     "units_per_launch": kd["units_per_launch"],
                     "algorithmic_flops_per_launch": kd["flops_per_launch_executed"],
                     "avg_launch_ms_overlapped_in_timed_region": kd.get("avg_ms_overlapped"),
-                    "timing": kernel_timing}
+                    "timing": kernel_timing,
+                    "traffic_source": "replayed from the committed rocprofv3 --pmc passes of this command "
+                                      "(profiles/r*/pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes); "
+                                      "not collected in this run"}
 
     out = {
         "metric": "EM iterations/sec", "value": args.steps / elapsed, "unit": "EM it/s",
@@ -396,6 +409,7 @@ def main():
                        ", H-step round sums added on the host (shared memory)"),
                    "transport": transport, "rccl_ranks": world if transport == "rccl" else 0},
         "ms_per_e_step": phase_ms["e"], "ms_per_m_step": phase_ms["m"], "ms_per_h_step": phase_ms["h"],
+        "ms_per_step_per_rank": per_rank_ms,
         "roofline": roofline, "kernels": kernels,
         # the H-step beyond its kernel: dependent L-BFGS-B rounds of the timed region, their kernel time at the stand-alone
         # launch average, and what is left (launch + mailbox + host optimiser step per round, prior rebuild, M-step lane)

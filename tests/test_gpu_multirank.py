@@ -103,6 +103,26 @@ def test_c4_full_size_two_ranks_match_single_process():
     assert all(r[7] == 2 for r in rs)
 
 
+@pytest.mark.parametrize("world", [8, 7])
+def test_c4_eight_way_and_uneven_seven_way_on_one_gpu(world):
+    """The 8-GPU configuration's code path (BASELINE configs[3]: 25 trials per rank; and an uneven 7-way split,
+    29 / 28 trials) with every rank on ONE GPU over the shared-memory transport: mailbox and exchange-segment
+    sizing at eight ranks, sharded M-step statistics, the H-step round sums added on the host, against the
+    single-process fit.  Two EM iterations, H-step on."""
+    out = _run_worlds((1, world), inject=True, workload="C3", iters=2)
+    one, rs = out[1][0], out[world]
+    for r in rs[1:]:
+        for i in (1, 2, 3, 4):
+            assert np.array_equal(rs[0][i], r[i])            # replicated parameters: bit-identical on every rank
+    for i in (1, 2, 3):
+        assert relerr(rs[0][i], one[i]) < PARAM_TOL, i
+    assert relerr(rs[0][4], one[4]) < OMEGA_TOL
+    sizes = [len(r[5]) for r in rs]
+    assert sum(sizes) == 200 and max(sizes) - min(sizes) <= 1 and sum((r[5] for r in rs), []) == one[5]
+    assert relerr(np.concatenate([r[6] for r in rs]), one[6]) < PARAM_TOL
+    assert all(r[7] == 2 for r in rs)
+
+
 def test_ranks_on_one_gpu_match_single_process():
     """2 and 4 ranks (uneven shards of the 10 trials at 4) against the single-process fit."""
     out = _run_worlds((1, 2, 4), inject=True)
@@ -142,12 +162,17 @@ def test_bench_launch_line_two_ranks_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C1"]
-    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    done = subprocess.run(cmd + ["--allow-shm"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert done.returncode == 0, done.stderr[-2000:]
     lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1  # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["transport"] == "shm" and d["config"]["rccl_ranks"] == 0 and len(d["ms_per_step_per_rank"]) == 2
+    # without the explicit flag a line that RCCL did not carry is refused
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert done.returncode != 0 and "must come from RCCL" in done.stderr
+    assert not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_rccl_failure_is_loud():

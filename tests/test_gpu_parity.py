@@ -656,7 +656,7 @@ def test_headline_size_properties(V):
     # ten latents, mixed likelihood (C5's shape), ranks <= 16 and one above
     dict(M=1311, N=24, L=10, P=1, g=6, vb=True, n_it=3, omega=[2e-3, 5e-3, 8e-3, 1e-3, 3e-3, 1.1e-2, 6e-3, 4e-3, 2e-2, 9e-4]),
     # all Gaussian, history-like regressors
-    dict(M=1300, N=16, L=5, P=3, g=16, vb=True, n_it=3, omega=None),
+    dict(M=1312, N=16, L=5, P=3, g=16, vb=True, n_it=3, omega=None),
 ])
 def test_split_estep_at_dispatch_size_vs_oracle(V, case):
     """Sets at and above the size where the split E-step takes over BY ITSELF (>= 512 units and >= 64 k rows, no

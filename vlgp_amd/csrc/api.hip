@@ -545,6 +545,11 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_m_start) (void)hipEventDestroy(ctx->ev_m_start);
     if (ctx->ev_m_done) (void)hipEventDestroy(ctx->ev_m_done);
+    if (ctx->ev_e_fork) (void)hipEventDestroy(ctx->ev_e_fork);
+    for (int i = 0; i < VLGP_E_LANES - 1; ++i) {
+        if (ctx->ev_e_join[i]) (void)hipEventDestroy(ctx->ev_e_join[i]);
+        if (ctx->elane[i]) (void)hipStreamDestroy(ctx->elane[i]);
+    }
     if (ctx->mstream) (void)hipStreamDestroy(ctx->mstream); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_hres) (void)hipHostFree(ctx->h_hres);

@@ -10,6 +10,7 @@
 #include "../../include/vlgp_hip.h"
 
 #define VLGP_WAVE 64
+#define VLGP_E_LANES 4          // split E-step: the unit set runs as up to this many independent lanes (streams)
 #define VLGP_PRIOR_SLOTS 64   // prior lengths factored per mailbox round
 
 // One low-rank prior factor per distinct unit length (gp.make_cholesky).
@@ -122,6 +123,9 @@ struct vlgp_ctx {
     void* hx = nullptr;           // host-side exchange segment for the H-step round sums (single node)
     int rank = 0, world = 1;
 
+    // second lane of the split E-step (estep_split.hip): half of the unit set runs its sweeps here
+    hipStream_t elane[VLGP_E_LANES - 1] = {};
+    hipEvent_t ev_e_fork = nullptr, ev_e_join[VLGP_E_LANES - 1] = {};
     int last_estep_path = 0;      // VLGP_PATH_ESTEP_* of the most recent E-step / update_w / update_v launch
 
     std::string err;

@@ -1103,11 +1103,15 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_
     }
 }
 
+// the stream the launch helpers below enqueue on: the handle's main stream, or the second E-step lane (the unit set
+// split in two halves that run their sweeps side by side, launch_estep_split)
+static thread_local hipStream_t t_lane = nullptr;
+
 template <int LT, int CS, int RPL>
 int run_passes_cs(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
     constexpr int RPB = (256 / CS) * RPL;
     const dim3 grid((unsigned)((A.rows + RPB - 1) / RPB)), blk(256);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = t_lane;
     if (A.xb) {
         if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, true, CS, RPL>), grid, blk, 0, st, A, cols);
         else hipLaunchKernelGGL((esplit_pass<LT, SP_W, true, CS, RPL>), grid, blk, 0, st, A, cols);
@@ -1123,8 +1127,8 @@ template <int LT>
 int run_passes(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
     if (kind == SP_YA) {
         const dim3 grid((unsigned)((A.rows + 255) / 256)), blk(256);
-        if (A.xb) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, true, 1, 1>), grid, blk, 0, ctx->stream, A, cols);
-        else hipLaunchKernelGGL((esplit_pass<LT, SP_YA, false, 1, 1>), grid, blk, 0, ctx->stream, A, cols);
+        if (A.xb) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, true, 1, 1>), grid, blk, 0, t_lane, A, cols);
+        else hipLaunchKernelGGL((esplit_pass<LT, SP_YA, false, 1, 1>), grid, blk, 0, t_lane, A, cols);
         HIPCHK(ctx, hipGetLastError());
         return VLGP_OK;
     }
@@ -1160,7 +1164,7 @@ int run_ya(vlgp_ctx* ctx, const SplitArgs& A, int LT, const double* cols, const 
     if (A.N > 128 || old_form) return run_pass(ctx, A, LT, SP_YA, cols);
     const int rows_per_wave = 64;
     const dim3 grid((unsigned)((A.rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave))), blk(256);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = t_lane;
 #define ESPLIT_YA(LTV, NJV) \
     hipLaunchKernelGGL((esplit_ya<LTV, NJV>), grid, blk, 0, st, A.N, A.L, A.rows, A.ld, A.y, ycoef, A.ya, rows_per_wave)
     const bool small = A.N <= 64;
@@ -1179,7 +1183,7 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     const dim3 grid(A.shg ? (unsigned)(((A.M + 3) / 4) * A.n_lat) : (unsigned)((tasks + 3) / 4)), blk(256);
     static const int lds_pad = getenv("VLGP_LDS_PAD") ? atoi(getenv("VLGP_LDS_PAD")) : 0;  // occupancy experiments
     const size_t lds = (size_t)(4 * (A.pkl + A.lds_g + 128 + (mean ? 192 : 0)) + (A.shg ? A.shg_cap : 0)) * 8 + (size_t)lds_pad;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = t_lane;
 #define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
     do {                                                                                                              \
         auto fn = (MEANV && A.last) ? esplit_latent<RA, MEANV, MEANV> : esplit_latent<RA, MEANV>;                                                                           \
@@ -1348,39 +1352,101 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     const int n_it = with_mean ? E.n_iter : ((mode & EM_W) ? 1 : 0);
     const int kind = maxra <= 16 ? VLGP_PROF_ESTEP_RA16 : (maxra <= 24 ? VLGP_PROF_ESTEP_RA24 : VLGP_PROF_ESTEP_RA32);
     vlgp_prof_begin(ctx, kind);
+    t_lane = ctx->stream;
     int rc = VLGP_OK;
     if (with_mean) rc = run_ya(ctx, A, LT, cols, ycoef);
+
+    // TWO LANES.  The units are independent inside an E-step call (core.estep is a loop over units, core.py:123-126),
+    // and every launch of a sweep is partly bound by the latency of one task's dependent chain (factor ~28 us, mean
+    // ~17 us of their 47 / 21 us at C3) and by the ~2.5 us of a dependent launch boundary: the set is cut in two
+    // parts (two by default, VLGP_ESTEP_LANES = 1 .. 4) whose sweeps are enqueued on their own streams, so that one half's latency-bound stretches sit under the other
+    // half's issue-bound passes.  No dependency crosses the halves between the fork and the join; results are
+    // bit-identical to the single lane (same arithmetic per unit).  VLGP_ESTEP_LANES=1 keeps one lane.
+    static const int lanes_env = getenv("VLGP_ESTEP_LANES") ? atoi(getenv("VLGP_ESTEP_LANES")) : 0;
+    int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 8 * ctx->n_cu && n_it >= 2 ? 2 : 1);
+    while (n_lanes > 1 && us.M < 8 * n_lanes) --n_lanes;
+    for (int h = 1; h < n_lanes; ++h) {
+        if (ctx->elane[h - 1]) continue;
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->elane[h - 1], hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_e_join[h - 1], hipEventDisableTiming));
+    }
+    if (n_lanes > 1 && !ctx->ev_e_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_e_fork, hipEventDisableTiming));
+    struct Half { SplitArgs pass, lat; hipStream_t st; int64_t rows; int M; };
+    Half H[VLGP_E_LANES];
+    {
+        for (int h = 0; h < n_lanes; ++h) {
+            // cuts at multiples of four units: the shared-G launches take four units per workgroup
+            int m0 = (int)(((int64_t)us.M * h / n_lanes + 3) & ~3LL), m1 = (int)(((int64_t)us.M * (h + 1) / n_lanes + 3) & ~3LL);
+            if (m0 > us.M) m0 = us.M;
+            if (m1 > us.M || h == n_lanes - 1) m1 = us.M;
+            const int64_t row_lo = us.off[m0], row_hi = us.off[m1];
+            Half& hf = H[h];
+            hf.st = h == 0 ? ctx->stream : ctx->elane[h - 1];
+            hf.M = m1 - m0;
+            hf.rows = row_hi - row_lo;
+            // per-unit kernels: unit tables shifted, rows stay absolute (off[] holds absolute rows)
+            hf.lat = A;
+            hf.lat.M = hf.M;
+            hf.lat.off = A.off + m0;
+            hf.lat.unit_prior = A.unit_prior ? A.unit_prior + m0 : nullptr;
+            hf.lat.xg = A.xg + (int64_t)m0 * L * pkg;
+            hf.lat.failg = A.failg + (int64_t)m0 * L;
+            // row passes: every row-indexed pointer shifted to the half's first row
+            hf.pass = A;
+            hf.pass.rows = hf.rows;
+            hf.pass.y = A.y + row_lo * N;
+            hf.pass.xb = A.xb ? A.xb + row_lo * N : nullptr;
+            hf.pass.mu = A.mu + row_lo; hf.pass.v = A.v + row_lo; hf.pass.w = A.w + row_lo;
+            hf.pass.ra = A.ra + row_lo; hf.pass.ya = A.ya + row_lo;
+        }
+    }
+    // (measured: three or four lanes are SLOWER than one -- E-step 5.7 ms against 3.5 / 3.0 for one / two at C3 -- and
+    // starting the second lane one or two launches late changes nothing)
+    if (n_lanes > 1 && rc == VLGP_OK) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_e_fork, ctx->stream));
+        for (int h = 1; h < n_lanes; ++h) HIPCHK(ctx, hipStreamWaitEvent(ctx->elane[h - 1], ctx->ev_e_fork, 0));
+    }
     for (int it = (mode & EM_FACTOR0) ? -1 : 0; it < n_it && rc == VLGP_OK; ++it) {
         const bool last = it == n_it - 1;
-        bool do_factor, do_v;
-        // per-kernel timing: the launches of ONE sweep per call are bracketed (events on every launch would cost
-        // more than they measure)
-        const bool sample = ctx->prof_on && it == (n_it > 1 ? 1 : 0);
-        if (it >= 0) {
-            if (with_mean) {
-                if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS);
-                rc = run_pass(ctx, A, LT, SP_RES, cols);
-                if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, (double)us.rows);
-                A.last = last ? 1 : 0;
-                if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_MEAN);
-                if (rc == VLGP_OK) rc = run_latent(ctx, A, C, true);
-                if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_MEAN, (double)us.M * L);
+        for (int h = 0; h < n_lanes && rc == VLGP_OK; ++h) {
+            Half& hf = H[h];
+            t_lane = hf.st;
+            bool do_factor, do_v;
+            // per-kernel timing: the launches of ONE sweep per call (first lane) are bracketed (events on every launch
+            // would cost more than they measure); with two lanes the other lane's launches run beside the bracketed one
+            const bool sample = ctx->prof_on && h == 0 && it == (n_it > 1 ? 1 : 0);
+            const double share = (double)hf.rows, tasks = (double)hf.M * L;
+            if (it >= 0) {
+                if (with_mean) {
+                    if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS, hf.st);
+                    rc = run_pass(ctx, hf.pass, LT, SP_RES, cols);
+                    if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, share, hf.st);
+                    hf.lat.last = last ? 1 : 0;
+                    if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_MEAN, hf.st);
+                    if (rc == VLGP_OK) rc = run_latent(ctx, hf.lat, C, true);
+                    if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_MEAN, tasks, hf.st);
+                }
+                if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS, hf.st);
+                if (rc == VLGP_OK) rc = run_pass(ctx, hf.pass, LT, SP_W, cols);
+                if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, share, hf.st);
+                do_factor = with_mean && (E.vb || !last);
+                do_v = E.vb != 0;
+            } else {
+                do_factor = true;
+                do_v = (mode & EM_V) && !with_mean;
             }
-            if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS);
-            if (rc == VLGP_OK) rc = run_pass(ctx, A, LT, SP_W, cols);
-            if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, (double)us.rows);
-            do_factor = with_mean && (E.vb || !last);
-            do_v = E.vb != 0;
-        } else {
-            do_factor = true;
-            do_v = (mode & EM_V) && !with_mean;
+            if (do_factor && rc == VLGP_OK) {
+                hf.lat.do_v = do_v ? 1 : 0;
+                if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_FACTOR, hf.st);
+                rc = run_latent(ctx, hf.lat, C, false);
+                if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_FACTOR, tasks, hf.st);
+            }
         }
-        if (do_factor && rc == VLGP_OK) {
-            A.do_v = do_v ? 1 : 0;
-            if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_FACTOR);
-            rc = run_latent(ctx, A, C, false);
-            if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_FACTOR, (double)us.M * L);
-        }
+    }
+    t_lane = ctx->stream;
+    for (int h = 1; h < n_lanes; ++h) {  // join whatever happened above: the extra lanes must never outlive the call
+        (void)hipEventRecord(ctx->ev_e_join[h - 1], ctx->elane[h - 1]);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_e_join[h - 1], 0);
     }
     if (rc == VLGP_OK) {
         const unsigned nb = (unsigned)((nRL + 255) / 256);
