@@ -191,7 +191,9 @@ def fit(trials, n_factors, device=0, comm=None, verbose=True, **kwargs):
     ``noise``, ``sigma``, ``omega`` and every ``get_config`` key.  Extra:
     ``device`` (GPU index), ``comm`` (a :class:`vlgp_amd.dist.Comm` when the
     trials are sharded over ranks), ``verbose``, ``ichol`` ("device"/"host": who builds the prior
-    factor -- both bit-identical to the reference's), ``materialize_x`` (default True: trials that came
+    factor -- the device kernel is bit-identical to the reference's on the NumPy 2.2 / AVX-512 / OpenBLAS
+    stack the golden vectors were captured on, "host" uses this host's own NumPy: INTEGRATION.md),
+    ``materialize_x`` (default True: trials that came
     without regressors get a writable ``np.ones((T, xdim, N))`` back, as the reference leaves them).
     """
     return FitSession(trials, n_factors, device=device, comm=comm, verbose=verbose, **kwargs).run().finish()

@@ -56,22 +56,29 @@ static inline int nstat_rt(int L, int P, int kind) {
 
 // EXACT: L == LT, P == PT and x == 1 known at compile time -- the common case (3, 5, 8, 10 latents, no regressors):
 // no per-latent predicates or branches in the row loop, and the scalar registers they held go to the exp constants
+//
+// The slices' partial sums meet in LDS MS_GS statistics at a time (the first version spent two barriers per statistic:
+// 54 per launch at five latents, at the end of every workgroup's life with nothing else left to run on the CU).
+// (Measured dead end: the next row tile prefetched into registers across the row loop -- twelve more registers, 27
+// spilled at the 128-register budget of four waves per SIMD.)
+#define MS_GS 8
 template <int LT, int PT, int KIND, bool EXACT>
 // four waves per SIMD (128 VGPRs) up to five latents; the 2 L + L (L + 1) / 2 accumulators of more latents
 // need the registers more than the occupancy
 __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_accum(MArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NA = nacc<LT, PT, KIND>();
+    constexpr int NBUF = 1;
     const int N = A.N, CT = A.CT, S = A.S;
     const int L = EXACT ? LT : A.L, P = EXACT ? PT : A.P;
     const int tid = threadIdx.x;
     const int nl = tid % CT, s = tid / CT;
     const int n = blockIdx.y * CT + nl;
     const bool active = s < S && n < N;
-    double* mu_t = smem;               // M_TILE x L
-    double* v_t = mu_t + M_TILE * L;   // M_TILE x L
-    double* red = v_t + M_TILE * L;    // S x CT
-    double* etab = red + S * CT;       // NEWTON: 2^(j/64) for fast_exp_tab (visible after the first barrier of the row loop)
+    const int tile_d = 2 * M_TILE * L;        // one buffer: mu tile | v tile
+    double* red = smem;                       // aliases the tiles after the row loop: MS_GS x (S CT)
+    const int red_d = MS_GS * S * CT;
+    double* etab = smem + (NBUF * tile_d > red_d ? NBUF * tile_d : red_d);  // NEWTON: 2^(j/64) for fast_exp_tab
     if constexpr (KIND == K_NEWTON) fast_exp_tab_init(etab, tid);
 
     double al[LT], al2[LT], bl[PT], acc[NA];
@@ -90,16 +97,21 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
     const int64_t c0 = (int64_t)blockIdx.x * A.rows_per_wg;
     int64_t c1 = c0 + A.rows_per_wg;
     if (c1 > A.rows) c1 = A.rows;
+    auto copy_tile = [&](double* buf, int64_t t0) {
+        const int cnt = (int)((c1 - t0) < M_TILE ? (c1 - t0) : M_TILE) * L;
+        for (int i = tid; i < cnt; i += blockDim.x) {
+            buf[i] = A.mu[t0 * L + i];
+            buf[M_TILE * L + i] = A.v[t0 * L + i];
+        }
+    };
+    if (c0 < c1) copy_tile(smem, c0);
+    __syncthreads();
     for (int64_t t0 = c0; t0 < c1; t0 += M_TILE) {
         const int nr = (int)((c1 - t0) < M_TILE ? (c1 - t0) : M_TILE);
-        __syncthreads();
-        for (int i = tid; i < nr * L; i += blockDim.x) {
-            mu_t[i] = A.mu[t0 * L + i];
-            v_t[i] = A.v[t0 * L + i];
-        }
-        __syncthreads();
-        if (!active) continue;
-        if (KIND == K_NEWTON && gch) continue;  // Gaussian channels need no rate statistics
+        const bool more = t0 + M_TILE < c1;
+        const double* mu_t = smem;
+        const double* v_t = mu_t + M_TILE * L;
+        if (active && !(KIND == K_NEWTON && gch)) {  // Gaussian channels need no rate statistics
 #pragma unroll 2
         for (int rr = s; rr < nr; rr += S) {  // two rows in flight: independent exp / FMA chains
             const int64_t row = t0 + rr;
@@ -167,53 +179,75 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
                 }
             }
         }
-    }
-    // slices -> one partial per workgroup, statistic by statistic.  The
-    // template index k (padded LT/PT) is mapped to the exact (L, P) layout.
-    auto emit = [&](int k_exact, double val) {
-        __syncthreads();
-        if (s < S) red[s * CT + nl] = active ? val : 0.0;
-        __syncthreads();
-        if (s == 0 && n < N) {
-            double t = 0.0;
-            for (int q = 0; q < S; ++q) t += red[q * CT + nl];
-            const int K = KIND == K_PREP ? L + P + P * L + tri(P)
-                        : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
-            A.partial[((int64_t)blockIdx.x * K + k_exact) * N + n] = t;
         }
-    };
-    if constexpr (KIND == K_PREP) {
+        if (more) {
+            __syncthreads();  // everybody is done with the tile
+            copy_tile(smem, t0 + M_TILE);
+        }
+        __syncthreads();
+    }
+    // slices -> one partial per workgroup, MS_GS statistics per round through LDS.  kex[k]: where the template's
+    // (padded LT / PT) accumulator k sits in the exact (L, P) layout, -1 for padding.
+    int kex[NA];
+    {
         int k = 0, ke = 0;
+        if constexpr (KIND == K_PREP) {
 #pragma unroll
-        for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+            for (int l = 0; l < LT; ++l, ++k) kex[k] = l < L ? ke++ : -1;
 #pragma unroll
-        for (int j = 0; j < PT; ++j, ++k) if (j < P) emit(ke++, acc[k]);
+            for (int j = 0; j < PT; ++j, ++k) kex[k] = j < P ? ke++ : -1;
 #pragma unroll
-        for (int j = 0; j < PT; ++j)
+            for (int j = 0; j < PT; ++j)
 #pragma unroll
-            for (int l = 0; l < LT; ++l, ++k) if (j < P && l < L) emit(ke++, acc[k]);
+                for (int l = 0; l < LT; ++l, ++k) kex[k] = (j < P && l < L) ? ke++ : -1;
 #pragma unroll
-        for (int i = 0; i < PT; ++i)
+            for (int i = 0; i < PT; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j, ++k) if (i < P) emit(ke++, acc[k]);
-    } else if constexpr (KIND == K_NEWTON) {
-        int k = 0, ke = 0;
+                for (int j = 0; j <= i; ++j, ++k) kex[k] = i < P ? ke++ : -1;
+        } else if constexpr (KIND == K_NEWTON) {
 #pragma unroll
-        for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+            for (int l = 0; l < LT; ++l, ++k) kex[k] = l < L ? ke++ : -1;
 #pragma unroll
-        for (int i = 0; i < LT; ++i)
+            for (int i = 0; i < LT; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j, ++k) if (i < L) emit(ke++, acc[k]);
+                for (int j = 0; j <= i; ++j, ++k) kex[k] = i < L ? ke++ : -1;
 #pragma unroll
-        for (int l = 0; l < LT; ++l, ++k) if (l < L) emit(ke++, acc[k]);
+            for (int l = 0; l < LT; ++l, ++k) kex[k] = l < L ? ke++ : -1;
 #pragma unroll
-        for (int j = 0; j < PT; ++j, ++k) if (j < P) emit(ke++, acc[k]);
+            for (int j = 0; j < PT; ++j, ++k) kex[k] = j < P ? ke++ : -1;
 #pragma unroll
-        for (int i = 0; i < PT; ++i)
+            for (int i = 0; i < PT; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j, ++k) if (i < P) emit(ke++, acc[k]);
-    } else {
-        emit(0, acc[0]);
+                for (int j = 0; j <= i; ++j, ++k) kex[k] = i < P ? ke++ : -1;
+        } else {
+            kex[0] = 0;
+        }
+    }
+    const int K = KIND == K_PREP ? L + P + P * L + tri(P) : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+    const int SC = S * CT;
+#pragma unroll
+    for (int g0 = 0; g0 < NA; g0 += MS_GS) {
+        if (s < S) {
+#pragma unroll
+            for (int j = 0; j < MS_GS; ++j)
+                if (g0 + j < NA) red[j * SC + s * CT + nl] = active ? acc[g0 + j] : 0.0;
+        }
+        __syncthreads();
+        // (statistic j, channel nl) pairs of this group, spread over the workgroup; slices added in slice order
+        for (int o = tid; o < MS_GS * CT; o += blockDim.x) {
+            const int j = o / CT, c = o - j * CT;
+            int ke = -1;
+#pragma unroll
+            for (int jj = 0; jj < MS_GS; ++jj)
+                if (g0 + jj < NA && jj == j) ke = kex[g0 + jj];
+            const int nn = blockIdx.y * CT + c;
+            if (ke >= 0 && nn < N) {
+                double t = 0.0;
+                for (int q = 0; q < S; ++q) t += red[j * SC + q * CT + c];
+                A.partial[((int64_t)blockIdx.x * K + ke) * N + nn] = t;
+            }
+        }
+        if (g0 + MS_GS < NA) __syncthreads();
     }
 }
 
@@ -646,7 +680,10 @@ static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
     g.rows_per_wg = (int)((rows + G - 1) / G);
     g.rows_per_wg = ((g.rows_per_wg + 7) / 8) * 8;  // an even split over the workgroups: every CU gets the same share
     g.G = (int)((rows + g.rows_per_wg - 1) / g.rows_per_wg);
-    g.lds = (size_t)(2 * M_TILE * L + g.S * g.CT + 64) * 8;  // + the exp table
+    {   // the row tile (mu | v) aliased by the MS_GS-statistic reduction buffer, + the exp table
+        const size_t tiles = (size_t)2 * M_TILE * L, redb = (size_t)MS_GS * g.S * g.CT;
+        g.lds = ((tiles > redb ? tiles : redb) + 64) * 8;
+    }
     return g;
 }
 
