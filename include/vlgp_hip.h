@@ -249,6 +249,7 @@ int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const do
 #define VLGP_PATH_ESTEP_FAST 2     /* persistent workgroup per unit, register-resident factors */
 #define VLGP_PATH_ESTEP_LONG 3     /* long units (T > 64), one workgroup per trial */
 #define VLGP_PATH_ESTEP_GENERIC 4  /* generic kernels (rank > 50 slots, L > 10, ...) */
+#define VLGP_PATH_ESTEP_LSPLIT 5   /* long units as chip-wide launches: one workgroup per (unit, latent) task */
 int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
 
 #ifdef __cplusplus

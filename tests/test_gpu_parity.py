@@ -35,8 +35,10 @@ def estep_path(request, monkeypatch):
     VLGP_ESTEP_SPLIT is read per call by launch_estep_split."""
     if request.param == "split":
         monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
+        monkeypatch.setenv("VLGP_ESTEP_LSPLIT", "1")   # long units: one workgroup per (unit, latent) task
     else:
         monkeypatch.delenv("VLGP_ESTEP_SPLIT", raising=False)
+        monkeypatch.delenv("VLGP_ESTEP_LSPLIT", raising=False)
     return request.param
 
 
@@ -47,9 +49,9 @@ def _ran(V, path, *calls):
     for c in calls:
         got = E.TRACE.get(c)
         if path == "split":
-            assert got == "split", (c, got)
+            assert got in ("split", "long_split"), (c, got)
         else:
-            assert got in ("fast", "generic", "long", "split"), (c, got)
+            assert got in ("fast", "generic", "long", "split", "long_split"), (c, got)
 
 
 def _params(g, L, N, P=1, rank=50, chol=None):
@@ -188,12 +190,15 @@ def test_estep_golden(V, golden, tag, method, n_it, estep_path):
         assert np.abs(units[m]["dmu"] - ref).max() < STAGE * np.abs(units[m]["mu"]).max()
 
 
-def test_estep_long_unit_golden(V, golden):
-    # T = 300 takes the streamed (non-LDS-resident) kernel path, truncated-rank G injected
+def test_estep_long_unit_golden(V, golden, estep_path):
+    # T = 300: the persistent long-unit kernel (default for a single unit) and the task-parallel launch sequence
+    # (forced), truncated-rank G injected
     g = golden("estep_long")
     units = _units(g)
     params = _params(g, 3, 20, chol={300: g["G"]})
     V.estep(units, params, V.get_config(Eniter=5))
+    from vlgp_amd import engine as E
+    assert E.TRACE["estep"] == ("long_split" if estep_path == "split" else "long")
     for k in ("mu", "v", "w", "dmu"):
         assert relerr(units[0][k], g[k + "_VB_5"][0]) < STAGE, k
 
@@ -249,8 +254,6 @@ def _random_problem(rng, lengths, N, L, P, n_gauss, rank=50):
 ])
 def test_estep_random_vs_oracle(V, case, estep_path):
     import zlib
-    if estep_path == "split" and max(case["lengths"]) > 64:
-        pytest.skip("the split E-step is the short-unit path (T <= 64); long units have one path")
     rng = np.random.default_rng(zlib.crc32(str(sorted(case.items())).encode()))
     units, params, gauss = _random_problem(rng, case["lengths"], case["N"], case["L"], case["P"], case["g"])
     cfg = V.get_config(Eniter=4)

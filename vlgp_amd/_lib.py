@@ -21,7 +21,7 @@ UNIQUE_ID_BYTES = 128
 PROF_ESTEP, PROF_MSTEP, PROF_HSTEP, PROF_PRIOR = 0, 1, 2, 3
 PROF_ESTEP_RA16, PROF_ESTEP_RA24, PROF_ESTEP_RA32, PROF_ESTEP_LONG, PROF_ESTEP_GENERIC = 4, 5, 6, 7, 8
 PROF_ESTEP_PASS, PROF_ESTEP_FACTOR, PROF_ESTEP_MEAN = 9, 10, 11  # split E-step, sampled launches
-ESTEP_PATHS = ("none", "split", "fast", "long", "generic")  # VLGP_PATH_ESTEP_*
+ESTEP_PATHS = ("none", "split", "fast", "long", "generic", "long_split")  # VLGP_PATH_ESTEP_*
 
 _lib = None
 

@@ -1103,6 +1103,336 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_
     }
 }
 
+// =========================================================================================================
+// LONG units (T > 64: core.infer / api.transform on full-length trials, update_w / update_v before them) on the same
+// launch sequence: the row passes above work for any unit length; the per-latent phases get one WORKGROUP per
+// (unit, latent) task -- 1000 tasks of 4 waves at C3 instead of the 200 eight-wave workgroups of the persistent
+// long-unit kernel (estep_long.hip: 1.6 waves per SIMD, latency-bound on L2 loads: 12.6 ms for ten sweeps).  Factor size
+// = the reference's fixed rank 50 (preprocess.py:80) with identity padding above the effective rank, as there.
+constexpr int LRP = 50;
+constexpr int LPK = tri_packed_size(LRP);  // packed lower-triangular 50 x 50, rows padded to even
+constexpr int LRED = 10 * 256;             // the ten 16 x 16 tiles of one half of the time axis
+
+__device__ __forceinline__ void ltile_of(int tile, int& bi, int& bj) {  // lower block triangle of 4 x 4, row-major
+    bi = tile < 1 ? 0 : (tile < 3 ? 1 : (tile < 6 ? 2 : 3));
+    bj = tile - (bi * (bi + 1)) / 2;
+}
+
+// elong_factor, task (m, l): H = I + G'WG on the matrix pipe (the time axis in two halves, the block rows {3, 0} /
+// {2, 1} of the lower block triangle on the two waves of a half: five tiles each), Cholesky + triangular inverse by one
+// wave (wave_tri.h, rows / columns in registers), X to global for the mean launch, v_t = |X g_t|^2 as Z = X G' in
+// 16-bin column blocks.  (Measured alternatives at C3, 1000 tasks: the three phases as three launches with the matrix
+// through global memory -- lighter waves for the build and the variance -- 180 + 34 + 155 us against 320 us for this
+// kernel; the build's loads software-pipelined one step ahead of its matrix instructions: no change.)
+__global__ void __launch_bounds__(256, 2) elong_factor(SplitArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Xp = smem;            // LPK
+    double* red = smem + LPK;     // LRED
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = A.L;
+    const int m = blockIdx.x / L, l = blockIdx.x - m * L;
+    const int64_t r0 = A.off[m];
+    const int T = (int)(A.off[m + 1] - r0);
+    const int pidx = A.unit_prior[m];
+    const int r = __builtin_amdgcn_readfirstlane(A.prior_rl[pidx * L + l]);
+    const double* __restrict__ Gl = A.prior_base[pidx] + A.prior_goff[pidx * L + l];
+    const double* __restrict__ w_s = A.w + (int64_t)l * A.ld + r0;
+    double* v_s = A.v + (int64_t)l * A.ld + r0;
+    const int col = lane & 15, kq = lane >> 4;
+
+    for (int i = tid; i < LPK; i += 256) Xp[i] = 0.0;
+    __syncthreads();
+    if (tid < LRP) Xp[tri_row_off(tid) + tid] = 1.0;  // identity: rows above the effective rank are never visited
+    // ---- F1 ----
+    {
+        const int half = wid >> 1, which = wid & 1;
+        const int Th = ((T / 2) + 15) & ~15;
+        const int ta = half ? Th : 0, tb = half ? T : (Th < T ? Th : T);
+        // tiles of this wave: which == 0: (3,0) (3,1) (3,2) (3,3) (0,0); which == 1: (2,0) (2,1) (2,2) (1,0) (1,1)
+        double4_t c[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) c[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        const int nbk = (r + 15) >> 4;  // 16-column blocks of G that hold anything (wave-uniform)
+        for (int t0 = ta; t0 < tb; t0 += 16) {  // four k-steps of loads in flight before the matrix instructions
+            double g[4][4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 4 * u + kq;
+                const bool in = t < tb;
+                const int tc = in ? t : tb - 1;
+                const double* row = Gl + (int64_t)tc * r;
+                wv[u] = in ? w_s[tc] : 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int cb = 16 * b + col;
+                    double gv = 0.0;
+                    if (b < nbk) gv = row[cb < r ? cb : 0];
+                    g[u][b] = (in && cb < r) ? gv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (which == 0) {
+                    if (nbk > 3) {
+                        const double a3 = wv[u] * g[u][3];
+                        c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][0], c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][1], c[1], 0, 0, 0);
+                        c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][2], c[2], 0, 0, 0);
+                        c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][3], c[3], 0, 0, 0);
+                    }
+                    c[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[u] * g[u][0], g[u][0], c[4], 0, 0, 0);
+                } else {
+                    if (nbk > 2) {
+                        const double a2 = wv[u] * g[u][2];
+                        c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g[u][0], c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g[u][1], c[1], 0, 0, 0);
+                        c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g[u][2], c[2], 0, 0, 0);
+                    }
+                    if (nbk > 1) {
+                        const double a1 = wv[u] * g[u][1];
+                        c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g[u][0], c[3], 0, 0, 0);
+                        c[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g[u][1], c[4], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // second half of the time axis -> LDS, first half adds it (fixed order) and plants the packed matrix
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[((which * 5 + i) * 4 + q) * 64 + lane] = c[i][q];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int bi = which == 0 ? (i < 4 ? 3 : 0) : (i < 3 ? 2 : 1);
+                const int bj = which == 0 ? (i < 4 ? i : 0) : (i < 3 ? i : i - 3);
+                const int cb = 16 * bj + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * bi + kq + 4 * q;
+                    const double val = c[i][q] + red[((which * 5 + i) * 4 + q) * 64 + lane];
+                    if (cb <= row && row < r) Xp[tri_row_off(row) + cb] = val + (cb == row ? 1.0 : 0.0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- F2: one wave, rows / columns in registers ----
+    if (wid == 0) {
+        bool ok;
+        {
+            double rr[LRP];
+            ok = wave_chol_rows<LRP>(rr, Xp, lane);
+        }
+        {
+            double x[LRP];
+            wave_tri_inverse_cols<LRP>(Xp, x, lane);
+            tri_wave_sync();
+            if (lane < LRP) {  // X overwrites L, row-major packed: X[i][c] for i >= c
+#pragma unroll
+                for (int i = 0; i < LRP; ++i)
+                    if (i >= lane) Xp[tri_row_off(i) + lane] = x[i];
+            }
+        }
+        if (lane == 0) {
+            s_ok = ok ? 1 : 0;
+            A.failg[m * L + l] = ok ? 0 : 1;
+            if (!ok) atomicAdd(A.fail, 1);
+        }
+    }
+    __syncthreads();
+    {
+        double* xd = A.xg + (int64_t)(m * L + l) * A.pkg;
+        for (int i = tid; i < LPK; i += 256) xd[i] = Xp[i];
+    }
+    if (!A.do_v || !s_ok) return;  // a failed factor leaves v as it is (core.py:112-113)
+    // ---- F3: v_t = |X g_t|^2.  X tiles (ib, kb <= ib) as A operands in registers, B operand G'[k][n] = G[t0 + n][k];
+    // D[row = kq + 4 q][n]: sum of squares over the rows ----
+    double xa[10][4];
+#pragma unroll
+    for (int pr = 0; pr < 10; ++pr) {
+        int ib, kb;
+        ltile_of(pr, ib, kb);
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+            const int i = 16 * ib + col, k = 16 * kb + 4 * sq + kq;
+            double val = (i == k) ? 1.0 : 0.0;
+            if (i < LRP) val = (k <= i) ? Xp[tri_row_off(i) + k] : 0.0;
+            xa[pr][sq] = val;
+        }
+    }
+    const int ntb = (T + 15) / 16;
+    for (int tb = wid; tb < ntb; tb += 4) {
+        const int t = 16 * tb + col;
+        const bool tin = t < T;
+        double4_t acc[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (16 * kb >= r) continue;  // wave-uniform: those columns of G are zero
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+                const int k = 16 * kb + 4 * sq + kq;
+                const double gB = (tin && k < r) ? Gl[(int64_t)t * r + k] : 0.0;
+#pragma unroll
+                for (int ib = kb; ib < 4; ++ib)
+                    acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(ib * (ib + 1)) / 2 + kb][sq], gB, acc[ib], 0, 0, 0);
+            }
+        }
+        double vv = 0.0;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv = fma(acc[ib][q], acc[ib][q], vv);
+        vv += __shfl_xor(vv, 16, 64);
+        vv += __shfl_xor(vv, 32, 64);
+        if (kq == 0 && tin) v_s[t] = vv;
+    }
+}
+
+// task (m, l): the Newton step on the posterior mean in the push-through form (see mean_task),
+//     delta = G (I + H)^-1 G'(ra + W mu) - mu,   (I + H)^-1 = X'X,
+// one reduction over the time axis (split over the four waves, lane <-> column of G), the two triangular products by
+// one wave, one expansion (thread <-> time bin).  `last`: the clipped step is handed back as dmu.
+__global__ void __launch_bounds__(256, 4) elong_mean(SplitArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Xp = smem;               // LPK
+    double* part = smem + LPK;       // 4 x 64
+    double* vec = part + 256;        // 64
+    double* vec2 = vec + 64;         // 64
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = A.L;
+    const int m = blockIdx.x / L, l = blockIdx.x - m * L;
+    const int64_t r0 = A.off[m];
+    const int T = (int)(A.off[m + 1] - r0);
+    if (A.failg[m * L + l]) {  // singular system: zero update (core.py:92-94)
+        if (tid == 0) atomicAdd(A.fail, 1);
+        if (A.last)
+            for (int t = tid; t < T; t += 256) A.dmu[(r0 + t) * L + l] = 0.0;
+        return;
+    }
+    const int pidx = A.unit_prior[m];
+    const int r = __builtin_amdgcn_readfirstlane(A.prior_rl[pidx * L + l]);
+    const double* __restrict__ Gl = A.prior_base[pidx] + A.prior_goff[pidx * L + l];
+    const double* __restrict__ w_s = A.w + (int64_t)l * A.ld + r0;
+    const double* __restrict__ ra_s = A.ra + (int64_t)l * A.ld + r0;
+    double* mu_s = A.mu + (int64_t)l * A.ld + r0;
+    {
+        const double* xs = A.xg + (int64_t)(m * L + l) * A.pkg;
+        for (int i = tid; i < LPK; i += 256) Xp[i] = xs[i];
+    }
+    // c = G' s, s = ra + w mu.  Sixteen lanes share a row of G and walk its columns sixteen at a time (128 contiguous
+    // bytes per row and load), four rows per wave and step; the time axis in four contiguous quarters over the waves.
+    const int r4 = lane >> 4, c16 = lane & 15;
+    {
+        const int Tc = (((T + 3) / 4) + 3) & ~3;
+        const int ta = wid * Tc, tb = ta + Tc < T ? ta + Tc : T;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int t0 = ta; t0 < tb; t0 += 16) {  // four steps (sixteen rows, twenty-eight loads) in flight: the loop is a chain of L2 round trips
+            double gv[4][4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 4 * u + r4;
+                const bool in = t < tb;
+                const int tc = in ? t : ta;
+                const double* row = Gl + (int64_t)tc * r;
+                sv[u] = in ? fma(w_s[tc], mu_s[tc], ra_s[tc]) : 0.0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int cb = 16 * bb + c16;
+                    gv[u][bb] = cb < r ? row[cb] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) acc[bb] = fma(gv[u][bb], sv[u], acc[bb]);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            acc[bb] += __shfl_xor(acc[bb], 16, 64);
+            acc[bb] += __shfl_xor(acc[bb], 32, 64);
+        }
+        if (r4 == 0) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) part[wid * 64 + 16 * bb + c16] = acc[bb];
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+        vec2[lane] = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+        tri_wave_sync();
+        // z = X c (lane = row), sol = X' z (lane = column); rows / columns >= r of X are the identity and c is zero there
+        double z = 0.0;
+        if (lane < LRP) {
+            const double* Xi = Xp + tri_row_off(lane);
+            double z0 = 0.0, z1 = 0.0;
+            int q = 0;
+            for (; q + 1 <= lane; q += 2) {
+                const double2 x2 = *reinterpret_cast<const double2*>(Xi + q);
+                z0 = fma(x2.x, vec2[q], z0);
+                z1 = fma(x2.y, vec2[q + 1], z1);
+            }
+            if (q <= lane) z0 = fma(Xi[q], vec2[q], z0);
+            z = z0 + z1;
+        }
+        vec[lane] = z;
+        tri_wave_sync();
+        double sol = 0.0;
+        if (lane < LRP) {
+            double s0 = 0.0, s1 = 0.0;
+            int i = lane;
+            for (; i + 1 < LRP; i += 2) {
+                s0 = fma(Xp[tri_row_off(i) + lane], vec[i], s0);
+                s1 = fma(Xp[tri_row_off(i + 1) + lane], vec[i + 1], s1);
+            }
+            if (i < LRP) s0 = fma(Xp[tri_row_off(i) + lane], vec[i], s0);
+            sol = s0 + s1;
+        }
+        tri_wave_sync();
+        vec2[lane] = lane < r ? sol : 0.0;
+    }
+    __syncthreads();
+    // delta_t = G[t] . sol - mu_t, clipped; mu += delta: the same sixteen-lanes-per-row walk, reduced over the sixteen
+    {
+        double so[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) so[bb] = vec2[16 * bb + c16];  // zero beyond the rank
+        for (int t0 = 16 * wid; t0 < T; t0 += 64) {  // four steps (sixteen rows) per wave and turn
+            double gv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 4 * u + r4;
+                const double* row = Gl + (int64_t)(t < T ? t : 0) * r;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int cb = 16 * bb + c16;
+                    gv[u][bb] = cb < r ? row[cb] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double d = (gv[u][0] * so[0] + gv[u][1] * so[1]) + (gv[u][2] * so[2] + gv[u][3] * so[3]);
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
+                const int t = t0 + 4 * u + r4;
+                if (c16 == 0 && t < T) {
+                    const double mt = mu_s[t];
+                    double sd = d - mt;
+                    sd = fmin(fmax(sd, -A.dmu_bound), A.dmu_bound);
+                    mu_s[t] = mt + sd;
+                    if (A.last) A.dmu[(r0 + t) * L + l] = sd;
+                }
+            }
+        }
+    }
+}
+
 // the stream the launch helpers below enqueue on: the handle's main stream, or the second E-step lane (the unit set
 // split in two halves that run their sweeps side by side, launch_estep_split)
 static thread_local hipStream_t t_lane = nullptr;
@@ -1201,6 +1531,16 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     return VLGP_OK;
 }
 
+// long units: one workgroup per (unit, latent)
+int run_latent_long(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
+    const unsigned tasks = (unsigned)(A.M * A.L);
+    if (tasks == 0) return VLGP_OK;
+    if (mean) hipLaunchKernelGGL(elong_mean, dim3(tasks), dim3(256), (size_t)(LPK + 384) * 8, t_lane, A);
+    else hipLaunchKernelGGL(elong_factor, dim3(tasks), dim3(256), (size_t)(LPK + LRED) * 8, t_lane, A);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
 // One launch per rank class: the latents of rank <= 16 run the lean instantiation (staged G, small LDS footprint),
 // the others the mixed one -- a single latent above 16 slows its own waves only.
 struct LatentClasses {
@@ -1260,9 +1600,18 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     const char* sw = getenv("VLGP_ESTEP_SPLIT");
     if (sw && sw[0] == '0') return VLGP_OK;
     if (getenv("VLGP_ESTEP_GENERIC")) return VLGP_OK;
-    if (us.Tmax > 64 || L > 10 || N > 1024) return VLGP_OK;
+    if (L > 10 || N > 1024) return VLGP_OK;
+    // long units (full-length trials): the same launch sequence with one workgroup per (unit, latent) task, once there
+    // are enough tasks to fill the chip (VLGP_ESTEP_LSPLIT=0/1 never / always)
+    const bool lng = us.Tmax > 64;
+    if (lng) {
+        const char* lsw = getenv("VLGP_ESTEP_LSPLIT");
+        if (lsw && lsw[0] == '0') return VLGP_OK;
+        if (ctx->R > LRP) return VLGP_OK;
+        if (!(lsw && lsw[0] == '1') && (int64_t)us.M * L < 128) return VLGP_OK;
+    }
     // the persistent kernel wins while a launch cannot fill the chip (its cost is latency, not throughput)
-    if (!(sw && sw[0] == '1') && (us.rows < 64LL * 1024 || us.M < 2 * ctx->n_cu)) return VLGP_OK;
+    if (!lng && !(sw && sw[0] == '1') && (us.rows < 64LL * 1024 || us.M < 2 * ctx->n_cu)) return VLGP_OK;
     const bool need_prior = (E.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
     int rmax = 0;
     int rlat[16] = {0};  // largest rank of each latent over the priors this set uses
@@ -1286,11 +1635,11 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             }
         }
     }
-    if (rmax > 32) return VLGP_OK;
+    if (!lng && rmax > 32) return VLGP_OK;
     const int maxra = rmax <= 16 ? 16 : (rmax <= 20 ? 20 : (rmax <= 24 ? 24 : 32));
     const int LT = L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : 10));
     const int REC = (2 * LT + 3 + 1) & ~1;
-    const int pkg = tri_packed_size(maxra);
+    const int pkg = lng ? LPK : tri_packed_size(maxra);
     // scratch of the set: ra | ya | xg | failg(int) ; records + wconst in ctx->d_ecols
     const int64_t nRL = us.rows * L;
     const int64_t need = 5 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8;
@@ -1344,13 +1693,14 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             if (kv.second.T == us.Tmax) C.single = &kv.second;
     }
     A.do_v = 0; A.last = 0;
-    *handled = 1;
+    *handled = lng ? 2 : 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
 
     const int mode = E.mode;
     const bool with_mean = (mode & EM_MEAN) != 0;
     const int n_it = with_mean ? E.n_iter : ((mode & EM_W) ? 1 : 0);
-    const int kind = maxra <= 16 ? VLGP_PROF_ESTEP_RA16 : (maxra <= 24 ? VLGP_PROF_ESTEP_RA24 : VLGP_PROF_ESTEP_RA32);
+    const int kind = lng ? VLGP_PROF_ESTEP_LONG
+                         : (maxra <= 16 ? VLGP_PROF_ESTEP_RA16 : (maxra <= 24 ? VLGP_PROF_ESTEP_RA24 : VLGP_PROF_ESTEP_RA32));
     vlgp_prof_begin(ctx, kind);
     t_lane = ctx->stream;
     int rc = VLGP_OK;
@@ -1423,7 +1773,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
                     if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, share, hf.st);
                     hf.lat.last = last ? 1 : 0;
                     if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_MEAN, hf.st);
-                    if (rc == VLGP_OK) rc = run_latent(ctx, hf.lat, C, true);
+                    if (rc == VLGP_OK) rc = lng ? run_latent_long(ctx, hf.lat, true) : run_latent(ctx, hf.lat, C, true);
                     if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_MEAN, tasks, hf.st);
                 }
                 if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS, hf.st);
@@ -1438,7 +1788,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             if (do_factor && rc == VLGP_OK) {
                 hf.lat.do_v = do_v ? 1 : 0;
                 if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_FACTOR, hf.st);
-                rc = run_latent(ctx, hf.lat, C, false);
+                rc = lng ? run_latent_long(ctx, hf.lat, false) : run_latent(ctx, hf.lat, C, false);
                 if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_FACTOR, tasks, hf.st);
             }
         }

@@ -66,6 +66,7 @@ class Engine:
             check(rc, None)
         self.h = h
         self.sets = {}  # set id -> (M, rows, offsets)
+        self.state_epoch = 0  # bumped by every call that can change a set's mu (em_iteration's norm cache keys on it)
         self.rank, self.world = 0, 1
         self.host_exchange = False
 
@@ -96,6 +97,7 @@ class Engine:
     # -- unit sets --------------------------------------------------------
     def upload(self, set_id, trials):
         """Pack a list of trial dicts (keys y, x, mu, v, w) into set ``set_id``."""
+        self.state_epoch += 1
         lengths = np.array([tr["y"].shape[0] for tr in trials], dtype=np.int64)
         off = np.zeros(len(trials) + 1, dtype=np.int64)
         np.cumsum(lengths, out=off[1:])
@@ -130,12 +132,14 @@ class Engine:
         self.sets[set_id] = (len(trials), int(off[-1]), off)
 
     def cut(self, src, dst, starts, window):
+        self.state_epoch += 1
         starts = np.ascontiguousarray(starts, dtype=np.int64)
         self._ck(self.lib.vlgp_cut_units(self.h, src, dst, len(starts), i64ptr(starts), int(window)))
         off = np.arange(len(starts) + 1, dtype=np.int64) * int(window)
         self.sets[dst] = (len(starts), int(off[-1]), off)
 
     def merge(self, cut_set):
+        self.state_epoch += 1
         self._ck(self.lib.vlgp_merge_units(self.h, cut_set))
 
     def download(self, set_id, keys=("mu", "v", "w", "dmu")):
@@ -148,9 +152,11 @@ class Engine:
 
     def stash_mu(self, set_id, restore=False):
         """Keep (or write back) a device-side copy of the set's mu (see vlgp_stash_mu)."""
+        self.state_epoch += 1
         self._ck(self.lib.vlgp_stash_mu(self.h, int(set_id), int(bool(restore))))
 
     def free_units(self, set_id):
+        self.state_epoch += 1
         self._ck(self.lib.vlgp_free_units(self.h, set_id))
         self.sets.pop(set_id, None)
 
@@ -198,14 +204,17 @@ class Engine:
 
     # -- E / M / H --------------------------------------------------------
     def update_w(self, set_id):
+        self.state_epoch += 1
         self._ck(self.lib.vlgp_update_w(self.h, set_id))
 
     def update_v(self, set_id, vb=True, count=True):
+        self.state_epoch += 1
         n = C.c_int(0)
         self._ck(self.lib.vlgp_update_v(self.h, set_id, int(bool(vb)), C.byref(n) if count else None))
         return n.value
 
     def estep(self, set_id, n_iter, dmu_bound=5.0, vb=True, count=True):
+        self.state_epoch += 1
         n = C.c_int(0)
         self._ck(self.lib.vlgp_estep(self.h, set_id, int(n_iter), float(dmu_bound), int(bool(vb)),
                                      C.byref(n) if count else None))
@@ -247,6 +256,7 @@ class Engine:
 
     def project_latent(self, set_id, proj, shift):
         """mu = y @ proj - shift on the device for every row of the set; returns the column sums of y."""
+        self.state_epoch += 1
         proj = _f64(proj)
         shift = _f64(shift)
         if proj.shape != (self.N, self.L) or shift.shape != (self.L,):
@@ -264,6 +274,7 @@ class Engine:
 
     # -- constraints / norms ----------------------------------------------
     def apply_latent_map(self, set_id, mat, shift=None):
+        self.state_epoch += 1
         mat = _f64(mat)
         if mat.shape != (self.L, self.L):
             raise ValueError("latent map must be (L, L)")
@@ -640,7 +651,14 @@ def em_iteration(trials, params, config, runtime, echo=None):
     eng, sid = trials.engine, trials.set_id
     tol = config["tol"]
     runtime["it"] += 1
-    norm_mu, _ = eng.norms(sid)       # pre-iteration norms (core.py:300-305)
+    # pre-iteration norm of mu (core.py:300-305): the value the previous iteration's closing norms call returned,
+    # when nothing has touched the set since (one kernel + one device -> host copy less per iteration)
+    cached = getattr(trials, "_norm_cache", None)
+    if cached is not None and cached[0] == (eng.state_epoch, sid):
+        norm_mu = cached[1]
+    else:
+        norm_mu, _ = eng.norms(sid)
+    trials._norm_cache = None
     norm_a = np.linalg.norm(params["a"])
     norm_b = np.linalg.norm(params["b"])
 
@@ -701,7 +719,8 @@ def em_iteration(trials, params, config, runtime, echo=None):
             except RuntimeError:
                 logger.error("Callback {} failed".format(cb))
 
-    _, norm_dmu = eng.norms(sid)
+    norm_mu_now, norm_dmu = eng.norms(sid)
+    trials._norm_cache = ((eng.state_epoch, sid), norm_mu_now)
     converged = (norm_dmu < tol * norm_mu
                  and np.linalg.norm(params["da"]) < tol * norm_a
                  and np.linalg.norm(params["db"]) < tol * norm_b)
