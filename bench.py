@@ -32,9 +32,10 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = matrix peak (AMD spec)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
-# C3s8 = the shard of C3 one rank holds at 8 GPUs (25 of the 200 trials): its time per EM iteration on one MI355X is the
+# C3s8 (C3s4, C3s2) = the shard of C3 one rank holds at 8 (4, 2) GPUs (25 of the 200 trials): its time per EM iteration on one MI355X is the
 # compute a rank has left at N = 8, i.e. an upper bound on the strong-scaling speed-up before any exchange
-WORKLOADS = {"C1": (10, 200, 20, 3), "C2": (50, 500, 50, 3), "C3": (200, 1000, 100, 5), "C3s8": (25, 1000, 100, 5)}
+WORKLOADS = {"C1": (10, 200, 20, 3), "C2": (50, 500, 50, 3), "C3": (200, 1000, 100, 5), "C3s8": (25, 1000, 100, 5),
+             "C3s2": (100, 1000, 100, 5), "C3s4": (50, 1000, 100, 5)}  # the shards of C3 at 2 and 4 GPUs
 
 
 def build_inputs(name):

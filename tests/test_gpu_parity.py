@@ -31,7 +31,7 @@ def V():
 def estep_path(request, monkeypatch):
     """Both dispatch paths of the short-unit E-step, every run: the size-based default (persistent kernels on
     fixture-sized sets) and the split E-step (estep_split.hip: the chip-wide launch sequence that takes over at
-    >= 512 units / 64 k rows -- the kernels the headline number is made of) forced onto the same inputs.
+    more than 512 units -- the kernels the headline number is made of) forced onto the same inputs.
     VLGP_ESTEP_SPLIT is read per call by launch_estep_split."""
     if request.param == "split":
         monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
@@ -662,7 +662,7 @@ def test_headline_size_properties(V):
     dict(M=1312, N=16, L=5, P=3, g=16, vb=True, n_it=3, omega=None),
 ])
 def test_split_estep_at_dispatch_size_vs_oracle(V, case):
-    """Sets at and above the size where the split E-step takes over BY ITSELF (>= 512 units and >= 64 k rows, no
+    """Sets at and above the size where the split E-step takes over BY ITSELF (more than 512 units, no
     environment switch): update_w, update_v and the E-step of every unit on the device, 60 random units against the
     oracle (core.infer_single_trial, vlgp/core.py:22-120; update_w/update_v :419-471)."""
     import zlib

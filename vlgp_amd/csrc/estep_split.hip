@@ -1610,8 +1610,10 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         if (ctx->R > LRP) return VLGP_OK;
         if (!(lsw && lsw[0] == '1') && (int64_t)us.M * L < 128) return VLGP_OK;
     }
-    // the persistent kernel wins while a launch cannot fill the chip (its cost is latency, not throughput)
-    if (!lng && !(sw && sw[0] == '1') && (us.rows < 64LL * 1024 || us.M < 2 * ctx->n_cu)) return VLGP_OK;
+    // the persistent kernel (one workgroup per unit, two or three per CU) wins while its workgroups are ONE generation
+    // (measured at N = 100, L = 5: 500 units 0.89 ms persistent / 1.09 ms split; 1000 units 2.09 / 1.42 ms -- the second
+    // generation costs as much as the first however few units it holds)
+    if (!lng && !(sw && sw[0] == '1') && (us.rows < 16LL * 1024 || us.M <= 2 * ctx->n_cu)) return VLGP_OK;
     const bool need_prior = (E.mode & (EM_FACTOR0 | EM_MEAN | EM_V)) != 0;
     int rmax = 0;
     int rlat[16] = {0};  // largest rank of each latent over the priors this set uses
@@ -1713,7 +1715,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     // half's issue-bound passes.  No dependency crosses the halves between the fork and the join; results are
     // bit-identical to the single lane (same arithmetic per unit).  VLGP_ESTEP_LANES=1 keeps one lane.
     static const int lanes_env = getenv("VLGP_ESTEP_LANES") ? atoi(getenv("VLGP_ESTEP_LANES")) : 0;
-    int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 8 * ctx->n_cu && n_it >= 2 ? 2 : 1);
+    int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 6 * ctx->n_cu && n_it >= 2 ? 2 : 1);  // 2000 units: 2.11 -> 1.77 ms, 1000 units: no change
     while (n_lanes > 1 && us.M < 8 * n_lanes) --n_lanes;
     for (int h = 1; h < n_lanes; ++h) {
         if (ctx->elane[h - 1]) continue;

@@ -59,8 +59,11 @@ static inline int nstat_rt(int L, int P, int kind) {
 //
 // The slices' partial sums meet in LDS MS_GS statistics at a time (the first version spent two barriers per statistic:
 // 54 per launch at five latents, at the end of every workgroup's life with nothing else left to run on the CU).
-// (Measured dead end: the next row tile prefetched into registers across the row loop -- twelve more registers, 27
-// spilled at the 128-register budget of four waves per SIMD.)
+// (Measured dead ends: the next row tile prefetched into registers across the row loop -- twelve more registers, 27
+// spilled at the 128-register budget of four waves per SIMD; at ten latents, the 77 accumulators of a thread split over
+// two launches per Newton iteration (gradient sums + Hessian rows < 7 / rows >= 7 + r'v sums, both recomputing the
+// rate) to get from two to four waves per SIMD: a, a^2, mu, v, mt and q of ten latents are 120 registers before the
+// first accumulator, 130 registers spilled, C5's M-step 46 -> 270 ms.)
 #define MS_GS 8
 template <int LT, int PT, int KIND, bool EXACT>
 // four waves per SIMD (128 VGPRs) up to five latents; the 2 L + L (L + 1) / 2 accumulators of more latents
