@@ -1143,6 +1143,13 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
         double* Kl = lds + TASKW;
         double* kvs = lds + LDSN - SHR;               // one-set layout: shared tables at the end of the block's LDS
         double* dks = kvs + HmGeom50::KVN;
+        // the operands of C for this wave's block row of the products: in flight while wave 0 factors
+        double preC[(T + 3) / 4];
+        constexpr bool PRE = NW >= (T + 15) / 16;
+        // (wave 0 fetches after its factorisation: thirteen values held across it cost 40 spilled registers)
+        if constexpr (PRE) {
+            if (wid != 0) hstep_kblock_fetch<T>(R.mom + (int64_t)A.latent[e] * T * T, lane, wid, preC);
+        }
         if (wid == 0) {
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
             if constexpr (ONESET) {
@@ -1171,11 +1178,12 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
                 A.scal[4 * e + 2] = omega;
                 A.scal[4 * e + 3] = (logdet == logdet && fabs(logdet) < 1e300) ? 1.0 : 0.0;  // a bad pivot -> NaN / inf
             }
+            if constexpr (PRE) hstep_kblock_fetch<T>(R.mom + (int64_t)A.latent[e] * T * T, lane, 0, preC);
         }
         __syncthreads();
         double quad, gq;
         hstep_kblock_products<T>(Kl, LDK, R.mom + (int64_t)A.latent[e] * T * T, ONESET ? dks : buf + G::O_DKV, A.Tr, lane,
-                                 wid, NW, quad, gq);
+                                 wid, NW, quad, gq, PRE ? &preC : nullptr);
         for (int o = 32; o > 0; o >>= 1) {
             quad += __shfl_xor(quad, o, 64);
             gq += __shfl_xor(gq, o, 64);

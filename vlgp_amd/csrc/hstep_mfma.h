@@ -795,14 +795,68 @@ __device__ __forceinline__ bool hstep_task_mfma50(double* buf, const double* kvs
 // with K^-1 in LDS (`kl`, full symmetric, stride ldk = 2 mod 4), C in global memory (TP x TP, zero beyond the rows
 // present) and dK Toeplitz from its first column `dkv` (zero beyond tr).  Wave `wid` of `nwv` takes the 16-row
 // block rows wid, wid + nwv, ...; returns this wave's partial sums (per lane; the caller reduces over the wave).
+// `pre` (optional): the C operands of block row `wid`, fetched by the caller BEFORE it waited for K^-1 (hstep_kblock_fetch:
+// the waves that do not factor are idle meanwhile, and thirteen dependent trips to L2 leave the critical path of a
+// round -- the K block is what a round costs when the segments do not fill the chip: C1, C2, a rank's shard at 8 GPUs)
+template <int TP>
+__device__ __forceinline__ void hstep_kblock_fetch(const double* __restrict__ C, int lane, int wid,
+                                                   double (&pre)[(TP + 3) / 4]) {
+    constexpr int NK = (TP + 3) / 4;
+    const int c = lane & 15, g = lane >> 4;
+    const int ra_ = 16 * wid + c;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        const int kcol = 4 * kk + g;
+        pre[kk] = (ra_ < TP && kcol < TP) ? C[ra_ * TP + kcol] : 0.0;
+    }
+}
+
 template <int TP>
 __device__ __forceinline__ void hstep_kblock_products(const double* kl, int ldk, const double* __restrict__ C,
                                                       const double* dkv, int tr_k, int lane, int wid, int nwv,
-                                                      double& quad, double& gq) {
+                                                      double& quad, double& gq,
+                                                      const double (*pre)[(TP + 3) / 4] = nullptr) {
     constexpr int NBK = (TP + 15) / 16, NK = (TP + 3) / 4;
     const int c = lane & 15, g = lane >> 4;
     quad = 0.0;
     gq = 0.0;
+    if (pre != nullptr && nwv >= NBK) {  // one block row per wave, operands of C already in registers
+        const int a = wid;
+        if (a >= NBK) return;
+        hm_d4 Eb[NBK], Gb[NBK];
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            Eb[b] = hm_d4{0.0, 0.0, 0.0, 0.0};
+            Gb[b] = hm_d4{0.0, 0.0, 0.0, 0.0};
+        }
+        const int ra_ = 16 * a + c;
+        const bool rin = ra_ < TP;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int kcol = 4 * kk + g;
+            const bool kin = kcol < TP;
+            const double opC = (*pre)[kk];
+            const double opKa = (rin && kin) ? kl[ra_ * ldk + kcol] : 0.0;
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                const int rb_ = 16 * b + c;
+                const bool bin = rb_ < TP && kin;
+                const double opKb = bin ? kl[rb_ * ldk + kcol] : 0.0;
+                const int dd = kcol - rb_;
+                const double opD = (bin && kcol < tr_k && rb_ < tr_k) ? dkv[dd < 0 ? -dd : dd] : 0.0;
+                Eb[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(opC, opKb, Eb[b], 0, 0, 0);
+                Gb[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(opKa, opD, Gb[b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                gq = fma(Eb[b][p], Gb[b][p], gq);
+                if (b == a && g + 4 * p == c) quad += Eb[b][p];
+            }
+        return;
+    }
     for (int a = wid; a < NBK; a += nwv) {
         hm_d4 Eb[NBK], Gb[NBK];
 #pragma unroll
