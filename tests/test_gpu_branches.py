@@ -75,12 +75,14 @@ def test_constraint_modes_two_em_iterations_vs_oracle(V, kw):
         assert relerr(tg["v"], tr["v"]) < (1e-5 if same else 1e-4)
 
 
-def test_hstep_objective_retry_when_K_does_not_factor(V):
+@pytest.mark.parametrize("T", [50, 100])
+def test_hstep_objective_retry_when_K_does_not_factor(V, T):
     """gp.construct_posterior_cov (vlgp/gp.py:128-135): a kernel matrix that fails its Cholesky gets log 10 ADDED
     to omega (the reference's quirk: it adds to the exponentiated parameter) until it factors; gp.elbo then
-    sees the modified omega too.  Provoked with a jitter far below rounding at a tiny omega."""
+    sees the modified omega too.  Provoked with a jitter far below rounding at a tiny omega.  T = 50: the round kernel
+    hands a failed K to the generic kernels; T = 100: the retry loop of hstep_prep_big."""
     rng = np.random.default_rng(4)
-    M, T, L = 37, 50, 2
+    M, L = 37, 2
     units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": rng.uniform(0.05, 3.0, (T, L)),
               "v": np.zeros((T, L))} for _ in range(M)]
     pts = np.log(np.array([[1.0, 1e-9, 1e-22],      # K = ones + 1e-22 I: not positive definite in fp64 -> retry

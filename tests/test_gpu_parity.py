@@ -449,11 +449,12 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
     assert abs(got[1][0, 1] - want[1][1]) <= STAGE * max(abs(want[1][1]), 1e-3 * abs(want[0]))
 
 
-@pytest.mark.parametrize("T", [20, 25, 40, 56, 64, 100, 128])
-def test_hstep_objective_other_windows_vs_oracle(V, T):
+@pytest.mark.parametrize("T", [20, 25, 40, 56, 64, 65, 80, 100, 127, 128])
+def test_hstep_objective_other_windows_vs_oracle(V, T, monkeypatch):
     """Windows other than 50: 24..50 and 51..64 run the matrix-pipe round compiled for 50 / 64 with identity
-    padding, the others the generic kernels (one T x T matrix per wave in LDS, lane-strided rows above 64 bins):
-    (ll, dll) against gp.obj_func's restatement."""
+    padding, 65..128 the workgroup-per-segment kernels (hstep_prep_big / hstep_seg_big: A split at row 64, both
+    64 x 64 inverses and the four products on the matrix pipe), below 24 the generic kernels (one T x T matrix per
+    wave in LDS): (ll, dll) against gp.obj_func's restatement; above 64 also against the generic kernels."""
     rng = np.random.default_rng(T)
     M, L = 6, 2
     units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": 2.0 * rng.random((T, L)),
@@ -468,6 +469,13 @@ def test_hstep_objective_other_windows_vs_oracle(V, T):
                                            np.stack([u["w"][:, l] for u in units], 1))
         assert abs(ll[l] - want_ll) <= STAGE * abs(want_ll), (T, l)
         assert abs(dll[l, 1] - want_dll[1]) <= 1e-7 * max(abs(want_dll[1]), 1e-3 * abs(want_ll)), (T, l)
+    if T > 64:
+        monkeypatch.setenv("VLGP_HSTEP_GENERIC_SEG", "1")
+        with V.Engine(2, L, 1, 50) as eng:
+            eng.upload(0, units)
+            ll2, dll2 = eng.hstep_objective(0, T, 1.0, np.arange(L), logp)
+        assert np.abs(ll2 - ll).max() <= STAGE * np.abs(ll).max()
+        assert np.abs(dll2[:, 1] - dll[:, 1]).max() <= 1e-7 * np.abs(ll).max()
 
 
 def test_hstep_optimize_golden(V, golden):

@@ -244,6 +244,295 @@ __global__ void __launch_bounds__(256) hstep_seg_kernel(HSegArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Windows 65 .. 128 (gp.py:77-80 with a window above the compiled 64): one WORKGROUP (four waves) per (segment,
+// evaluation), everything cubic on the matrix pipe.  A = I + S K S (S = diag sqrt(w)) is split at row 64,
+//     A = [A11 A21'; A21 A22],   P11 = A11^-1,  B = A21 P11,  Q = (A22 - B A21')^-1,  C = Q B,
+//     A^-1 = [P11 + B'C, -C'; -C, Q],
+// with the two 64 x 64 inverses from the blocked augmented elimination of hstep_mfma.h (wave 0; the second one on the
+// explicit Schur complement, identity-padded to 64) and the four 64 x 64 x 64 products as v_mfma_f64_16x16x4 block rows
+// over the four waves, operands of the Toeplitz blocks generated from the first columns of K and dK in LDS.  What the
+// round needs are tr(A^-1) and cs = sum_jk s_j s_k dK_jk (A^-1)_jk (see "Fast path" below):
+//     tr = tr P11 + <B, C> + tr Q - (padding),   cs = <W11, P11> + <B W11, C> - 2 <W21, C> + <W22, Q>,  W = ss' o dK.
+// The quadratic terms alpha = K^-1 mu, alpha' dK alpha use K^-1 of hstep_prep_kernel and run on the idle waves while
+// wave 0 factors.  Replaces hstep_seg_kernel (one wave per segment, the whole T x T matrix walked entry by entry in LDS:
+// 12.9 ms per launch at window 100 on the C3 data).
+struct HBigArgs {
+    HSegArgs S;
+    const double* logp;  // (n_eval, 3) on the device
+    double dt;
+};
+
+// D (64 x 64) = A (64 x 64) B (64 x 64): wave `wid` owns block row wid; fa(i, k), fb(k, j) produce the operands,
+// fo(i, j, value) consumes the result
+template <class FA, class FB, class FO>
+__device__ __forceinline__ void big_gemm64(int lane, int wid, FA fa, FB fb, FO fo) {
+    const int c = lane & 15, g = lane >> 4;
+    hm_d4 acc[4];
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) acc[bj] = hm_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + g;
+        const double opa = fa(16 * wid + c, k);
+        double opb[4];
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) opb[bj] = fb(k, 16 * bj + c);
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa, opb[bj], acc[bj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) fo(16 * wid + g + 4 * p, 16 * bj + c, acc[bj][p]);
+}
+
+// The K part of a round for windows 65 .. 128: K^-1 (full, to global memory, for alpha = K^-1 mu) and log det chol(K)
+// of one evaluation per workgroup through the same split -- K11^-1, B = K21 K11^-1, Q = (K22 - B K21')^-1, C = Q B,
+// K^-1 = [K11^-1 + B'C, -C'; -C, Q] -- with the reference's retry (omega += log 10 while K does not factor, gp.py:135).
+// Replaces hstep_prep_kernel there (entry-by-entry loops over T x T matrices: 1.5 ms at window 100, 3.5 ms at 128 per
+// launch); the segment kernel below needs neither K^-1 dK K^-1 nor tr(K^-1 dK).
+__global__ void __launch_bounds__(256, 1) hstep_prep_big(HPrepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    using G = HmGeom<64>;
+    constexpr int LD = 66;
+    double* P11 = smem;
+    double* Bm = P11 + 64 * LD;
+    double* Sm = Bm + 64 * LD;
+    double* Cm = Sm + 64 * LD;
+    double* buf = Cm + 64 * LD;
+    double* sv = buf + G::TASK;
+    double* kv = sv + 128;
+    __shared__ int s_bad;
+    __shared__ double s_ld[2];
+    const int T = A.T, T2 = T - 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = blockIdx.x;
+    const double sigmasq = exp(A.logp[3 * e + 0]), eps = exp(A.logp[3 * e + 2]);
+    double omega = exp(A.logp[3 * e + 1]);
+    bool ok = false;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        if (tid == 0) s_bad = 0;
+        if (tid < 128) {
+            const double d = tid * A.dt;
+            sv[tid] = tid < T ? 1.0 : 0.0;
+            kv[tid] = sigmasq * exp(-omega * d * d) + (tid == 0 ? eps : 0.0);
+        }
+        __syncthreads();
+        if (wid == 0) {
+            buf[G::O_SV + lane] = 1.0;
+            buf[G::O_KVM + 63 + lane] = kv[lane];
+            buf[G::O_KVM + 63 - lane] = kv[lane];
+            buf[G::O_DKV + lane] = 0.0;
+            if (lane < 32) buf[G::O_Z + lane] = 0.0;
+            tri_wave_sync();
+            double ld, unused;
+            hstep_task_mfma<64, true>(buf, eps, lane, ld, unused, 64, P11, LD);  // tr_k = 64: K11 itself, no unit diagonal
+            if (lane == 0) {
+                s_ld[0] = ld;
+                if (!(ld == ld && fabs(ld) < 1e300)) s_bad = 1;
+            }
+        }
+        __syncthreads();
+        big_gemm64(lane, wid,
+                   [&](int i, int k) { return sv[64 + i] * kv[64 + i - k]; },
+                   [&](int k, int j) { return P11[k * LD + j]; },
+                   [&](int i, int j, double v) { Bm[i * LD + j] = v; });
+        __syncthreads();
+        big_gemm64(lane, wid,
+                   [&](int i, int k) { return Bm[i * LD + k]; },
+                   [&](int k, int j) { return sv[64 + j] * kv[64 + j - k]; },
+                   [&](int i, int j, double v) {
+                       const int dd = i > j ? i - j : j - i;
+                       const double pad = (i == j && i >= T2) ? 1.0 : 0.0;  // identity below the rows present
+                       Sm[i * LD + j] = fma(sv[64 + i] * sv[64 + j], kv[dd], pad) - v;
+                   });
+        __syncthreads();
+        if (wid == 0) {
+            double ld, unused;
+            hstep_task_mfma<64, true, true>(buf, eps, lane, ld, unused, 64, Sm, LD, Sm, LD);
+            if (lane == 0) {
+                s_ld[1] = ld;
+                if (!(ld == ld && fabs(ld) < 1e300)) s_bad = 1;
+            }
+        }
+        __syncthreads();
+        ok = s_bad == 0;
+        if (ok) break;
+        omega += 2.302585092994046;  // gp.py:135 adds log(10) to omega itself
+        __syncthreads();
+    }
+    big_gemm64(lane, wid,
+               [&](int i, int k) { return Sm[i * LD + k]; },
+               [&](int k, int j) { return Bm[k * LD + j]; },
+               [&](int i, int j, double v) { Cm[i * LD + j] = v; });
+    __syncthreads();
+    double* Ki = A.kinv + (int64_t)e * T * T;
+    big_gemm64(lane, wid,
+               [&](int j, int i) { return Bm[i * LD + j]; },
+               [&](int i, int k) { return Cm[i * LD + k]; },
+               [&](int j, int k, double v) { Ki[j * T + k] = P11[j * LD + k] + v; });
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = idx >> 6, k = idx & 63;
+        if (i < T2) {
+            const double cv = -Cm[i * LD + k];
+            Ki[(64 + i) * T + k] = cv;
+            Ki[k * T + 64 + i] = cv;
+            if (k < T2) Ki[(64 + i) * T + 64 + k] = Sm[i * LD + k];
+        }
+    }
+    if (tid == 0) {
+        A.scal[4 * e + 0] = s_ld[0] + s_ld[1];
+        A.scal[4 * e + 1] = 0.0;
+        A.scal[4 * e + 2] = omega;
+        A.scal[4 * e + 3] = ok ? 1.0 : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) hstep_seg_big(HBigArgs H) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    using G = HmGeom<64>;
+    constexpr int LD = 66;
+    const HSegArgs& A = H.S;
+    double* P11 = smem;              // 64 x LD: A11^-1, later C = Q B
+    double* Bm = P11 + 64 * LD;      // 64 x LD: B = A21 P11 (rows >= T - 64 are zero)
+    double* Sm = Bm + 64 * LD;       // 64 x LD: Schur complement, then Q
+    double* buf = Sm + 64 * LD;      // task buffer of the factor routine
+    double* sv = buf + G::TASK;      // sqrt(w), zero beyond T
+    double* kv = sv + 128;           // first column of K (jitter at distance 0)
+    double* dkv = kv + 128;          // first column of dK / dln omega
+    double* muv = dkv + 128;
+    double* alv = muv + 128;
+    __shared__ double red[4][8];
+    __shared__ int s_bad;
+    const int T = A.T, T2 = T - 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seg = blockIdx.x, e = blockIdx.y;
+    const int l = A.latent[e];
+    const int64_t r0 = A.off[seg];
+    const double sigmasq = exp(H.logp[3 * e + 0]), omega = A.scal[4 * e + 2], eps = exp(H.logp[3 * e + 2]);
+    const double* Ki = A.kinv + (int64_t)e * T * T;
+    if (tid == 0) s_bad = 0;
+    if (tid < 128) {
+        const double w = tid < T ? A.w[(r0 + tid) * A.L + l] : 0.0;
+        const double d = tid * H.dt, d2 = d * d;
+        const double kk = sigmasq * exp(-omega * d2);
+        sv[tid] = sqrt(w);
+        kv[tid] = kk + (tid == 0 ? eps : 0.0);
+        dkv[tid] = -kk * d2 * omega;
+        muv[tid] = tid < T ? A.mu[(r0 + tid) * A.L + l] : 0.0;
+    }
+    __syncthreads();
+    double acc_s[8];  // this thread's shares of: quad, gq, tr, cs (and spares)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc_s[i] = 0.0;
+    // ---- S1: wave 0 inverts A11 = I + S1 K11 S1; the other waves form alpha = K^-1 mu ----
+    if (wid == 0) {
+        buf[G::O_SV + lane] = sv[lane];
+        buf[G::O_KVM + 63 + lane] = kv[lane];
+        buf[G::O_KVM + 63 - lane] = kv[lane];
+        buf[G::O_DKV + lane] = dkv[lane];
+        if (lane < 32) buf[G::O_Z + lane] = 0.0;
+        tri_wave_sync();
+        double ld, unused;
+        hstep_task_mfma<64, true>(buf, eps, lane, ld, unused, 0, P11, LD);
+        if (lane == 0 && !(ld == ld && fabs(ld) < 1e300)) s_bad = 1;
+    } else {
+        for (int t = tid - 64; t < T; t += 192) {  // K^-1 symmetric: columns for coalescing
+            double a0 = 0.0, a1 = 0.0;
+            int j = 0;
+            for (; j + 8 <= T; j += 8) {
+                double kx[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) kx[q] = Ki[(j + q) * T + t];
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    a0 = fma(kx[q], muv[j + q], a0);
+                    a1 = fma(kx[q + 1], muv[j + q + 1], a1);
+                }
+            }
+            for (; j < T; ++j) a0 = fma(Ki[j * T + t], muv[j], a0);
+            alv[t] = a0 + a1;
+        }
+    }
+    __syncthreads();
+    // ---- S2: B = A21 P11 ----
+    big_gemm64(lane, wid,
+               [&](int i, int k) { return (sv[64 + i] * sv[k]) * kv[64 + i - k]; },
+               [&](int k, int j) { return P11[k * LD + j]; },
+               [&](int i, int j, double v) { Bm[i * LD + j] = v; });
+    __syncthreads();
+    // ---- S3: Schur complement A22 - B A21' (rows >= T2: s = 0, B = 0 -> the identity) ----
+    big_gemm64(lane, wid,
+               [&](int i, int k) { return Bm[i * LD + k]; },
+               [&](int k, int j) { return (sv[64 + j] * sv[k]) * kv[64 + j - k]; },
+               [&](int i, int j, double v) {
+                   const int dd = i > j ? i - j : j - i;
+                   Sm[i * LD + j] = fma(sv[64 + i] * sv[64 + j], kv[dd], (i == j ? 1.0 : 0.0)) - v;
+               });
+    __syncthreads();
+    // ---- S4: wave 0 inverts the Schur complement in place; the others take the sums over P11 and the quadratic terms ----
+    if (wid == 0) {
+        double ld, unused;
+        hstep_task_mfma<64, true, true>(buf, eps, lane, ld, unused, 64, Sm, LD, Sm, LD);
+        if (lane == 0 && !(ld == ld && fabs(ld) < 1e300)) s_bad = 1;
+    } else {
+        for (int idx = tid - 64; idx < 64 * 64; idx += 192) {
+            const int j = idx >> 6, k = idx & 63;
+            const int dd = j > k ? j - k : k - j;
+            const double pv = P11[j * LD + k];
+            acc_s[3] = fma((sv[j] * sv[k]) * dkv[dd], pv, acc_s[3]);
+            if (j == k) acc_s[2] += pv;
+        }
+        for (int t = tid - 64; t < T; t += 192) {
+            double s0 = 0.0;
+            for (int j = 0; j < T; ++j) s0 = fma(dkv[j > t ? j - t : t - j], alv[j], s0);
+            acc_s[0] = fma(muv[t], alv[t], acc_s[0]);
+            acc_s[1] = fma(s0, alv[t], acc_s[1]);
+        }
+    }
+    __syncthreads();
+    // ---- S5: C = Q B (over P11) ----
+    big_gemm64(lane, wid,
+               [&](int i, int k) { return Sm[i * LD + k]; },
+               [&](int k, int j) { return Bm[k * LD + j]; },
+               [&](int i, int j, double v) { P11[i * LD + j] = v; });
+    __syncthreads();
+    // ---- S6: <B W11, C>, <B, C>, <W21, C>, <W22, Q>, tr Q ----
+    big_gemm64(lane, wid,
+               [&](int i, int k) { return Bm[i * LD + k]; },
+               [&](int k, int j) { return (sv[k] * sv[j]) * dkv[k > j ? k - j : j - k]; },
+               [&](int i, int j, double v) { acc_s[3] = fma(v, P11[i * LD + j], acc_s[3]); });
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = idx >> 6, k = idx & 63;
+        const double cv = P11[i * LD + k];
+        acc_s[2] = fma(Bm[i * LD + k], cv, acc_s[2]);
+        acc_s[3] = fma(-2.0 * (sv[64 + i] * sv[k]) * dkv[64 + i - k], cv, acc_s[3]);
+        const double qv = Sm[i * LD + k];
+        const int dd = i > k ? i - k : k - i;
+        acc_s[3] = fma((sv[64 + i] * sv[64 + k]) * dkv[dd], qv, acc_s[3]);
+        if (i == k) acc_s[2] += qv;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = acc_s[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wid][q] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t4[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        const double quad = t4[0], gq = t4[1], tr = t4[2] - (double)(64 - T2), cs = t4[3];
+        double ll = -0.5 * quad - 0.5 * tr - A.scal[4 * e + 0];
+        double dll = 0.5 * (gq - cs);
+        if (s_bad) { ll = nan(""); dll = nan(""); }
+        A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
+        A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
+    }
+}
+
 // out[e][c] = sum_i in[e][i][c]  (fixed order: strided partial sums, then a tree)
 __global__ void __launch_bounds__(256) hstep_reduce_kernel(int M, const double* in, double* out,
                                                            const double* scal = nullptr, double* ok_out = nullptr) {
@@ -1486,13 +1775,32 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     if (lds_prep > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
-    hipLaunchKernelGGL(hstep_prep_kernel, dim3(n_eval), dim3(256), lds_prep, ctx->stream, P);
+    const bool big = T > 64 && T <= 128 && !getenv("VLGP_HSTEP_GENERIC_SEG");  // hstep_prep_big / hstep_seg_big
+    if (big) {
+        const size_t lds_pb = (size_t)(4 * 64 * 66 + HmGeom<64>::TASK + 2 * 128) * 8;
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_big),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pb));
+        hipLaunchKernelGGL(hstep_prep_big, dim3(n_eval), dim3(256), lds_pb, ctx->stream, P);
+    } else {
+        hipLaunchKernelGGL(hstep_prep_kernel, dim3(n_eval), dim3(256), lds_prep, ctx->stream, P);
+    }
     HIPCHK(ctx, hipGetLastError());
 
     HSegArgs S;
     S.T = T; S.L = L; S.M = M; S.off = us.d_off; S.mu = us.mu; S.w = us.w;
     S.latent = reinterpret_cast<const int*>(W + o_lat);
     S.kinv = W + o_kinv; S.q = W + o_q; S.dk = W + o_dk; S.scal = W + o_scal; S.out = W + o_out;
+    if (big) {  // one workgroup per segment, matrix pipe (hstep_seg_big)
+        HBigArgs B;
+        B.S = S; B.logp = W + o_logp; B.dt = dt;
+        const size_t lds_big = (size_t)(3 * 64 * 66 + HmGeom<64>::TASK + 5 * 128) * 8;
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_seg_big),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+        vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
+        hipLaunchKernelGGL(hstep_seg_big, dim3(M, n_eval), dim3(256), lds_big, ctx->stream, B);
+        vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
     const int nw = (size_t)2 * (T * (T | 1) + 2 * HS_MAXT) * 8 <= 160 * 1024 ? 2 : 1;
     const size_t lds_seg = (size_t)nw * (T * (T | 1) + 2 * HS_MAXT) * 8;
     if (lds_seg > 64 * 1024)
@@ -1502,6 +1810,7 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     hipLaunchKernelGGL(hstep_seg_kernel, dim3((M + nw - 1) / nw, n_eval), dim3(64 * nw), lds_seg, ctx->stream, S);
     vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
     HIPCHK(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red);
     HIPCHK(ctx, hipGetLastError());
     CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));

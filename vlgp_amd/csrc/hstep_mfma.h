@@ -71,9 +71,16 @@ __device__ __forceinline__ double hm_rsqrt(double d) {
 // KMODE (the K block of the round): the same elimination applied to K itself -- sv holds 1 for the rows present and
 // 0 beyond, rows >= tr_k carry a unit diagonal (identity padding) -- and instead of the two sums the routine leaves
 // K^-1 as a full symmetric TP x ldk matrix in `kl` (LDS) and returns log det chol(K) in tr.
-template <int TP, bool KMODE = false>
+//
+// EXPL (with KMODE, tr_k = TP): the matrix is not generated from the tables but read from `aex` (LDS, full symmetric
+// TP x lda, its own diagonal included): the inverse of an explicit SPD matrix, used for the Schur complement of the
+// long-window segment kernel (hstep.hip, hstep_seg_big).  In place (kl == aex) is fine: every panel's entries are read
+// before the inverse is written at the end.
+template <int TP, bool KMODE = false, bool EXPL = false>
 __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lane, double& tr, double& cs,
-                                                int tr_k = 0, double* kl = nullptr, int ldk = 0) {
+                                                int tr_k = 0, double* kl = nullptr, int ldk = 0,
+                                                const double* aex = nullptr, int lda = 0) {
+    static_assert(!EXPL || KMODE, "the explicit-matrix form returns the inverse (KMODE)");
     using G = HmGeom<TP>;
     constexpr int NB = G::NB, E = G::E, LDB = G::LDB, WL = G::WL, TB = 16 * NB;
     const double* sv = buf + G::O_SV;
@@ -153,7 +160,18 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     mv = *reinterpret_cast<const double2*>(pm + q);
                 }
                 // A = diag(one) + S K S - N: the addend comes ready from LDS (first panel: the unit diagonal by select)
-                if (k > 0) {
+                if constexpr (EXPL) {
+                    const double2 av = *reinterpret_cast<const double2*>(aex + (i < TP ? i : TP - 1) * lda + col0 + q);
+                    ra[q] = av.x + nv.x;
+                    ra[q + 1] = av.y + nv.y;
+                    if (k > 0) {
+                        rx[q] = mv.x;
+                        rx[q + 1] = mv.y;
+                    } else {
+                        rx[q] = (ln == q ? 1.0 : 0.0);
+                        rx[q + 1] = (ln == q + 1 ? 1.0 : 0.0);
+                    }
+                } else if (k > 0) {
                     ra[q] = fma(si * sj.x, pk[-q], nv.x);
                     ra[q + 1] = fma(si * sj.y, pk[-q - 1], nv.y);
                     rx[q] = mv.x;
