@@ -64,6 +64,9 @@ int vlgp_destroy(vlgp_ctx* ctx);
 /* Last error text of this handle (or of the failed vlgp_create when ctx is NULL). */
 const char* vlgp_last_error(vlgp_ctx* ctx);
 int vlgp_synchronize(vlgp_ctx* ctx);
+/* Drains the main stream only: an M-step begun with vlgp_mstep_begin keeps running on its lane (vlgp_synchronize
+ * waits for it too).  The EM loop uses it to time the E-step (core.py:307-315) with the M-step already enqueued. */
+int vlgp_synchronize_main(vlgp_ctx* ctx);
 
 /* ---- unit sets -------------------------------------------------------- */
 /* Replaces the list-of-dicts the reference passes around (trial dict keys

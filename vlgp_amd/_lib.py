@@ -43,6 +43,7 @@ _SIGNATURES = {
     "vlgp_destroy": (C.c_int, [_h]),
     "vlgp_last_error": (C.c_char_p, [_h]),
     "vlgp_synchronize": (C.c_int, [_h]),
+    "vlgp_synchronize_main": (C.c_int, [_h]),
     "vlgp_upload_units": (C.c_int, [_h, C.c_int, C.c_int, _i64p, _dp, _dp, _dp, _dp, _dp]),
     "vlgp_cut_units": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _i64p, C.c_int]),
     "vlgp_merge_units": (C.c_int, [_h, C.c_int]),

@@ -568,6 +568,12 @@ extern "C" int vlgp_synchronize(vlgp_ctx* ctx) {
     return VLGP_OK;
 }
 
+extern "C" int vlgp_synchronize_main(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+
 // ---- unit sets -------------------------------------------------------------
 static int set_offsets(vlgp_ctx* ctx, UnitSet& us, int M, const int64_t* off) {
     us.M = M;

@@ -91,8 +91,9 @@ class Engine:
     def _ck(self, rc):
         check(rc, self.h)
 
-    def synchronize(self):
-        self._ck(self.lib.vlgp_synchronize(self.h))
+    def synchronize(self, main_only=False):
+        """Wait for the device: everything, or (main_only) the main stream without a pending M-step lane."""
+        self._ck(self.lib.vlgp_synchronize_main(self.h) if main_only else self.lib.vlgp_synchronize(self.h))
 
     # -- unit sets --------------------------------------------------------
     def upload(self, set_id, trials):
@@ -166,6 +167,13 @@ class Engine:
         if a.shape != (self.L, self.N) or b.shape != (self.P, self.N) or noise.shape != (self.N,):
             raise ValueError("parameter shapes must be a (L,N), b (P,N), noise (N)")
         self._ck(self.lib.vlgp_set_params(self.h, dptr(a), dptr(b), dptr(noise)))
+
+    def set_loading(self, a):
+        """Replace the loading matrix only (constrain_loading rescales a and leaves b, noise alone)."""
+        a = _f64(a)
+        if a.shape != (self.L, self.N):
+            raise ValueError("loading matrix must be (L, N)")
+        self._ck(self.lib.vlgp_set_params(self.h, dptr(a), None, None))
 
     def get_params(self):
         a, da = np.empty((self.L, self.N)), np.empty((self.L, self.N))
@@ -600,7 +608,7 @@ def constrain_loading(trials, params, config):
             trials.engine.stash_mu(trials.parent_set)
             trials.detached = True
         trials.engine.apply_latent_map(trials.set_id, mat)
-        _push_params(trials.engine, params)
+        trials.engine.set_loading(params["a"])  # b and noise are untouched by this constraint
     else:
         for tr in trials:
             tr["mu"] = tr["mu"] @ mat if kind == "svd" else _imul_cols(tr["mu"], np.diag(mat))
@@ -665,21 +673,31 @@ def em_iteration(trials, params, config, runtime, echo=None):
     t0 = time.perf_counter()
     constrain_loading(trials, params, config)
     estep(trials, params, config)
-    eng.synchronize()
-    t1 = time.perf_counter()
     # M and H are independent given the posterior (M: a, b from mu, v; H: omega from
     # mu, w): the M-step is enqueued on the engine's second stream and runs under the
     # H-step's host-driven rounds.  m_elapsed is the M-step's device time, h_elapsed
     # the wall time of the H-step, em_elapsed the wall time of the whole iteration.
-    constrain_latent(trials, params, config)
     m_ms = 0.0
     m_async = config["Mniter"] >= 1
-    if m_async:
+    latent_constraint = bool(config["constrain_latent"]) and config["constrain_latent"] != "none"
+
+    def begin_m():
         if params.get("da") is None:
             params["da"] = np.zeros_like(params["a"])
             params["db"] = np.zeros_like(params["b"])
         eng.mstep_begin(sid, config["Mniter"], config["use_hessian"], config["eps"], config["learning_rate"],
                         config["da_bound"], config["db_bound"])
+
+    # the M-step lane waits for the E-step on the device (an event): its ~50 launches are enqueued (one graph launch,
+    # ~80 us of host time) while the E-step still runs, unless constrain_latent has to touch mu, a, b in between
+    early_m = m_async and not latent_constraint
+    if early_m:
+        begin_m()
+    eng.synchronize(main_only=True)   # the E-step; the M-step lane is not waited for
+    t1 = time.perf_counter()
+    constrain_latent(trials, params, config)
+    if m_async and not early_m:
+        begin_m()
 
     def finish_m():
         bad, ms = eng.mstep_end()
