@@ -43,6 +43,7 @@ struct UnitSet {
     double* d_mu_stash = nullptr; // copy of mu taken by vlgp_stash_mu (rows x L)
     double* d_scratch = nullptr;  // long-unit E-step scratch
     int64_t scratch_len = 0;
+    double rows_all_ranks = 0.0;  // sum of `rows` over the ranks (M-step noise), exchanged on first use; 0 = unknown
 };
 
 struct ProfSlot {

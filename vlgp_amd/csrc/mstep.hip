@@ -828,7 +828,9 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     CHK(reduce_to(Kp, d_prep));
     CHK(latent_moments(ctx, us, d_part, d_lat, true));
     double total_rows = (double)us.rows;
-    if (ctx->world > 1) {
+    if (ctx->world > 1 && us.rows_all_ranks > 0.0) {
+        total_rows = us.rows_all_ranks;  // fixed at upload: exchanged once per set, not once per M-step
+    } else if (ctx->world > 1) {
         // total row count over ranks rides along in the workspace
         double h = total_rows;
         HIPCHK(ctx, hipMemcpyAsync(d_lat + Kl, &h, sizeof(double), hipMemcpyHostToDevice, st));
@@ -837,6 +839,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
         HIPCHK(ctx, hipMemcpyAsync(&h, d_lat + Kl, sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         total_rows = h;
+        us.rows_all_ranks = h;
     }
 
     SolveArgs S;
