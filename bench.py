@@ -168,8 +168,10 @@ def cpu_baseline(name, budget_trials):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed EM iterations first (the first four run the rank 17-32 classes of the E-step: "
+                         "omega starts at its upper bound)")
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-shm", action="store_true",
