@@ -1118,16 +1118,19 @@ __device__ __forceinline__ void ltile_of(int tile, int& bi, int& bj) {  // lower
     bj = tile - (bi * (bi + 1)) / 2;
 }
 
-// elong_factor, task (m, l): H = I + G'WG on the matrix pipe (the time axis in two halves, the block rows {3, 0} /
-// {2, 1} of the lower block triangle on the two waves of a half: five tiles each), Cholesky + triangular inverse by one
-// wave (wave_tri.h, rows / columns in registers), X to global for the mean launch, v_t = |X g_t|^2 as Z = X G' in
-// 16-bin column blocks.  (Measured alternatives at C3, 1000 tasks: the three phases as three launches with the matrix
-// through global memory -- lighter waves for the build and the variance -- 180 + 34 + 155 us against 320 us for this
-// kernel; the build's loads software-pipelined one step ahead of its matrix instructions: no change.)
+// elong_factor, task (m, l): H = I + G'WG on the matrix pipe, Cholesky + triangular inverse by one wave (wave_tri.h,
+// rows / columns in registers), X to global for the mean launch, v_t = |X g_t|^2 as Z = X G' in 16-bin column blocks.
+// Rank 50 = 3 x 16 + 2: the matrix pipe sees the 48 x 48 part only (six 16 x 16 tiles of H: the time axis in two halves,
+// three tiles on each of the two waves of a half; six tiles of X in the variance), the rows 48, 49 of H and of Z = X G'
+// are dot products on the vector pipe -- padded to 64 they were four tiles of ten in both phases, 87 % zeros (measured:
+// 320 -> 300 us per launch at C3: 40 % fewer matrix instructions buy 6 %, the launch is bound by its 1.6 GB of 8-byte
+// loads of G from L2 -- every task re-reads the factor its 199 neighbours of the same latent read).  (Measured alternatives at C3, 1000 tasks: the three phases as three launches with
+// the matrix through global memory -- lighter waves for the build and the variance -- 180 + 34 + 155 us against 320 us
+// for one kernel; the build's loads software-pipelined one step ahead of its matrix instructions: no change.)
 __global__ void __launch_bounds__(256, 2) elong_factor(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Xp = smem;            // LPK
-    double* red = smem + LPK;     // LRED
+    double* red = smem + LPK;     // LRED: the second half's tiles (6 x 256), then its tail rows (2 x 2 x 64)
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = A.L;
@@ -1140,6 +1143,9 @@ __global__ void __launch_bounds__(256, 2) elong_factor(SplitArgs A) {
     const double* __restrict__ w_s = A.w + (int64_t)l * A.ld + r0;
     double* v_s = A.v + (int64_t)l * A.ld + r0;
     const int col = lane & 15, kq = lane >> 4;
+    const int rb = r < 48 ? r : 48;            // columns the matrix pipe handles
+    const int nbk = (rb + 15) >> 4;            // 16-column blocks among them (wave-uniform)
+    const int ne = r - rb;                     // tail rows 48 .. r - 1 (0, 1 or 2)
 
     for (int i = tid; i < LPK; i += 256) Xp[i] = 0.0;
     __syncthreads();
@@ -1149,75 +1155,107 @@ __global__ void __launch_bounds__(256, 2) elong_factor(SplitArgs A) {
         const int half = wid >> 1, which = wid & 1;
         const int Th = ((T / 2) + 15) & ~15;
         const int ta = half ? Th : 0, tb = half ? T : (Th < T ? Th : T);
-        // tiles of this wave: which == 0: (3,0) (3,1) (3,2) (3,3) (0,0); which == 1: (2,0) (2,1) (2,2) (1,0) (1,1)
-        double4_t c[5];
+        // tiles of this wave: which == 0: (2,0) (2,1) (2,2); which == 1: (1,0) (1,1) (0,0)
+        double4_t c[3];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) c[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-        const int nbk = (r + 15) >> 4;  // 16-column blocks of G that hold anything (wave-uniform)
-        for (int t0 = ta; t0 < tb; t0 += 16) {  // four k-steps of loads in flight before the matrix instructions
-            double g[4][4], wv[4];
+        for (int i = 0; i < 3; ++i) c[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        if (which == 1 || nbk > 2) {
+            for (int t0 = ta; t0 < tb; t0 += 16) {  // four k-steps of loads in flight before the matrix instructions
+                double g[4][3], wv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + 4 * u + kq;
-                const bool in = t < tb;
-                const int tc = in ? t : tb - 1;
-                const double* row = Gl + (int64_t)tc * r;
-                wv[u] = in ? w_s[tc] : 0.0;
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 4 * u + kq;
+                    const bool in = t < tb;
+                    const int tc = in ? t : tb - 1;
+                    const double* row = Gl + (int64_t)tc * r;
+                    wv[u] = in ? w_s[tc] : 0.0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int cb = 16 * b + col;
-                    double gv = 0.0;
-                    if (b < nbk) gv = row[cb < r ? cb : 0];
-                    g[u][b] = (in && cb < r) ? gv : 0.0;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (which == 0) {
-                    if (nbk > 3) {
-                        const double a3 = wv[u] * g[u][3];
-                        c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][0], c[0], 0, 0, 0);
-                        c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][1], c[1], 0, 0, 0);
-                        c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][2], c[2], 0, 0, 0);
-                        c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, g[u][3], c[3], 0, 0, 0);
+                    for (int b = 0; b < 3; ++b) {
+                        const int cb = 16 * b + col;
+                        double gv = 0.0;
+                        if (b < nbk) gv = row[cb < rb ? cb : 0];
+                        g[u][b] = (in && cb < rb) ? gv : 0.0;
                     }
-                    c[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[u] * g[u][0], g[u][0], c[4], 0, 0, 0);
-                } else {
-                    if (nbk > 2) {
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (which == 0) {
                         const double a2 = wv[u] * g[u][2];
                         c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g[u][0], c[0], 0, 0, 0);
                         c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g[u][1], c[1], 0, 0, 0);
                         c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g[u][2], c[2], 0, 0, 0);
-                    }
-                    if (nbk > 1) {
-                        const double a1 = wv[u] * g[u][1];
-                        c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g[u][0], c[3], 0, 0, 0);
-                        c[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g[u][1], c[4], 0, 0, 0);
+                    } else {
+                        const double a0 = wv[u] * g[u][0];
+                        c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, g[u][0], c[2], 0, 0, 0);
+                        if (nbk > 1) {
+                            const double a1 = wv[u] * g[u][1];
+                            c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g[u][0], c[0], 0, 0, 0);
+                            c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g[u][1], c[1], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
+        // tail rows 48, 49 of H on the vector pipe: lane <-> column j, the wave's quarter of the time axis
+        double tl0 = 0.0, tl1 = 0.0;
+        if (ne > 0) {
+            const int tm = (ta + tb) >> 1;
+            const int qa = which ? tm : ta, qb = which ? tb : tm;
+            const int jc = lane < r ? lane : 0;
+            int t = qa;
+            for (; t + 4 <= qb; t += 4) {
+                double gr[4], wq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gr[u] = Gl[(int64_t)(t + u) * r + jc];
+                    wq[u] = w_s[t + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double wg = wq[u] * gr[u];
+                    tl0 = fma(tri_readlane(gr[u], 48), wg, tl0);
+                    tl1 = fma(tri_readlane(gr[u], 49), wg, tl1);  // (lane 49 holds column 0 when r == 49: unused then)
+                }
+            }
+            for (; t < qb; ++t) {
+                const double gr = Gl[(int64_t)t * r + jc];
+                const double wg = w_s[t] * gr;
+                tl0 = fma(tri_readlane(gr, 48), wg, tl0);
+                tl1 = fma(tri_readlane(gr, 49), wg, tl1);
+            }
+        }
         // second half of the time axis -> LDS, first half adds it (fixed order) and plants the packed matrix
+        double* tred = red + 6 * 256;  // [wave 1..3][2][64]
         if (half == 1) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) red[((which * 5 + i) * 4 + q) * 64 + lane] = c[i][q];
+                for (int q = 0; q < 4; ++q) red[((which * 3 + i) * 4 + q) * 64 + lane] = c[i][q];
+        }
+        if (wid > 0) {
+            tred[((wid - 1) * 2 + 0) * 64 + lane] = tl0;
+            tred[((wid - 1) * 2 + 1) * 64 + lane] = tl1;
         }
         __syncthreads();
         if (half == 0) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int bi = which == 0 ? (i < 4 ? 3 : 0) : (i < 3 ? 2 : 1);
-                const int bj = which == 0 ? (i < 4 ? i : 0) : (i < 3 ? i : i - 3);
+            for (int i = 0; i < 3; ++i) {
+                const int bi = which == 0 ? 2 : (i < 2 ? 1 : 0);
+                const int bj = which == 0 ? i : (i < 2 ? i : 0);
                 const int cb = 16 * bj + col;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = 16 * bi + kq + 4 * q;
-                    const double val = c[i][q] + red[((which * 5 + i) * 4 + q) * 64 + lane];
-                    if (cb <= row && row < r) Xp[tri_row_off(row) + cb] = val + (cb == row ? 1.0 : 0.0);
+                    const double val = c[i][q] + red[((which * 3 + i) * 4 + q) * 64 + lane];
+                    if (cb <= row && row < rb) Xp[tri_row_off(row) + cb] = val + (cb == row ? 1.0 : 0.0);
                 }
             }
+        }
+        if (wid == 0 && ne > 0) {
+            const double s0 = ((tl0 + tred[0 * 64 + lane]) + tred[2 * 64 + lane]) + tred[4 * 64 + lane];
+            const double s1 = ((tl1 + tred[1 * 64 + lane]) + tred[3 * 64 + lane]) + tred[5 * 64 + lane];
+            if (lane <= 48) Xp[tri_row_off(48) + lane] = s0 + (lane == 48 ? 1.0 : 0.0);
+            if (ne > 1 && lane <= 49) Xp[tri_row_off(49) + lane] = s1 + (lane == 49 ? 1.0 : 0.0);
         }
     }
     __syncthreads();
@@ -1250,47 +1288,66 @@ __global__ void __launch_bounds__(256, 2) elong_factor(SplitArgs A) {
         for (int i = tid; i < LPK; i += 256) xd[i] = Xp[i];
     }
     if (!A.do_v || !s_ok) return;  // a failed factor leaves v as it is (core.py:112-113)
-    // ---- F3: v_t = |X g_t|^2.  X tiles (ib, kb <= ib) as A operands in registers, B operand G'[k][n] = G[t0 + n][k];
-    // D[row = kq + 4 q][n]: sum of squares over the rows ----
-    double xa[10][4];
+    // ---- F3: v_t = |X g_t|^2.  Rows < 48 of Z = X G': X tiles (ib, kb <= ib), ib < 3, as A operands in registers, B
+    // operand G'[k][n] = G[t0 + n][k], D[row = kq + 4 q][n]; rows 48, 49: dot products of the same B operands with the
+    // rows of X (LDS), reduced over the four k-lanes of a time bin ----
+    double xa[6][4];
 #pragma unroll
-    for (int pr = 0; pr < 10; ++pr) {
+    for (int pr = 0; pr < 6; ++pr) {
         int ib, kb;
         ltile_of(pr, ib, kb);
 #pragma unroll
         for (int sq = 0; sq < 4; ++sq) {
             const int i = 16 * ib + col, k = 16 * kb + 4 * sq + kq;
-            double val = (i == k) ? 1.0 : 0.0;
-            if (i < LRP) val = (k <= i) ? Xp[tri_row_off(i) + k] : 0.0;
-            xa[pr][sq] = val;
+            xa[pr][sq] = (k <= i) ? Xp[tri_row_off(i) + k] : 0.0;   // rows i >= r: the identity (planted above)
         }
     }
+    const double* x48 = Xp + tri_row_off(48);
+    const double* x49 = Xp + tri_row_off(49);
     const int ntb = (T + 15) / 16;
     for (int tb = wid; tb < ntb; tb += 4) {
         const int t = 16 * tb + col;
         const bool tin = t < T;
-        double4_t acc[4];
+        double4_t acc[3];
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib) acc[ib] = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int ib = 0; ib < 3; ++ib) acc[ib] = double4_t{0.0, 0.0, 0.0, 0.0};
+        double z0 = 0.0, z1 = 0.0;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            if (16 * kb >= r) continue;  // wave-uniform: those columns of G are zero
+        for (int kb = 0; kb < 3; ++kb) {
+            if (16 * kb >= rb) continue;  // wave-uniform: those columns of G are zero
 #pragma unroll
             for (int sq = 0; sq < 4; ++sq) {
                 const int k = 16 * kb + 4 * sq + kq;
-                const double gB = (tin && k < r) ? Gl[(int64_t)t * r + k] : 0.0;
+                const double gB = (tin && k < rb) ? Gl[(int64_t)t * r + k] : 0.0;
 #pragma unroll
-                for (int ib = kb; ib < 4; ++ib)
+                for (int ib = kb; ib < 3; ++ib)
                     acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(ib * (ib + 1)) / 2 + kb][sq], gB, acc[ib], 0, 0, 0);
+                if (ne > 0) {
+                    z0 = fma(x48[k], gB, z0);
+                    z1 = fma(x49[k], gB, z1);  // (row 49 of X is the unit row when r == 49: x49[k] = 0 for k < 49)
+                }
             }
         }
         double vv = 0.0;
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
+        for (int ib = 0; ib < 3; ++ib)
 #pragma unroll
             for (int q = 0; q < 4; ++q) vv = fma(acc[ib][q], acc[ib][q], vv);
         vv += __shfl_xor(vv, 16, 64);
         vv += __shfl_xor(vv, 32, 64);
+        if (ne > 0) {
+            // columns 48, 49 of G: two lanes of the four carry them (kq = 0, 1)
+            const int k = 48 + kq;
+            const double gT = (tin && kq < 2 && k < r) ? Gl[(int64_t)t * r + k] : 0.0;
+            z0 = fma(x48[kq < 1 ? 48 : 0], kq < 1 ? gT : 0.0, z0);
+            z1 = fma(x49[kq < 2 ? k : 0], kq < 2 ? gT : 0.0, z1);
+            z0 += __shfl_xor(z0, 16, 64);
+            z0 += __shfl_xor(z0, 32, 64);
+            z1 += __shfl_xor(z1, 16, 64);
+            z1 += __shfl_xor(z1, 32, 64);
+            vv = fma(z0, z0, vv);
+            if (ne > 1) vv = fma(z1, z1, vv);
+        }
         if (kq == 0 && tin) v_s[t] = vv;
     }
 }
