@@ -218,6 +218,32 @@ def test_sample_posterior_on_the_device(V):
         assert np.abs(draws[:, :, l].mean(0) - trial["mu"][:, l]).max() < 0.02
 
 
+def test_sample_posterior_more_latents_than_a_handle_and_legacy_rng(V):
+    """More than 16 latents go through the device in groups (the latents are independent), and a generator without
+    standard_normal (numpy.random.RandomState-like: normal(loc, scale, size)) draws (r, n) arrays, not shape-as-loc."""
+    rng = np.random.default_rng(5)
+    T, L, n = 30, 19, 16
+    omega = 10 ** rng.uniform(-3, -1.7, L)
+    chol = O.build_prior([T], omega, np.ones(L), 50)
+    trial = {"mu": rng.standard_normal((T, L)), "w": rng.random((T, L)) * 2.0}
+
+    class Legacy:  # only normal(loc, scale, size)
+        def __init__(self, seed):
+            self.g = np.random.default_rng(seed)
+
+        def normal(self, loc=0.0, scale=1.0, size=None):
+            return loc + scale * self.g.standard_normal(size)
+
+    got = V.sample_posterior(trial, {"cholesky": chol}, n, rng=Legacy(3))
+    g2 = np.random.default_rng(3)
+    eps = []
+    for l in range(L):
+        r = int(np.flatnonzero(np.any(chol[T][l] != 0, axis=0))[-1]) + 1
+        eps.append(g2.standard_normal((r, n)))
+    want = O.sample_posterior_lowrank(trial["mu"], trial["w"], chol[T], eps)
+    assert got.shape == (n, T, L) and relerr(got, want) < 1e-10
+
+
 def test_command_line_fit_and_result_file(V, tmp_path):
     """python -m vlgp_amd FIN FOUT N_FACTORS --max_iter --min_iter (vlgp/__main__.py:6-22): the saved result is
     the dict fit returns, loadable with util.load, and equals the in-process fit on the same input."""
