@@ -1123,8 +1123,9 @@ __device__ __forceinline__ void ltile_of(int tile, int& bi, int& bj) {  // lower
 // Rank 50 = 3 x 16 + 2: the matrix pipe sees the 48 x 48 part only (six 16 x 16 tiles of H: the time axis in two halves,
 // three tiles on each of the two waves of a half; six tiles of X in the variance), the rows 48, 49 of H and of Z = X G'
 // are dot products on the vector pipe -- padded to 64 they were four tiles of ten in both phases, 87 % zeros (measured:
-// 320 -> 300 us per launch at C3: 40 % fewer matrix instructions buy 6 %, the launch is bound by its 1.6 GB of 8-byte
-// loads of G from L2 -- every task re-reads the factor its 199 neighbours of the same latent read).  (Measured alternatives at C3, 1000 tasks: the three phases as three launches with
+// 320 -> 300 us per launch at C3: 40 % fewer matrix instructions buy 6 %; sharing the staged tiles of G between four
+// tasks of a workgroup -- a quarter of the L2 traffic -- was slower: what bounds the launch is the latency of a wave's
+// load -> multiply chain at two waves per SIMD, the register budget of the wave that factors).  (Measured alternatives at C3, 1000 tasks: the three phases as three launches with
 // the matrix through global memory -- lighter waves for the build and the variance -- 180 + 34 + 155 us against 320 us
 // for one kernel; the build's loads software-pipelined one step ahead of its matrix instructions: no change.)
 __global__ void __launch_bounds__(256, 2) elong_factor(SplitArgs A) {
