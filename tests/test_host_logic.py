@@ -112,6 +112,30 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_weighted_shards_balance_rows_of_ragged_trials():
+    """Ragged trials (BASELINE configs[4]) are cut into contiguous blocks of about equal ROWS, identically on every
+    rank; equal-length trials keep the equal-count split."""
+    from vlgp_amd.dist import shard, shard_bounds, shard_bounds_weighted
+
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n, world = int(rng.integers(1, 60)), int(rng.integers(1, 9))
+        w = (50 * rng.integers(10, 41, n)).tolist()
+        cuts = [shard_bounds_weighted(w, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        if n >= world:
+            assert all(hi > lo for lo, hi in cuts)
+    w = (50 * np.random.default_rng(0).integers(10, 41, 500)).tolist()
+    for world in (2, 4, 8):
+        rows = [sum(w[lo:hi]) for lo, hi in (shard_bounds_weighted(w, r, world) for r in range(world))]
+        assert max(rows) <= 1.02 * sum(w) / world
+    trials = [{"y": np.zeros((t, 2))} for t in (100, 100, 100, 100, 400, 400)]
+    assert [len(shard(trials, r, 2)) for r in range(2)] == [5, 1]          # 800 | 400 rows, not 3 | 3 trials (300 | 900)
+    same = [{"y": np.zeros((50, 2))} for _ in range(7)]
+    assert [len(shard(same, r, 3)) for r in range(3)] == [hi - lo for lo, hi in (shard_bounds(7, r, 3) for r in range(3))]
+
+
 def test_mstep_sufficient_statistics_form_equals_mstep(golden):
     for tag in ("p1", "p3", "mixed"):
         g = golden("mstep_" + tag)

@@ -26,8 +26,42 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_bounds_weighted(weights, rank, world):
+    """Contiguous block [lo, hi) for ``rank`` such that the blocks' total weights are as even as a contiguous cut
+    allows: cut k sits where the running sum first reaches k / world of the total (ragged trials: weight = bins, so
+    that every GPU holds about the same number of rows; BASELINE configs[4]).  Every rank computes the same cuts; a
+    block is never empty while there are at least ``world`` items."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    n = len(weights)
+    if n < world:
+        return shard_bounds(n, rank, world)
+    total = float(sum(weights))
+    cuts, run = [0], 0.0
+    for i, w in enumerate(weights):
+        run += float(w)
+        while len(cuts) < world and run >= total * len(cuts) / world:
+            cuts.append(i + 1)
+    while len(cuts) < world:
+        cuts.append(n)
+    cuts.append(n)
+    for k in range(1, world):                 # no empty block: at least one item each, front to back ...
+        cuts[k] = max(cuts[k], cuts[k - 1] + 1)
+    for k in range(world - 1, 0, -1):         # ... and enough items left for the blocks behind
+        cuts[k] = min(cuts[k], n - (world - k))
+    return cuts[rank], cuts[rank + 1]
+
+
 def shard(items, rank, world):
-    lo, hi = shard_bounds(len(items), rank, world)
+    """Block of ``items`` for ``rank``: equal counts, or -- for trial dicts of unequal length -- about equal rows."""
+    try:
+        lengths = [int(it["y"].shape[0]) for it in items]
+    except (TypeError, KeyError, IndexError, AttributeError):
+        lengths = None
+    if lengths and len(set(lengths)) > 1:
+        lo, hi = shard_bounds_weighted(lengths, rank, world)
+    else:
+        lo, hi = shard_bounds(len(items), rank, world)
     return items[lo:hi]
 
 
