@@ -604,7 +604,7 @@ def test_reference_smoke_test_fit_then_transform(V):
 
 
 # ------------------------------------------------------------------ headline-size properties
-def test_headline_size_properties(V):
+def test_headline_size_properties(V, monkeypatch):
     """C3 dims (4000 segments x 50 bins x 100 channels x 5 latents): properties
     that hold at any size -- E-step sweeps compose (25 = 10 + 15, bit for bit,
     since mu, v, w carry the whole state), units are independent (a permuted
@@ -640,6 +640,12 @@ def test_headline_size_properties(V):
     two, _ = run(ident, [10, 15])
     for k in ("mu", "v", "w"):
         assert np.array_equal(one[k], two[k]), k
+    # the two lanes (streams) the unit set runs on by default change nothing: one lane, bit for bit
+    monkeypatch.setenv("VLGP_ESTEP_LANES", "1")
+    lane1, _ = run(ident, [25])
+    monkeypatch.delenv("VLGP_ESTEP_LANES")
+    for k in ("mu", "v", "w", "dmu"):
+        assert np.array_equal(one[k], lane1[k]), k
     perm = np.random.default_rng(2).permutation(4000)
     shuf, _ = run(perm, [25])
     for k in ("mu", "v", "w", "dmu"):

@@ -1772,7 +1772,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     // parts (two by default, VLGP_ESTEP_LANES = 1 .. 4) whose sweeps are enqueued on their own streams, so that one half's latency-bound stretches sit under the other
     // half's issue-bound passes.  No dependency crosses the halves between the fork and the join; results are
     // bit-identical to the single lane (same arithmetic per unit).  VLGP_ESTEP_LANES=1 keeps one lane.
-    static const int lanes_env = getenv("VLGP_ESTEP_LANES") ? atoi(getenv("VLGP_ESTEP_LANES")) : 0;
+    const int lanes_env = getenv("VLGP_ESTEP_LANES") ? atoi(getenv("VLGP_ESTEP_LANES")) : 0;  // (per call: tests toggle it)
     int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 6 * ctx->n_cu && n_it >= 2 ? 2 : 1);  // 2000 units: 2.11 -> 1.77 ms, 1000 units: no change
     while (n_lanes > 1 && us.M < 8 * n_lanes) --n_lanes;
     for (int h = 1; h < n_lanes; ++h) {
