@@ -254,6 +254,14 @@ int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const do
 #define VLGP_PATH_ESTEP_GENERIC 4  /* generic kernels (rank > 50 slots, L > 10, ...) */
 #define VLGP_PATH_ESTEP_LSPLIT 5   /* long units as chip-wide launches: one workgroup per (unit, latent) task */
 int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
+/* Same for the most recent vlgp_hstep_objective call: which kernel family evaluated the per-segment terms. */
+#define VLGP_PATH_HSTEP_NONE 0
+#define VLGP_PATH_HSTEP_LOWRANK 1  /* exact low-rank (Woodbury) round, sixteen segments per workgroup (hstep_lr.h) */
+#define VLGP_PATH_HSTEP_DENSE 2    /* one wave per segment, blocked elimination on the matrix pipe (hstep_mfma.h) */
+#define VLGP_PATH_HSTEP_BIG 3      /* windows 65 ... 128: one workgroup per segment */
+#define VLGP_PATH_HSTEP_GENERIC 4  /* generic kernels (any window; the reference's omega retry) */
+#define VLGP_PATH_HSTEP_OLD 5      /* round-1 kernels behind their debug switches */
+int vlgp_debug_last_hstep_path(vlgp_ctx* ctx, int* path);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ PROF_ESTEP, PROF_MSTEP, PROF_HSTEP, PROF_PRIOR = 0, 1, 2, 3
 PROF_ESTEP_RA16, PROF_ESTEP_RA24, PROF_ESTEP_RA32, PROF_ESTEP_LONG, PROF_ESTEP_GENERIC = 4, 5, 6, 7, 8
 PROF_ESTEP_PASS, PROF_ESTEP_FACTOR, PROF_ESTEP_MEAN = 9, 10, 11  # split E-step, sampled launches
 ESTEP_PATHS = ("none", "split", "fast", "long", "generic", "long_split")  # VLGP_PATH_ESTEP_*
+HSTEP_PATHS = ("none", "lowrank", "dense", "big", "generic", "old")  # VLGP_PATH_HSTEP_*
 
 _lib = None
 
@@ -84,6 +85,7 @@ _SIGNATURES = {
     "vlgp_debug_phase_clock": (C.c_int, [_h, C.c_int, C.POINTER(C.c_uint64)]),
     "vlgp_debug_npx": (C.c_int, [_h, C.c_int, C.c_int64, _dp, _dp, _dp]),
     "vlgp_debug_last_estep_path": (C.c_int, [_h, _ip]),
+    "vlgp_debug_last_hstep_path": (C.c_int, [_h, _ip]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

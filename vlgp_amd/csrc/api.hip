@@ -1175,6 +1175,13 @@ extern "C" int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path) {
     return VLGP_OK;
 }
 
+extern "C" int vlgp_debug_last_hstep_path(vlgp_ctx* ctx, int* path) {
+    NEED_CTX(ctx);
+    if (!path) return vlgp_fail(ctx, VLGP_ERR_ARG, "null path");
+    *path = ctx->last_hstep_path;
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const double* b, double* out) {
     NEED_CTX(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));

@@ -109,6 +109,10 @@ struct vlgp_ctx {
     const UnitSet* hmom_us = nullptr;
     int hmom_T = 0;
     bool hmom_bracket = false;    // inside vlgp_hstep_begin/end: d_hmom stays valid across objective calls
+    // low-rank H-step round (hstep_lr.h): per (window, dt, tol) the largest omega whose folded kernel blocks have rank <= r
+    struct LrThr { int T; double dt, tol; std::vector<double> om; };
+    std::vector<LrThr> lr_thr;
+    int last_hstep_path = 0;      // VLGP_PATH_HSTEP_* of the most recent H-step objective call
 
     // profiling
     bool prof_on = false;

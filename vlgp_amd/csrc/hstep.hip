@@ -18,6 +18,7 @@
 #include "ctx.h"
 #include "wave_tri.h"
 #include "hstep_mfma.h"
+#include "hstep_lr.h"
 
 #define HS_MAXT 128  // generic kernels: rows are lane-strided, one T x T matrix per wave in LDS
 
@@ -1066,6 +1067,10 @@ struct HRoundArgs {
     double* qsum;          // (n_eval, 2): tr(K^-1 C), tr(K^-1 dK K^-1 C)
     double* red;           // device: (ll, dll) x n_eval, then ok x n_eval
     double* host;          // mapped pinned copy of `red` + sequence word at [48], or null
+    // low-rank round (hstep_round_lr): tables written by hstep_lr_tables; null in the dense rounds
+    const double* lr_tab;
+    const LrMeta* lr_meta;
+    const unsigned short* lr_pairs;
 };
 
 template <int T>
@@ -1406,17 +1411,170 @@ __global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
     }
 }
 
+// K block of a round (shared by the dense and the low-rank round kernels): wave 0 takes K -> K^-1 and log det through
+// the blocked elimination of hstep_mfma.h (KMODE); then every wave takes block rows of the two products against the
+// second moments of this latent.  `lds`: TASKW + T * LDK doubles, `kvs`: the SHR doubles of shared tables (one-set layout).
+template <int T, int NW, bool ONESET>
+struct HRoundK {
+    using G = HmGeom<T>;
+    static constexpr int LDK = T | 2;                  // row stride of K^-1 in LDS: 2 mod 4 -> conflict-free operand reads
+    static constexpr int TASKW = ONESET ? HmGeom50::TASK : G::TASK;           // per-wave task buffer
+    static constexpr int SHR = ONESET ? HmGeom50::SHARED : 0;                // per-workgroup tables (one-set layout)
+    static constexpr int KBLK = TASKW + T * LDK + SHR;  // wave 0's task buffer | K^-1 (| tables)
+};
+
+template <int T, int NW, bool ONESET>
+__device__ __forceinline__ void hstep_round_kblock(const HRoundArgs& R, int e, double* lds, double* kvs, double (*part)[2],
+                                                   int lane, int wid) {
+    using G = HmGeom<T>;
+    using KG = HRoundK<T, NW, ONESET>;
+    constexpr int LDK = KG::LDK, TASKW = KG::TASKW;
+    const HFastArgs& A = R.F;
+    double* buf = lds;
+    double* Kl = lds + TASKW;
+    double* dks = kvs + HmGeom50::KVN;
+    // the operands of C for this wave's block row of the products: in flight while wave 0 factors
+    double preC[(T + 3) / 4];
+    constexpr bool PRE = NW >= (T + 15) / 16;
+    // (wave 0 fetches after its factorisation: thirteen values held across it cost 40 spilled registers)
+    if constexpr (PRE) {
+        if (wid != 0) hstep_kblock_fetch<T>(R.mom + (int64_t)A.latent[e] * T * T, lane, wid, preC);
+    }
+    if (wid == 0) {
+        const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
+        if constexpr (ONESET) {
+            const double d = lane * A.dt, d2 = d * d;
+            const double kk = sigmasq * exp(-omega * d2);
+            if (lane < HmGeom50::SVN) buf[HmGeom50::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
+            if (lane < T) kvs[17 + lane] = kk + (lane == 0 ? eps : 0.0);
+            if (lane >= 1 && lane <= 17) kvs[17 - lane] = kk;
+            if (lane < HmGeom50::DKN) dks[lane] = -kk * d2 * omega;
+        } else {
+            const double d = lane * A.dt, d2 = d * d;
+            const double kk = sigmasq * exp(-omega * d2);
+            buf[G::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
+            buf[G::O_KVM + 63 + lane] = kk + (lane == 0 ? eps : 0.0);
+            buf[G::O_KVM + 63 - lane] = kk + (lane == 0 ? eps : 0.0);
+            buf[G::O_DKV + lane] = -kk * d2 * omega;
+            if (lane < 32) buf[G::O_Z + lane] = 0.0;
+        }
+        tri_wave_sync();
+        double logdet, unused;
+        if constexpr (ONESET) hstep_task_mfma50<true>(buf, kvs, dks, eps, lane, logdet, unused, A.Tr, Kl, LDK);
+        else hstep_task_mfma<T, true>(buf, eps, lane, logdet, unused, A.Tr, Kl, LDK);
+        if (lane == 0) {
+            A.scal[4 * e + 0] = logdet;
+            A.scal[4 * e + 1] = 0.0;
+            A.scal[4 * e + 2] = omega;
+            A.scal[4 * e + 3] = (logdet == logdet && fabs(logdet) < 1e300) ? 1.0 : 0.0;  // a bad pivot -> NaN / inf
+        }
+        if constexpr (PRE) hstep_kblock_fetch<T>(R.mom + (int64_t)A.latent[e] * T * T, lane, 0, preC);
+    }
+    __syncthreads();
+    double quad, gq;
+    hstep_kblock_products<T>(Kl, LDK, R.mom + (int64_t)A.latent[e] * T * T, ONESET ? dks : buf + G::O_DKV, A.Tr, lane,
+                             wid, NW, quad, gq, PRE ? &preC : nullptr);
+    for (int o = 32; o > 0; o >>= 1) {
+        quad += __shfl_xor(quad, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+    }
+    if (lane == 0) {
+        part[wid][0] = quad;
+        part[wid][1] = gq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double q0 = part[0][0], q1 = part[0][1];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            q0 += part[w][0];
+            q1 += part[w][1];
+        }
+        R.qsum[2 * e + 0] = q0;
+        R.qsum[2 * e + 1] = q1;
+    }
+}
+
+// Completion of a round: one partial per segment block (part[w] summed over the NW waves), then the block that draws
+// the last ticket adds the partials of every evaluation in a fixed order and publishes (ll, dll, flag).  `rs`: 2 x 64 NW
+// doubles of LDS.  flag: 1 = fine, 0 = K did not factor, 2 = the low-rank tables overflowed (R.lr_meta)
+template <int NW>
+__device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* rs, double (*part)[2], int* s_last) {
+    const HFastArgs& A = R.F;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if ((int)blockIdx.x >= R.n_eval) {
+            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
+            double t0 = part[0][0], t1 = part[0][1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                t0 += part[w][0];
+                t1 += part[w][1];
+            }
+            o[0] = t0;
+            o[1] = t1;
+        }
+        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    constexpr int NT = 64 * NW;
+    for (int e = 0; e < R.n_eval; ++e) {
+        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int m = threadIdx.x; m < R.nb; m += NT) {
+            const double2 v = in[m];
+            s0 += v.x;
+            s1 += v.y;
+        }
+        __syncthreads();
+        rs[threadIdx.x] = s0;
+        rs[NT + threadIdx.x] = s1;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                rs[threadIdx.x] += rs[threadIdx.x + o];
+                rs[NT + threadIdx.x] += rs[NT + threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            double okf = A.scal[4 * e + 3];
+            if (R.lr_meta != nullptr && R.lr_meta[e].overflow) okf = okf != 0.0 ? 2.0 : 0.0;
+            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
+            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[NT]);
+            R.red[2 * e + 0] = ll;
+            R.red[2 * e + 1] = dll;
+            R.red[2 * R.n_eval + e] = okf;
+            if (R.host) {
+                R.host[2 * e + 0] = ll;
+                R.host[2 * e + 1] = dll;
+                R.host[2 * R.n_eval + e] = okf;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        R.sync[16] = 0;  // next launch is stream-ordered after this one
+        if (R.host) {
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // The round on the matrix pipe (hstep_mfma.h): one wave per segment, NW waves per block.  Blocks [0, n_eval) are
 // the K blocks as in hstep_round_lean (all NW waves share the trace phase).
 // ONESET (T = 50 only): the one-register-set task routine hstep_task_mfma50 (buffer row = lane); else the two-set routine.
 template <int T, int NW, bool ONESET = false>
 __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3) : 2) : 1) hstep_round_mfma(HRoundArgs R) {
-    static_assert(!ONESET || T == 50, "the one-set routine is written for 50 = 3 x 16 + 2");
+    static_assert(!ONESET || T == 50, "the one-register-set routine is written for 50 = 3 x 16 + 2");
     using G = HmGeom<T>;
-    constexpr int LDK = T | 2;                  // row stride of K^-1 in LDS: 2 mod 4 -> conflict-free operand reads
-    constexpr int TASKW = ONESET ? HmGeom50::TASK : G::TASK;           // per-wave task buffer
-    constexpr int SHR = ONESET ? HmGeom50::SHARED : 0;                // per-workgroup tables (one-set layout)
-    constexpr int KBLK = TASKW + T * LDK + SHR;  // wave 0's task buffer | K^-1 (| tables)
+    using KG = HRoundK<T, NW, ONESET>;
+    constexpr int TASKW = KG::TASKW, SHR = KG::SHR, KBLK = KG::KBLK;
     constexpr int LDSN = NW * TASKW + SHR > KBLK ? NW * TASKW + SHR : KBLK;
     static_assert(!ONESET || LDSN * 8 + 128 <= 40960, "four workgroups per CU");
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
@@ -1425,73 +1583,7 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
     const HFastArgs& A = R.F;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if ((int)blockIdx.x < R.n_eval) {
-        // K block.  Wave 0: K -> K^-1 and log det through the same blocked elimination as the segments (KMODE);
-        // then every wave takes block rows of the two products against the second moments of this latent.
-        const int e = blockIdx.x;
-        double* buf = lds;
-        double* Kl = lds + TASKW;
-        double* kvs = lds + LDSN - SHR;               // one-set layout: shared tables at the end of the block's LDS
-        double* dks = kvs + HmGeom50::KVN;
-        // the operands of C for this wave's block row of the products: in flight while wave 0 factors
-        double preC[(T + 3) / 4];
-        constexpr bool PRE = NW >= (T + 15) / 16;
-        // (wave 0 fetches after its factorisation: thirteen values held across it cost 40 spilled registers)
-        if constexpr (PRE) {
-            if (wid != 0) hstep_kblock_fetch<T>(R.mom + (int64_t)A.latent[e] * T * T, lane, wid, preC);
-        }
-        if (wid == 0) {
-            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
-            if constexpr (ONESET) {
-                const double d = lane * A.dt, d2 = d * d;
-                const double kk = sigmasq * exp(-omega * d2);
-                if (lane < HmGeom50::SVN) buf[HmGeom50::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
-                if (lane < T) kvs[17 + lane] = kk + (lane == 0 ? eps : 0.0);
-                if (lane >= 1 && lane <= 17) kvs[17 - lane] = kk;
-                if (lane < HmGeom50::DKN) dks[lane] = -kk * d2 * omega;
-            } else {
-                const double d = lane * A.dt, d2 = d * d;
-                const double kk = sigmasq * exp(-omega * d2);
-                buf[G::O_SV + lane] = lane < A.Tr ? 1.0 : 0.0;  // rows >= Tr: identity padding
-                buf[G::O_KVM + 63 + lane] = kk + (lane == 0 ? eps : 0.0);
-                buf[G::O_KVM + 63 - lane] = kk + (lane == 0 ? eps : 0.0);
-                buf[G::O_DKV + lane] = -kk * d2 * omega;
-                if (lane < 32) buf[G::O_Z + lane] = 0.0;
-            }
-            tri_wave_sync();
-            double logdet, unused;
-            if constexpr (ONESET) hstep_task_mfma50<true>(buf, kvs, dks, eps, lane, logdet, unused, A.Tr, Kl, LDK);
-            else hstep_task_mfma<T, true>(buf, eps, lane, logdet, unused, A.Tr, Kl, LDK);
-            if (lane == 0) {
-                A.scal[4 * e + 0] = logdet;
-                A.scal[4 * e + 1] = 0.0;
-                A.scal[4 * e + 2] = omega;
-                A.scal[4 * e + 3] = (logdet == logdet && fabs(logdet) < 1e300) ? 1.0 : 0.0;  // a bad pivot -> NaN / inf
-            }
-            if constexpr (PRE) hstep_kblock_fetch<T>(R.mom + (int64_t)A.latent[e] * T * T, lane, 0, preC);
-        }
-        __syncthreads();
-        double quad, gq;
-        hstep_kblock_products<T>(Kl, LDK, R.mom + (int64_t)A.latent[e] * T * T, ONESET ? dks : buf + G::O_DKV, A.Tr, lane,
-                                 wid, NW, quad, gq, PRE ? &preC : nullptr);
-        for (int o = 32; o > 0; o >>= 1) {
-            quad += __shfl_xor(quad, o, 64);
-            gq += __shfl_xor(gq, o, 64);
-        }
-        if (lane == 0) {
-            part[wid][0] = quad;
-            part[wid][1] = gq;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double q0 = part[0][0], q1 = part[0][1];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                q0 += part[w][0];
-                q1 += part[w][1];
-            }
-            R.qsum[2 * e + 0] = q0;
-            R.qsum[2 * e + 1] = q1;
-        }
+        hstep_round_kblock<T, NW, ONESET>(R, blockIdx.x, lds, lds + LDSN - SHR, part, lane, wid);
     } else {
         const int b = blockIdx.x - R.n_eval;
         const int e = b / R.nb, bx = b - e * R.nb;
@@ -1538,70 +1630,37 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
             part[wid][1] = cs;
         }
     }
-    // ---- completion: one partial per block, then the last block reduces and publishes ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if ((int)blockIdx.x >= R.n_eval) {
-            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
-            double t0 = part[0][0], t1 = part[0][1];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                t0 += part[w][0];
-                t1 += part[w][1];
-            }
-            o[0] = t0;
-            o[1] = t1;
-        }
-        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    constexpr int NT = 64 * NW;
-    double* rs = lds;  // 2 x NT partials
-    for (int e = 0; e < R.n_eval; ++e) {
-        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int m = threadIdx.x; m < R.nb; m += NT) {
-            const double2 v = in[m];
-            s0 += v.x;
-            s1 += v.y;
-        }
-        __syncthreads();
-        rs[threadIdx.x] = s0;
-        rs[NT + threadIdx.x] = s1;
-        __syncthreads();
-        for (int o = NT / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                rs[threadIdx.x] += rs[threadIdx.x + o];
-                rs[NT + threadIdx.x] += rs[NT + threadIdx.x + o];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const double okf = A.scal[4 * e + 3];
-            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
-            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[NT]);
-            R.red[2 * e + 0] = ll;
-            R.red[2 * e + 1] = dll;
-            R.red[2 * R.n_eval + e] = okf;
-            if (R.host) {
-                R.host[2 * e + 0] = ll;
-                R.host[2 * e + 1] = dll;
-                R.host[2 * R.n_eval + e] = okf;
-            }
+    hstep_round_finish<NW>(R, lds, part, &s_last);
+}
+
+// The round in the low-rank form (hstep_lr.h): blocks [0, n_eval) are the K blocks as above, every other block takes
+// sixteen segments of one evaluation.  The tables of the evaluations come from hstep_lr_tables, launched in front.
+// T: compiled window of the K block (50: windows <= 50, 64: <= 64); RC: register class of the ranks in this round.
+template <int T, int NW, int RC>
+__global__ void __launch_bounds__(64 * NW, RC <= 16 ? 4 : (RC <= 24 ? 3 : 2)) hstep_round_lr(HRoundArgs R) {
+    constexpr bool ONESET = T == 50;
+    constexpr int NK = T == 50 ? 7 : 8;
+    using KG = HRoundK<T, NW, ONESET>;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    __shared__ double part[NW][2];
+    __shared__ int s_last;
+    const HFastArgs& A = R.F;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if ((int)blockIdx.x < R.n_eval) {
+        hstep_round_kblock<T, NW, ONESET>(R, blockIdx.x, lds_dyn, lds_dyn + KG::KBLK - KG::SHR, part, lane, wid);
+    } else {
+        const int b = blockIdx.x - R.n_eval;
+        const int e = b / R.nb, bx = b - e * R.nb;
+        double tr = 0.0, cs = 0.0;
+        const double eps = exp(A.logp[3 * e + 2]);
+        lr_group<RC, NK, NW>(R.lr_tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP, R.lr_meta[e], R.lr_pairs + (int64_t)e * LR_NPAIR,
+                             A.w, A.off, A.L, A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs);
+        if (lane == 0) {
+            part[wid][0] = wid == 0 ? tr : 0.0;
+            part[wid][1] = wid == 0 ? cs : 0.0;
         }
     }
-    if (threadIdx.x == 0) {
-        R.sync[16] = 0;  // next launch is stream-ordered after this one
-        if (R.host) {
-            __threadfence_system();
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    hstep_round_finish<NW>(R, lds_dyn, part, &s_last);
 }
 
 template <int T>
@@ -1615,8 +1674,96 @@ static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
     return VLGP_OK;
 }
 
+// ---- low-rank round: host side ------------------------------------------------------------------------------
+// Rank of the folded even / odd blocks of exp(-omega D^2) under the pivoted Cholesky of hstep_lr_tables (same pivot
+// rule, no tangent), used to predict the LDS a round needs; > LR_RCAP when a block exceeds the kernel's capacity.
+static int lr_host_rank(int T, double dt, double omega, double tol) {
+    const int h = T / 2, nt = (T + 1) / 2;
+    const bool odd = (T & 1) != 0;
+    std::vector<double> kv(T);
+    for (int d = 0; d < T; ++d) kv[d] = exp(-omega * (d * dt) * (d * dt));
+    const double RS2 = 0.70710678118654752440;
+    int total = 0;
+    for (int par = 0; par < 2; ++par) {
+        const int n = par == 0 ? nt : h;
+        auto kent = [&](int t, int p) {
+            const int d1 = t > p ? t - p : p - t, d2 = T - 1 - t - p;
+            if (par == 0) {
+                const double s = ((odd && t == h) ? RS2 : 1.0) * ((odd && p == h) ? RS2 : 1.0);
+                return s * (kv[d1] + kv[d2]);
+            }
+            return kv[d1] - kv[d2];
+        };
+        std::vector<double> G((size_t)n * (n > 0 ? n : 1), 0.0), d(n);
+        for (int t = 0; t < n; ++t) d[t] = kent(t, t);
+        int r = 0;
+        for (; r < n; ++r) {
+            int p = -1;
+            double bv = -1.0;
+            for (int t = 0; t < n; ++t)
+                if (d[t] > bv) { bv = d[t]; p = t; }
+            if (!(bv > tol)) break;
+            const double ginv = 1.0 / sqrt(bv);
+            for (int t = 0; t < n; ++t) {
+                double col = kent(t, p);
+                for (int j = 0; j < r; ++j) col -= G[(size_t)t * n + j] * G[(size_t)p * n + j];
+                const double gk = col * ginv;
+                G[(size_t)t * n + r] = gk;
+                if (d[t] >= 0.0) d[t] -= gk * gk;
+            }
+            d[p] = -1.0;
+        }
+        if (r > LR_RH) return LR_RCAP + 1;
+        total += r;
+    }
+    return total;
+}
+
+// largest omega whose predicted rank is <= r, r = 0 .. LR_RCAP (the rank grows with omega)
+static const std::vector<double>& lr_thresholds(vlgp_ctx* ctx, int T, double dt, double tol) {
+    for (auto& t : ctx->lr_thr)
+        if (t.T == T && t.dt == dt && t.tol == tol) return t.om;
+    vlgp_ctx::LrThr t;
+    t.T = T; t.dt = dt; t.tol = tol;
+    t.om.assign(LR_RCAP + 1, 0.0);
+    const double lo0 = log(1e-14), hi0 = log(1e8);
+    for (int r = 0; r <= LR_RCAP; ++r) {
+        double lo = r > 0 && t.om[r - 1] > 0.0 ? log(t.om[r - 1]) : lo0, hi = hi0;
+        if (lr_host_rank(T, dt, exp(lo), tol) > r) { t.om[r] = 0.0; continue; }
+        for (int it = 0; it < 48; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (lr_host_rank(T, dt, exp(mid), tol) <= r) lo = mid;
+            else hi = mid;
+        }
+        t.om[r] = exp(lo);
+    }
+    ctx->lr_thr.push_back(t);
+    return ctx->lr_thr.back().om;
+}
+
+template <int T, int RC>
+static int launch_round_lr(vlgp_ctx* ctx, const HRoundArgs& R, int grid, size_t lds_bytes) {
+    constexpr int NW = 4;
+    static size_t attr_set = 0;
+    if (lds_bytes > attr_set) {
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512)));
+        attr_set = 160 * 1024;
+    }
+    hipLaunchKernelGGL((hstep_round_lr<T, NW, RC>), dim3(grid), dim3(64 * NW), lds_bytes, ctx->stream, R);
+    return VLGP_OK;
+}
+
+static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
+                             const double* logp, double* ll, double* dll, bool force_dense);
+
 int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
                  const double* logp, double* ll, double* dll) {
+    return launch_hstep_impl(ctx, us, window, dt, n_eval, latent, logp, ll, dll, false);
+}
+
+static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
+                             const double* logp, double* ll, double* dll, bool force_dense) {
     const int T = window, L = ctx->L, M = us.M;
     if (T > HS_MAXT) return vlgp_fail(ctx, VLGP_ERR_ARG, "H-step kernel supports window <= %d, got %d", HS_MAXT, T);
     if (us.Tmin != T || us.Tmax != T)
@@ -1633,7 +1780,11 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
     const int64_t o_lat = o_logp + 3 * n_eval, o_qsum = o_lat + n_eval + 8, o_mpart = o_qsum + 2 * n_eval + 2;
     const int64_t o_tm = o_mpart + (fast ? (int64_t)L * 64 * TT : 0);
-    const int64_t total = o_tm + (T > 64 ? n_eval * TT : 0);
+    // low-rank round: tables | meta | pair codes (doubles; each region 16-byte aligned)
+    const int64_t o_lrtab = (o_tm + (T > 64 ? n_eval * TT : 0) + 1) & ~1LL;
+    const int64_t o_lrmeta = o_lrtab + (fast ? (int64_t)n_eval * 2 * LR_TROWS * LR_RCAP : 0);
+    const int64_t o_lrpairs = o_lrmeta + (fast ? (int64_t)n_eval * 4 : 0);
+    const int64_t total = o_lrpairs + (fast ? ((int64_t)n_eval * LR_NPAIR * 2 + 7) / 8 : 0);
     CHK(vlgp_ensure_work(ctx, total));
     CHK(vlgp_ensure_pinned(ctx, 12 * n_eval + 32));
     double* W = ctx->d_work;
@@ -1696,9 +1847,41 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
             const bool lean = getenv("VLGP_HSTEP_LEAN") != nullptr;                 // register-row kernel (round 1)
             const bool mfma = !padded && !lean;
             const bool twoset = getenv("VLGP_HSTEP_TWOSET") != nullptr;  // two-register-set task routine at window <= 50
-            R.n_eval = n_eval; R.nb = mfma ? (M + MFMA_NW - 1) / MFMA_NW : (M + 3) / 4; R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
+            // the exact low-rank round (hstep_lr.h) when every evaluation's kernel matrix has numerical rank <= LR_RCAP
+            // (omega below about 2e-2 on a 50-bin window); VLGP_HSTEP_DENSE=1 keeps the dense matrix-pipe round
+            const bool lr_off = getenv("VLGP_HSTEP_DENSE") != nullptr;  // read per call: the tests switch it
+            const double lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-13;
+            bool lr = mfma && !twoset && !lr_off && !force_dense;
+            int rcap[16], rmax = 0;
+            if (lr) {
+                const std::vector<double>& om = lr_thresholds(ctx, T, dt, 0.5 * lr_tol);
+                for (int e = 0; e < n_eval && lr; ++e) {
+                    const double omega = exp(logp[3 * e + 1]);
+                    int r = 0;
+                    while (r <= LR_RCAP && !(omega <= om[r])) ++r;
+                    if (r > LR_RCAP) lr = false;
+                    rcap[e] = r < 4 ? 4 : r;
+                    if (rcap[e] > rmax) rmax = rcap[e];
+                }
+            }
+            R.n_eval = n_eval; R.nb = lr ? (M + 15) / 16 : (mfma ? (M + MFMA_NW - 1) / MFMA_NW : (M + 3) / 4);
+            R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
+            R.lr_tab = nullptr; R.lr_meta = nullptr; R.lr_pairs = nullptr;
+            if (lr) {
+                HLrTabArgs TA;
+                TA.n_eval = n_eval; TA.T = T; TA.dt = dt; TA.tol = lr_tol;
+                for (int i = 0; i < 3 * n_eval; ++i) TA.logp[i] = logp[i];
+                for (int e = 0; e < n_eval; ++e) TA.rcap[e] = rcap[e];
+                TA.tab = W + o_lrtab;
+                TA.meta = reinterpret_cast<LrMeta*>(W + o_lrmeta);
+                TA.pairs = reinterpret_cast<unsigned short*>(W + o_lrpairs);
+                hipLaunchKernelGGL(hstep_lr_tables, dim3(n_eval), dim3(128), 0, ctx->stream, TA);
+                HIPCHK(ctx, hipGetLastError());
+                R.lr_tab = TA.tab; R.lr_meta = TA.meta; R.lr_pairs = TA.pairs;
+            }
+            ctx->last_hstep_path = lr ? VLGP_PATH_HSTEP_LOWRANK : (mfma ? VLGP_PATH_HSTEP_DENSE : VLGP_PATH_HSTEP_OLD);
             // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
             // their sums on the host (vlgp_hx_allreduce); without the exchange segment the sums go through the
             // device all-reduce and a copy instead
@@ -1709,7 +1892,25 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else if (lean)
                 hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
-            else if (TC == 50 && twoset)
+            else if (lr) {
+                constexpr int NW = 4;
+                const int NK = TC == 50 ? 7 : 8;
+                const int kblk = TC == 50 ? HRoundK<50, NW, true>::KBLK : HRoundK<64, NW, false>::KBLK;
+                int need = lr_geom(rmax, 4 * NK, NW).total;
+                if (need < kblk) need = kblk;
+                if (need < 2 * 64 * NW) need = 2 * 64 * NW;
+                const size_t lds_bytes = (size_t)need * 8;
+                const int grid = n_eval + n_eval * R.nb;
+                if (TC == 50) {
+                    if (rmax <= 16) CHK((launch_round_lr<50, 16>(ctx, R, grid, lds_bytes)));
+                    else if (rmax <= 24) CHK((launch_round_lr<50, 24>(ctx, R, grid, lds_bytes)));
+                    else CHK((launch_round_lr<50, 32>(ctx, R, grid, lds_bytes)));
+                } else {
+                    if (rmax <= 16) CHK((launch_round_lr<64, 16>(ctx, R, grid, lds_bytes)));
+                    else if (rmax <= 24) CHK((launch_round_lr<64, 24>(ctx, R, grid, lds_bytes)));
+                    else CHK((launch_round_lr<64, 32>(ctx, R, grid, lds_bytes)));
+                }
+            } else if (TC == 50 && twoset)
                 hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
                                    ctx->stream, R);
             else if (TC == 50)
@@ -1740,8 +1941,13 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             }
         }
-        bool all_ok = true;
-        for (int e = 0; e < n_eval; ++e) all_ok = all_ok && hres[2 * n_eval + e] != 0.0;
+        bool all_ok = true, lr_over = false;
+        for (int e = 0; e < n_eval; ++e) {
+            all_ok = all_ok && hres[2 * n_eval + e] != 0.0;
+            lr_over = lr_over || hres[2 * n_eval + e] == 2.0;
+        }
+        // a rank beyond the host's prediction (never seen; the prediction runs at half the tolerance): dense round
+        if (all_ok && lr_over) return launch_hstep_impl(ctx, us, window, dt, n_eval, latent, logp, ll, dll, true);
         if (all_ok) {
             for (int e = 0; e < n_eval; ++e) {
                 ll[e] = hres[2 * e + 0];

@@ -1,0 +1,434 @@
+// H-step objective, per-segment part, in an EXACT low-rank (Woodbury) form -- round 4.
+//
+// Reference math: vlgp/gp.py:12-43 (elbo), 126-147 (construct_posterior_cov).  Per segment i and evaluation
+// (sigma^2, omega, eps) the round needs, with A = I + S K S, S = diag sqrt(w_i), K = K_s + eps I,
+// K_s = sigma^2 exp(-omega D^2):
+//     tr  = tr(A^-1)                         ( = tr(K^-1 S_i) of the reference )
+//     cs  = sum_jk s_j s_k dK_jk (A^-1)_jk   ( = d/dln(omega) log det A; enters tr(K^-1 S_i K^-1 dK) )
+// The dense kernels (hstep_mfma.h) factor the 50 x 50 matrix A per segment: T^3 / 2 multiply-adds whatever the
+// smoothness of K_s.  But K_s is numerically low-rank -- the squared-exponential kernel on a 50-bin window has
+// 12 ... 28 eigenvalues above 1e-13 at the omegas a fit visits after its first iterations -- and only w changes
+// from segment to segment.  With K_s = U U' (U: T x r, pivoted Cholesky run until the residual diagonal drops
+// below `tol`, the tail is below the rounding of the dense kernels), d = 1 / (1 + eps w), wt = w d:
+//     A^-1 = D - D S U M^-1 U' S D,    D = diag d,    M = I_r + U' diag(wt) U        (eigenvalues of M >= 1)
+//     tr   = sum_t d_t - < M^-1, U' diag(wt d) U >
+//     cs   = < M^-1, Ud' diag(wt) U + U' diag(wt) Ud >,   Ud = dU / dln(omega)
+// (cs is the derivative of log det M along omega; Ud comes out of the same pivoted Cholesky recursion by forward
+// differentiation, so that Ud U' + U Ud' = dK_s up to the same tail).  Checked against 40-digit arithmetic in
+// tools/lr_proto.py: 1e-14 ... 1e-12 relative for tol 1e-14 ... 1e-12.
+//
+// Two more structural facts are used:
+//   * K_s is centro-symmetric: in the basis of even / odd time courses (e_t + e_t') / sqrt 2, (e_t - e_t') / sqrt 2,
+//     t' = T - 1 - t, it is block diagonal, each block has about half the rank, and diag(wt) becomes
+//     [[wp, wm], [wm, wp]] with wp/wm = (wt_t +- wt_t') / 2 on HALF the time axis: the sums over t are 25 long.
+//   * the three r x r matrices of a segment are sums over t of (weight_t) x (a product of two table entries that
+//     does not depend on the segment): B[seg][pair (i, j)] = sum_t wgt[seg][t] P[t][pair], a GEMM across SEGMENTS
+//     with the segments on the 16 rows of v_mfma_f64_16x16x4, 16 (i <= j) pairs on its columns and t on its
+//     depth -- symmetric halves never computed, no per-segment operand staging.
+// A workgroup takes 16 segments of one evaluation:
+//   phase 1  M = I + B0 for the 16 segments (tiles of 16 pairs split over the waves) -> packed lower triangles in LDS
+//   phase 2  M^-1 in place by symmetric Gauss-Jordan sweeps, one lane per row, 2 or 4 segments side by side in a
+//            wave, the pivot column (= row) handed round through a small LDS buffer
+//   phase 3  the tiles of U'diag(wt d)U and of the symmetrised Ud'diag(wt)U stream through the matrix pipe once
+//            more and are contracted with M^-1 as they leave it (never stored)
+// Cost per segment at r = 24: 57 matrix instructions (19 tiles x 3 x 7 / 16 ... per segment 25) and ~ 600 vector
+// instructions against 78 + 1960 of the dense kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hstep_mfma.h"
+
+#define LR_RCAP 32    // largest total rank (even + odd) the low-rank round takes; above it the dense kernels run
+#define LR_RH 20      // per-parity capacity of the factor kernel
+#define LR_TROWS 32   // folded time rows of a table (windows up to 64 bins)
+#define LR_NPAIR 576  // pair codes per evaluation: 16 ceil(same / 16) + 16 ceil(cross / 16) <= 528 + 30
+
+struct LrMeta {
+    int re, ro;     // ranks of the even and the odd block
+    int r;          // re + ro (clamped to LR_RCAP)
+    int ns_tiles;   // tiles of same-parity pairs (weights wp)
+    int n_tiles;    // all tiles; [ns_tiles, n_tiles) hold the cross pairs (weights wm)
+    int overflow;   // 1: the rank did not fit the capacity the host predicted -> results of this evaluation invalid
+    int pad0, pad1;
+};
+
+struct HLrTabArgs {
+    int n_eval, T;
+    double dt, tol;
+    double logp[48];
+    int rcap[16];           // columns the round kernel has room for (host prediction)
+    double* tab;            // (n_eval, 2, LR_TROWS, LR_RCAP): U | dU/dln(omega), sigma folded in, zero padded
+    LrMeta* meta;           // (n_eval)
+    unsigned short* pairs;  // (n_eval, LR_NPAIR): (i << 8) | j, i >= j; 0xffff = padding
+};
+
+__device__ __forceinline__ double lr_rcp(double x) {  // 1 / x for x >= 1 (no denormals, no scaling needed)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tables of one evaluation: pivoted Cholesky of the even and of the odd block of K_0 = exp(-omega D^2) (one wave
+// each, lane <-> folded time row, factor columns in registers, pivot row entries by v_readlane), differentiated
+// along ln(omega) step by step.  Even block: Ke[t][p] = s_t s_p (k(t - p) + k(t + p - (T - 1))), s = 1 / sqrt 2 at
+// the middle row of an odd window and 1 elsewhere; odd block: Ko[t][p] = k(t - p) - k(t + p - (T - 1)), t, p < T / 2.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
+    __shared__ double kv[64], dkv[64];
+    __shared__ int s_r[2], s_cap[2];
+    const int e = blockIdx.x, lane = threadIdx.x & 63, par = threadIdx.x >> 6;
+    const int T = A.T, h = T >> 1, nt = (T + 1) >> 1;
+    const bool oddT = (T & 1) != 0;
+    const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]);
+    double* U = A.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP;
+    double* Ud = U + LR_TROWS * LR_RCAP;
+    unsigned short* pairs = A.pairs + (int64_t)e * LR_NPAIR;
+    for (int i = threadIdx.x; i < 2 * LR_TROWS * LR_RCAP; i += 128) U[i] = 0.0;
+    for (int q = threadIdx.x; q < LR_NPAIR; q += 128) pairs[q] = 0xffffu;
+    if (threadIdx.x < 64) {
+        const double d = lane * A.dt, d2 = d * d;
+        const double k = lane < T ? exp(-omega * d2) : 0.0;
+        kv[lane] = k;
+        dkv[lane] = -omega * d2 * k;
+    }
+    __syncthreads();
+    const int n = par == 0 ? nt : h;
+    const bool rowin = lane < n;
+    const int tau = rowin ? lane : 0;
+    constexpr double RS2 = 0.70710678118654752440;
+    const double stau = (par == 0 && oddT && tau == h) ? RS2 : 1.0;
+    auto kent = [&](int p, double& kk, double& dk) {
+        const int d1 = tau > p ? tau - p : p - tau, d2 = T - 1 - tau - p;
+        const double a = kv[d1], b = kv[d2], da = dkv[d1], db = dkv[d2];
+        if (par == 0) {
+            const double s = stau * ((oddT && p == h) ? RS2 : 1.0);
+            kk = s * (a + b);
+            dk = s * (da + db);
+        } else {
+            kk = a - b;
+            dk = da - db;
+        }
+    };
+    double g[LR_RH], gd[LR_RH];
+#pragma unroll
+    for (int k = 0; k < LR_RH; ++k) {
+        g[k] = 0.0;
+        gd[k] = 0.0;
+    }
+    double d, dd;
+    kent(tau, d, dd);
+    if (!rowin) {
+        d = -1.0;
+        dd = 0.0;
+    }
+    int r = 0;
+    auto wave_argmax = [&](double& bv, int& bi) {
+        bv = d;
+        bi = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < LR_RH; ++k) {
+        double bv;
+        int bi;
+        wave_argmax(bv, bi);
+        if (!(bv > A.tol)) break;  // (a NaN stops too)
+        const int p = __builtin_amdgcn_readfirstlane(bi);
+        const double ddp = tri_readlane(dd, p);
+        double ginv, gpp;
+        tri_rsqrt(bv, &ginv, &gpp);
+        const double gdot = 0.5 * ddp * ginv;
+        double col, cold;
+        kent(p, col, cold);
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+            const double gpj = tri_readlane(g[j], p), gdpj = tri_readlane(gd[j], p);
+            col = fma(-g[j], gpj, col);
+            cold = fma(-gd[j], gpj, cold);
+            cold = fma(-g[j], gdpj, cold);
+        }
+        const double gk = rowin ? col * ginv : 0.0;
+        const double gdk = rowin ? (cold - gk * gdot) * ginv : 0.0;
+        g[k] = gk;
+        gd[k] = gdk;
+        d = fma(-gk, gk, d);
+        dd = fma(-2.0 * gk, gdk, dd);
+        if (lane == p || !rowin) {
+            d = -1.0;
+            dd = 0.0;
+        }
+        r = k + 1;
+    }
+    int capped = 0;
+    if (r == LR_RH) {
+        double bv;
+        int bi;
+        wave_argmax(bv, bi);
+        capped = bv > A.tol;
+    }
+    if (lane == 0) {
+        s_r[par] = r;
+        s_cap[par] = capped;
+    }
+    __syncthreads();
+    int re = s_r[0], ro = s_r[1];
+    int overflow = s_cap[0] | s_cap[1];
+    if (re + ro > A.rcap[e] || re + ro > LR_RCAP) overflow = 1;
+    if (overflow) re = ro = 0;  // the round kernel's LDS is carved for rcap columns: leave it nothing to do
+    const int coff = par == 0 ? 0 : re;
+    const int rw = par == 0 ? re : ro;
+    const double sig = sqrt(sigmasq);
+    if (rowin) {
+#pragma unroll
+        for (int k = 0; k < LR_RH; ++k)
+            if (k < rw) {
+                U[tau * LR_RCAP + coff + k] = sig * g[k];
+                Ud[tau * LR_RCAP + coff + k] = sig * gd[k];
+            }
+    }
+    // pair list: same-parity pairs (even-even, then odd-odd), padded to a tile boundary, then the cross pairs
+    const int rt = re + ro;
+    const int n_ee = re * (re + 1) / 2, n_oo = ro * (ro + 1) / 2;
+    const int ns16 = (n_ee + n_oo + 15) & ~15, nc16 = (re * ro + 15) & ~15;
+    for (int x = threadIdx.x; x < rt * rt; x += 128) {
+        const int i = x / rt, j = x - i * rt;
+        if (j > i) continue;
+        const bool io = i >= re, jo = j >= re;
+        int pos;
+        if (io == jo)
+            pos = io ? n_ee + (i - re) * (i - re + 1) / 2 + (j - re) : i * (i + 1) / 2 + j;
+        else
+            pos = ns16 + (i - re) * re + j;  // i odd block, j even block
+        pairs[pos] = (unsigned short)((i << 8) | j);
+    }
+    if (threadIdx.x == 0) {
+        LrMeta m;
+        m.re = re;
+        m.ro = ro;
+        m.r = rt;
+        m.ns_tiles = ns16 >> 4;
+        m.n_tiles = (ns16 + nc16) >> 4;
+        m.overflow = overflow;
+        m.pad0 = m.pad1 = 0;
+        A.meta[e] = m;
+    }
+}
+
+// LDS carve of a segment group (doubles), for rank r, ntp folded time rows, nw waves
+struct LrGeom {
+    int LDU, NPS;
+    int o_u, o_ud, o_mp, o_xb, o_red, total;
+};
+__host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw) {
+    LrGeom G;
+    G.LDU = (r + 1) | 1;                   // column r: zeros (padding pairs point at it)
+    G.NPS = (r * (r + 1) / 2 + 1) | 1;     // packed lower triangle + one dummy slot
+    G.o_u = 0;
+    G.o_ud = ntp * G.LDU;
+    G.o_mp = (2 * ntp * G.LDU + 1) & ~1;
+    G.o_xb = (G.o_mp + 16 * G.NPS + 1) & ~1;
+    G.o_red = G.o_xb + nw * 64;
+    G.total = G.o_red + nw * 32 + 2;
+    return G;
+}
+
+// One group of 16 segments (seg0 ... seg0 + 15, those >= M masked) of one evaluation, by a workgroup of NW waves.
+// RC: register class (rank <= RC); NK: depth steps (4 NK >= folded rows).  Returns the group's sums of tr and cs
+// in lane 0 of wave 0 (other threads: garbage).
+template <int RC, int NK, int NW>
+__device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const LrMeta mt,
+                                         const unsigned short* __restrict__ pairs_e, const double* __restrict__ w,
+                                         const int64_t* __restrict__ off, int L, int l, int M, int T, double eps,
+                                         int seg0, double* lds, int lane, int wid, double& out_tr, double& out_cs) {
+    const int c = lane & 15, g = lane >> 4;
+    const int r = mt.r;
+    const LrGeom G = lr_geom(r, 4 * NK, NW);
+    double* Ul = lds + G.o_u;
+    double* Udl = lds + G.o_ud;
+    double* Mp = lds + G.o_mp;
+    double* xb = lds + G.o_xb + wid * 64;
+    double* red = lds + G.o_red;
+    const int LDU = G.LDU, NPS = G.NPS;
+    for (int x = threadIdx.x; x < 4 * NK * LDU; x += 64 * NW) {
+        const int tau = x / LDU, cc = x - tau * LDU;
+        const bool in = cc < r;
+        Ul[x] = in ? tab_e[tau * LR_RCAP + cc] : 0.0;
+        Udl[x] = in ? tab_e[LR_TROWS * LR_RCAP + tau * LR_RCAP + cc] : 0.0;
+    }
+    // ---- phase 0: folded weights of segment c at the depth positions of this lane ----
+    // (evaluated before phase 1 and again before phase 3: 4 NK values that would otherwise sit in registers through the
+    // sweeps of phase 2, which need the room for the matrix rows)
+    const int h = T >> 1, nt = (T + 1) >> 1;
+    const int gs = seg0 + c;
+    const bool sval = gs < M;
+    const int64_t r0 = sval ? off[gs] : 0;
+    double ap[NK], am[NK], bp[NK], bm[NK];
+    double dsum = 0.0;
+    auto weights = [&]() {
+        dsum = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int tau = 4 * kk + g;
+            const bool in1 = sval && tau < nt, in2 = sval && tau < h;
+            const double w1 = in1 ? w[(r0 + tau) * L + l] : 0.0;
+            const double w2 = in2 ? w[(r0 + T - 1 - tau) * L + l] : 0.0;
+            const double d1 = lr_rcp(fma(eps, w1, 1.0)), d2 = lr_rcp(fma(eps, w2, 1.0));
+            const double t1 = w1 * d1, t2 = w2 * d2;
+            const double q1 = t1 * d1, q2 = t2 * d2;
+            const double fa = in2 ? 0.5 : 1.0;  // the middle row of an odd window is its own mirror image
+            ap[kk] = fa * (t1 + t2);
+            bp[kk] = fa * (q1 + q2);
+            am[kk] = in2 ? 0.5 * (t1 - t2) : 0.0;
+            bm[kk] = in2 ? 0.5 * (q1 - q2) : 0.0;
+            dsum += (in1 ? d1 : 0.0) + (in2 ? d2 : 0.0);
+        }
+    };
+    weights();
+    __syncthreads();
+    // ---- phase 1: M = I + U' diag(wt) U, 16 pairs x 16 segments per tile ----
+    for (int q = wid; q < mt.n_tiles; q += NW) {
+        const unsigned code = pairs_e[q * 16 + c];
+        const bool valid = code != 0xffffu;
+        const int i = valid ? (int)(code >> 8) : r, j = valid ? (int)(code & 255u) : r;
+        const double* ui = Ul + g * LDU + i;
+        const double* uj = Ul + g * LDU + j;
+        hm_d4 acc = hm_d4{0.0, 0.0, 0.0, 0.0};
+        auto tile = [&](const double(&aw)[NK]) {
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const double b = ui[4 * kk * LDU] * uj[4 * kk * LDU];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], b, acc, 0, 0, 0);
+            }
+        };
+        if (q >= mt.ns_tiles) tile(am);
+        else tile(ap);
+        const int idx = valid ? i * (i + 1) / 2 + j : NPS - 1;
+        const double dg = (valid && i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) Mp[(g + 4 * p) * NPS + idx] = acc[p] + dg;
+    }
+    __syncthreads();
+    // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps, lane <-> row, SPP segments side by side ----
+    {
+        constexpr int LPS = RC <= 16 ? 16 : 32, SPP = 64 / LPS;
+        const int sl = lane / LPS, row = lane % LPS;
+        const bool rowok = row < r;
+        double* xs = xb + sl * LPS;
+        for (int P = wid; P < 16 / SPP; P += NW) {
+            int rowv = row;  // opaque per pass: the packed indices of a row are not worth 2 RC registers across passes
+            asm volatile("" : "+v"(rowv));
+            const int seg = P * SPP + sl;
+            double* Ms = Mp + seg * NPS;
+            double a[RC];
+#pragma unroll
+            for (int j = 0; j < RC; ++j) {
+                const int hi = rowv > j ? rowv : j, lo = rowv > j ? j : rowv;
+                a[j] = (rowok && j < r) ? Ms[hi * (hi + 1) / 2 + lo] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                if (k < r) {
+                    xs[row] = a[k];  // column k = row k (symmetric): every lane contributes its entry
+                    tri_wave_order();
+                    const double dinv = lr_rcp(xs[k]);
+                    const double f = row == k ? 1.0 - dinv : a[k] * dinv;
+#pragma unroll
+                    for (int j = 0; j < RC; j += 2) {
+                        if (j < r) {
+                            const double2 pv = *reinterpret_cast<const double2*>(xs + j);
+                            a[j] = fma(-f, pv.x, a[j]);
+                            if (j + 1 < RC) a[j + 1] = fma(-f, pv.y, a[j + 1]);
+                        }
+                    }
+                    a[k] = row == k ? -dinv : f;
+                    tri_wave_order();
+                }
+            }
+            // a = -(M^-1)[row][:]; stored with the off-diagonal entries doubled: the contraction runs over i >= j
+            if (rowok) {
+#pragma unroll
+                for (int j = 0; j < RC; ++j)
+                    if (j <= rowv) Ms[rowv * (rowv + 1) / 2 + j] = j == rowv ? -a[j] : -2.0 * a[j];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: < M^-1, U' diag(wt d) U > and < M^-1, Ud' diag(wt) U + U' diag(wt) Ud > ----
+    double ts[4] = {0.0, 0.0, 0.0, 0.0}, cs[4] = {0.0, 0.0, 0.0, 0.0};
+    weights();
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    for (int q = wid; q < mt.n_tiles; q += NW) {
+        const unsigned code = pairs_e[q * 16 + c];
+        const bool valid = code != 0xffffu;
+        const int i = valid ? (int)(code >> 8) : r, j = valid ? (int)(code & 255u) : r;
+        const double* ui = Ul + g * LDU + i;
+        const double* uj = Ul + g * LDU + j;
+        const double* di = Udl + g * LDU + i;
+        const double* dj = Udl + g * LDU + j;
+        hm_d4 accB = hm_d4{0.0, 0.0, 0.0, 0.0}, accD = hm_d4{0.0, 0.0, 0.0, 0.0};
+        auto tile = [&](const double(&aw)[NK], const double(&bw)[NK]) {
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int o = 4 * kk * LDU;
+                const double vi = ui[o], vj = uj[o];
+                const double pb = vi * vj;
+                const double pd = fma(di[o], vj, vi * dj[o]);
+                accB = __builtin_amdgcn_mfma_f64_16x16x4f64(bw[kk], pb, accB, 0, 0, 0);
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], pd, accD, 0, 0, 0);
+            }
+        };
+        if (q >= mt.ns_tiles) tile(am, bm);
+        else tile(ap, bp);
+        const int idx = valid ? i * (i + 1) / 2 + j : NPS - 1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const double m = Mp[(g + 4 * p) * NPS + idx];
+            ts[p] = fma(m, accB[p], ts[p]);
+            cs[p] = fma(m, accD[p], cs[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            ts[p] += __shfl_xor(ts[p], o, 64);
+            cs[p] += __shfl_xor(cs[p], o, 64);
+        }
+        if (c == 0) {
+            red[(wid * 16 + g + 4 * p) * 2 + 0] = ts[p];
+            red[(wid * 16 + g + 4 * p) * 2 + 1] = cs[p];
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+        double t = 0.0, cc = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) {
+            t += red[(wv * 16 + c) * 2 + 0];
+            cc += red[(wv * 16 + c) * 2 + 1];
+        }
+        double tA = (sval && g == 0) ? dsum - t : 0.0;
+        double cv = (sval && g == 0) ? cc : 0.0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // lanes 0..15 hold the 16 segments
+            tA += __shfl_xor(tA, o, 64);
+            cv += __shfl_xor(cv, o, 64);
+        }
+        out_tr = tA;
+        out_cs = cv;
+    }
+}

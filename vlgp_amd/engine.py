@@ -344,6 +344,13 @@ class Engine:
         self._ck(self.lib.vlgp_debug_last_estep_path(self.h, C.byref(p)))
         return _lib.ESTEP_PATHS[p.value]
 
+    @property
+    def last_hstep_path(self):
+        """Kernel family of the most recent hstep_objective call: one of _lib.HSTEP_PATHS."""
+        p = C.c_int(0)
+        self._ck(self.lib.vlgp_debug_last_hstep_path(self.h, C.byref(p)))
+        return _lib.HSTEP_PATHS[p.value]
+
     def profile_get(self, kind):
         n, ms, units = C.c_int64(0), C.c_double(0), C.c_double(0)
         self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms), C.byref(units)))
