@@ -1067,10 +1067,14 @@ struct HRoundArgs {
     double* qsum;          // (n_eval, 2): tr(K^-1 C), tr(K^-1 dK K^-1 C)
     double* red;           // device: (ll, dll) x n_eval, then ok x n_eval
     double* host;          // mapped pinned copy of `red` + sequence word at [48], or null
-    // low-rank round (hstep_round_lr): tables written by hstep_lr_tables; null in the dense rounds
-    const double* lr_tab;
-    const LrMeta* lr_meta;
-    const unsigned short* lr_pairs;
+    // low-rank round (hstep_round_lr): tables written by hstep_lr_tables, launched in front
+    HLrTabArgs lr;         // lr.tab == null in the dense rounds
+    // a round may be several launches (one per rank class of the low-rank kernel): the ticket counts the blocks of all
+    unsigned total_blocks;  // blocks of the whole round
+    int k_blocks;           // this launch starts with the n_eval K blocks (the first launch of a round), else 0
+    int lr_nev;             // evaluations this launch takes the segments of ...
+    int lr_ev[16];          // ... and which
+    unsigned long long* clk;  // debug: per-phase cycle counters of the first segment block (vlgp_debug_phase_clock), or null
 };
 
 template <int T>
@@ -1497,14 +1501,15 @@ __device__ __forceinline__ void hstep_round_kblock(const HRoundArgs& R, int e, d
 
 // Completion of a round: one partial per segment block (part[w] summed over the NW waves), then the block that draws
 // the last ticket adds the partials of every evaluation in a fixed order and publishes (ll, dll, flag).  `rs`: 2 x 64 NW
-// doubles of LDS.  flag: 1 = fine, 0 = K did not factor, 2 = the low-rank tables overflowed (R.lr_meta)
+// doubles of LDS.  flag: 1 = fine, 0 = K did not factor, 2 = the low-rank tables overflowed (R.lr.meta)
 template <int NW>
-__device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* rs, double (*part)[2], int* s_last) {
+__device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* rs, double (*part)[2], int* s_last,
+                                                   int64_t out_slot) {
     const HFastArgs& A = R.F;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if ((int)blockIdx.x >= R.n_eval) {
-            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
+        if (out_slot >= 0) {
+            double* o = A.out + 2 * out_slot;
             double t0 = part[0][0], t1 = part[0][1];
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
@@ -1515,7 +1520,7 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
             o[1] = t1;
         }
         const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = ticket == gridDim.x - 1;
+        *s_last = ticket == R.total_blocks - 1;
     }
     __syncthreads();
     if (!*s_last) return;
@@ -1543,7 +1548,7 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
         }
         if (threadIdx.x == 0) {
             double okf = A.scal[4 * e + 3];
-            if (R.lr_meta != nullptr && R.lr_meta[e].overflow) okf = okf != 0.0 ? 2.0 : 0.0;
+            if (R.lr.tab != nullptr && R.lr.meta[e].overflow) okf = okf != 0.0 ? 2.0 : 0.0;
             const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
             const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[NT]);
             R.red[2 * e + 0] = ll;
@@ -1630,14 +1635,22 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
             part[wid][1] = cs;
         }
     }
-    hstep_round_finish<NW>(R, lds, part, &s_last);
+    hstep_round_finish<NW>(R, lds, part, &s_last, (int)blockIdx.x >= R.n_eval ? (int64_t)blockIdx.x - R.n_eval : -1);
+}
+
+// Tables of the evaluations of a low-rank round: one block per evaluation (hstep_lr.h, lr_tables_block).
+__global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
+    __shared__ double kv[64], dkv[64];
+    __shared__ int s_i[4];
+    const int e = blockIdx.x;
+    lr_tables_block<128>(R.lr, e, exp(R.F.logp[3 * e + 0]), exp(R.F.logp[3 * e + 1]), kv, dkv, s_i);
 }
 
 // The round in the low-rank form (hstep_lr.h): blocks [0, n_eval) are the K blocks as above, every other block takes
 // sixteen segments of one evaluation.  The tables of the evaluations come from hstep_lr_tables, launched in front.
 // T: compiled window of the K block (50: windows <= 50, 64: <= 64); RC: register class of the ranks in this round.
-template <int T, int NW, int RC>
-__global__ void __launch_bounds__(64 * NW, RC <= 16 ? 4 : (RC <= 24 ? 3 : 2)) hstep_round_lr(HRoundArgs R) {
+template <int T, int NW, int RC, bool TABG = false>
+__global__ void __launch_bounds__(64 * NW, RC <= 16 ? 4 : 3) hstep_round_lr(HRoundArgs R) {
     constexpr bool ONESET = T == 50;
     constexpr int NK = T == 50 ? 7 : 8;
     using KG = HRoundK<T, NW, ONESET>;
@@ -1646,21 +1659,25 @@ __global__ void __launch_bounds__(64 * NW, RC <= 16 ? 4 : (RC <= 24 ? 3 : 2)) hs
     __shared__ int s_last;
     const HFastArgs& A = R.F;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if ((int)blockIdx.x < R.n_eval) {
+    int64_t out_slot = -1;
+    if ((int)blockIdx.x < R.k_blocks) {
         hstep_round_kblock<T, NW, ONESET>(R, blockIdx.x, lds_dyn, lds_dyn + KG::KBLK - KG::SHR, part, lane, wid);
     } else {
-        const int b = blockIdx.x - R.n_eval;
-        const int e = b / R.nb, bx = b - e * R.nb;
+        const int b = blockIdx.x - R.k_blocks;
+        const int ei = b / R.nb, bx = b - ei * R.nb;
+        const int e = R.lr_ev[ei];
+        out_slot = (int64_t)e * R.nb + bx;
         double tr = 0.0, cs = 0.0;
         const double eps = exp(A.logp[3 * e + 2]);
-        lr_group<RC, NK, NW>(R.lr_tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP, R.lr_meta[e], R.lr_pairs + (int64_t)e * LR_NPAIR,
-                             A.w, A.off, A.L, A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs);
+        lr_group<RC, NK, NW, TABG>(R.lr.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP, R.lr.meta[e], R.lr.pairs + (int64_t)e * LR_NPAIR,
+                             A.w, A.off, A.L, A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs,
+                             b == 0 ? R.clk : nullptr);
         if (lane == 0) {
             part[wid][0] = wid == 0 ? tr : 0.0;
             part[wid][1] = wid == 0 ? cs : 0.0;
         }
     }
-    hstep_round_finish<NW>(R, lds_dyn, part, &s_last);
+    hstep_round_finish<NW>(R, lds_dyn, part, &s_last, out_slot);
 }
 
 template <int T>
@@ -1741,16 +1758,18 @@ static const std::vector<double>& lr_thresholds(vlgp_ctx* ctx, int T, double dt,
     return ctx->lr_thr.back().om;
 }
 
-template <int T, int RC>
+constexpr int LR_NW = 4;  // waves per workgroup of the low-rank round (sixteen segments)
+
+template <int T, int RC, bool TABG = false>
 static int launch_round_lr(vlgp_ctx* ctx, const HRoundArgs& R, int grid, size_t lds_bytes) {
-    constexpr int NW = 4;
+    constexpr int NW = LR_NW;
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC>),
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC, TABG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512)));
         attr_set = 160 * 1024;
     }
-    hipLaunchKernelGGL((hstep_round_lr<T, NW, RC>), dim3(grid), dim3(64 * NW), lds_bytes, ctx->stream, R);
+    hipLaunchKernelGGL((hstep_round_lr<T, NW, RC, TABG>), dim3(grid), dim3(64 * NW), lds_bytes, ctx->stream, R);
     return VLGP_OK;
 }
 
@@ -1850,7 +1869,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             // the exact low-rank round (hstep_lr.h) when every evaluation's kernel matrix has numerical rank <= LR_RCAP
             // (omega below about 2e-2 on a 50-bin window); VLGP_HSTEP_DENSE=1 keeps the dense matrix-pipe round
             const bool lr_off = getenv("VLGP_HSTEP_DENSE") != nullptr;  // read per call: the tests switch it
-            const double lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-13;
+            const double lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-12;
             bool lr = mfma && !twoset && !lr_off && !force_dense;
             int rcap[16], rmax = 0;
             if (lr) {
@@ -1868,18 +1887,19 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
-            R.lr_tab = nullptr; R.lr_meta = nullptr; R.lr_pairs = nullptr;
+            R.lr.tab = nullptr; R.lr.meta = nullptr; R.lr.pairs = nullptr;
+            R.total_blocks = (unsigned)(n_eval + n_eval * R.nb); R.k_blocks = n_eval; R.lr_nev = 0; R.clk = ctx->d_clk;
             if (lr) {
-                HLrTabArgs TA;
-                TA.n_eval = n_eval; TA.T = T; TA.dt = dt; TA.tol = lr_tol;
-                for (int i = 0; i < 3 * n_eval; ++i) TA.logp[i] = logp[i];
-                for (int e = 0; e < n_eval; ++e) TA.rcap[e] = rcap[e];
-                TA.tab = W + o_lrtab;
-                TA.meta = reinterpret_cast<LrMeta*>(W + o_lrmeta);
-                TA.pairs = reinterpret_cast<unsigned short*>(W + o_lrpairs);
-                hipLaunchKernelGGL(hstep_lr_tables, dim3(n_eval), dim3(128), 0, ctx->stream, TA);
+                R.lr.T = T; R.lr.dt = dt; R.lr.tol = lr_tol;
+                for (int e = 0; e < n_eval; ++e) R.lr.rcap[e] = rcap[e];
+                R.lr.tab = W + o_lrtab;
+                R.lr.meta = reinterpret_cast<LrMeta*>(W + o_lrmeta);
+                R.lr.pairs = reinterpret_cast<unsigned short*>(W + o_lrpairs);
+                // (Measured: the tables built by blocks of the round kernel itself, the segment blocks waiting on a flag,
+                // is SLOWER than this extra launch -- 57 against 26 + 12 us for one evaluation: the waiting blocks fill
+                // the chip before the table blocks finish.)
+                hipLaunchKernelGGL(hstep_lr_tables, dim3(n_eval), dim3(128), 0, ctx->stream, R);
                 HIPCHK(ctx, hipGetLastError());
-                R.lr_tab = TA.tab; R.lr_meta = TA.meta; R.lr_pairs = TA.pairs;
             }
             ctx->last_hstep_path = lr ? VLGP_PATH_HSTEP_LOWRANK : (mfma ? VLGP_PATH_HSTEP_DENSE : VLGP_PATH_HSTEP_OLD);
             // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
@@ -1893,22 +1913,49 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             else if (lean)
                 hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else if (lr) {
-                constexpr int NW = 4;
+                // one launch per rank class present in the round (registers and LDS are sized by the class: a smooth
+                // latent's segments must not run at the occupancy of a rough one's); the K blocks ride in the first
+                constexpr int NW = LR_NW;
                 const int NK = TC == 50 ? 7 : 8;
                 const int kblk = TC == 50 ? HRoundK<50, NW, true>::KBLK : HRoundK<64, NW, false>::KBLK;
-                int need = lr_geom(rmax, 4 * NK, NW).total;
-                if (need < kblk) need = kblk;
-                if (need < 2 * 64 * NW) need = 2 * 64 * NW;
-                const size_t lds_bytes = (size_t)need * 8;
-                const int grid = n_eval + n_eval * R.nb;
-                if (TC == 50) {
-                    if (rmax <= 16) CHK((launch_round_lr<50, 16>(ctx, R, grid, lds_bytes)));
-                    else if (rmax <= 24) CHK((launch_round_lr<50, 24>(ctx, R, grid, lds_bytes)));
-                    else CHK((launch_round_lr<50, 32>(ctx, R, grid, lds_bytes)));
-                } else {
-                    if (rmax <= 16) CHK((launch_round_lr<64, 16>(ctx, R, grid, lds_bytes)));
-                    else if (rmax <= 24) CHK((launch_round_lr<64, 24>(ctx, R, grid, lds_bytes)));
-                    else CHK((launch_round_lr<64, 32>(ctx, R, grid, lds_bytes)));
+                // ONE launch, compiled for the largest rank of the round.  (Measured: one launch per rank class --
+                // registers and LDS sized by the class -- serialises three under-filled launches, 137 us against
+                // 97 us for a steady-state round of C3.)
+                const int cls_of_max = rmax <= 16 ? 0 : (rmax <= 24 ? 1 : 2);
+                bool first = true;
+                for (int ci = cls_of_max; ci <= cls_of_max; ++ci) {
+                    HRoundArgs Rc = R;
+                    Rc.lr_nev = 0;
+                    int rm = rmax;
+                    for (int e = 0; e < n_eval; ++e) Rc.lr_ev[Rc.lr_nev++] = e;
+                    if (Rc.lr_nev == 0) continue;
+                    Rc.k_blocks = first ? n_eval : 0;
+                    // tables in LDS unless leaving them in global memory lets one more workgroup share a CU
+                    auto wgs = [&](int doubles) {
+                        int n = doubles;
+                        if (first && n < kblk) n = kblk;
+                        if (n < 2 * 64 * NW) n = 2 * 64 * NW;
+                        return (160 * 1024) / (n * 8 + 256);
+                    };
+                    const int need_l = lr_geom(rm, 4 * NK, NW, false).total, need_g = lr_geom(rm, 4 * NK, NW, true).total;
+                    const bool tabg = ci == 2 && rm < LR_RCAP && wgs(need_g) > wgs(need_l) && wgs(need_l) < 3;
+                    int need = tabg ? need_g : need_l;
+                    if (first && need < kblk) need = kblk;
+                    if (need < 2 * 64 * NW) need = 2 * 64 * NW;
+                    const size_t lds_bytes = (size_t)need * 8;
+                    const int grid = Rc.k_blocks + Rc.lr_nev * R.nb;
+                    if (TC == 50) {
+                        if (ci == 0) CHK((launch_round_lr<50, 16>(ctx, Rc, grid, lds_bytes)));
+                        else if (ci == 1) CHK((launch_round_lr<50, 24>(ctx, Rc, grid, lds_bytes)));
+                        else if (tabg) CHK((launch_round_lr<50, 32, true>(ctx, Rc, grid, lds_bytes)));
+                        else CHK((launch_round_lr<50, 32>(ctx, Rc, grid, lds_bytes)));
+                    } else {
+                        if (ci == 0) CHK((launch_round_lr<64, 16>(ctx, Rc, grid, lds_bytes)));
+                        else if (ci == 1) CHK((launch_round_lr<64, 24>(ctx, Rc, grid, lds_bytes)));
+                        else if (tabg) CHK((launch_round_lr<64, 32, true>(ctx, Rc, grid, lds_bytes)));
+                        else CHK((launch_round_lr<64, 32>(ctx, Rc, grid, lds_bytes)));
+                    }
+                    first = false;
                 }
             } else if (TC == 50 && twoset)
                 hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,

@@ -54,9 +54,8 @@ struct LrMeta {
 };
 
 struct HLrTabArgs {
-    int n_eval, T;
+    int T;
     double dt, tol;
-    double logp[48];
     int rcap[16];           // columns the round kernel has room for (host prediction)
     double* tab;            // (n_eval, 2, LR_TROWS, LR_RCAP): U | dU/dln(omega), sigma folded in, zero padded
     LrMeta* meta;           // (n_eval)
@@ -78,18 +77,22 @@ __device__ __forceinline__ double lr_rcp(double x) {  // 1 / x for x >= 1 (no de
 // along ln(omega) step by step.  Even block: Ke[t][p] = s_t s_p (k(t - p) + k(t + p - (T - 1))), s = 1 / sqrt 2 at
 // the middle row of an odd window and 1 elsewhere; odd block: Ko[t][p] = k(t - p) - k(t + p - (T - 1)), t, p < T / 2.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
-    __shared__ double kv[64], dkv[64];
-    __shared__ int s_r[2], s_cap[2];
-    const int e = blockIdx.x, lane = threadIdx.x & 63, par = threadIdx.x >> 6;
+// Called by every thread of a block of NT >= 128 threads; the first two waves factor, the others help with the fills.
+// kv, dkv: 2 x 64 doubles of LDS; s_i: 4 ints of LDS.
+template <int NT>
+__device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, double sigmasq, double omega, double* kv,
+                                                double* dkv, int* s_i) {
+    int* s_r = s_i;
+    int* s_cap = s_i + 2;
+    const int lane = threadIdx.x & 63, par = threadIdx.x >> 6;
+    const bool fac = par < 2;  // this wave factors a block (0: even, 1: odd)
     const int T = A.T, h = T >> 1, nt = (T + 1) >> 1;
     const bool oddT = (T & 1) != 0;
-    const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]);
     double* U = A.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP;
     double* Ud = U + LR_TROWS * LR_RCAP;
     unsigned short* pairs = A.pairs + (int64_t)e * LR_NPAIR;
-    for (int i = threadIdx.x; i < 2 * LR_TROWS * LR_RCAP; i += 128) U[i] = 0.0;
-    for (int q = threadIdx.x; q < LR_NPAIR; q += 128) pairs[q] = 0xffffu;
+    for (int i = threadIdx.x; i < 2 * LR_TROWS * LR_RCAP; i += NT) U[i] = 0.0;
+    for (int q = threadIdx.x; q < LR_NPAIR; q += NT) pairs[q] = 0xffffu;
     if (threadIdx.x < 64) {
         const double d = lane * A.dt, d2 = d * d;
         const double k = lane < T ? exp(-omega * d2) : 0.0;
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
         dkv[lane] = -omega * d2 * k;
     }
     __syncthreads();
-    const int n = par == 0 ? nt : h;
+    const int n = par == 0 ? nt : (par == 1 ? h : 0);
     const bool rowin = lane < n;
     const int tau = rowin ? lane : 0;
     constexpr double RS2 = 0.70710678118654752440;
@@ -127,18 +130,12 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
         dd = 0.0;
     }
     int r = 0;
-    auto wave_argmax = [&](double& bv, int& bi) {
+    auto wave_argmax = [&](double& bv, int& bi) {  // largest residual diagonal, lowest lane on ties; branch-free
         bv = d;
-        bi = lane;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
-        }
+        for (int o = 32; o > 0; o >>= 1) bv = fmax(bv, __shfl_xor(bv, o, 64));
+        const unsigned long long m = __ballot(d == bv);
+        bi = m ? __builtin_ctzll(m) : 0;
     };
 #pragma unroll
     for (int k = 0; k < LR_RH; ++k) {
@@ -153,13 +150,17 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
         const double gdot = 0.5 * ddp * ginv;
         double col, cold;
         kent(p, col, cold);
+        double cold2 = 0.0, col2 = 0.0;  // (independent partial sums: the chains are what a step costs)
 #pragma unroll
         for (int j = 0; j < k; ++j) {
             const double gpj = tri_readlane(g[j], p), gdpj = tri_readlane(gd[j], p);
-            col = fma(-g[j], gpj, col);
+            if (j & 1) col2 = fma(-g[j], gpj, col2);
+            else col = fma(-g[j], gpj, col);
             cold = fma(-gd[j], gpj, cold);
-            cold = fma(-g[j], gdpj, cold);
+            cold2 = fma(-g[j], gdpj, cold2);
         }
+        col += col2;
+        cold += cold2;
         const double gk = rowin ? col * ginv : 0.0;
         const double gdk = rowin ? (cold - gk * gdot) * ginv : 0.0;
         g[k] = gk;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
         wave_argmax(bv, bi);
         capped = bv > A.tol;
     }
-    if (lane == 0) {
+    if (lane == 0 && fac) {
         s_r[par] = r;
         s_cap[par] = capped;
     }
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
     const int coff = par == 0 ? 0 : re;
     const int rw = par == 0 ? re : ro;
     const double sig = sqrt(sigmasq);
-    if (rowin) {
+    if (rowin && fac) {
 #pragma unroll
         for (int k = 0; k < LR_RH; ++k)
             if (k < rw) {
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HLrTabArgs A) {
     const int rt = re + ro;
     const int n_ee = re * (re + 1) / 2, n_oo = ro * (ro + 1) / 2;
     const int ns16 = (n_ee + n_oo + 15) & ~15, nc16 = (re * ro + 15) & ~15;
-    for (int x = threadIdx.x; x < rt * rt; x += 128) {
+    for (int x = threadIdx.x; x < rt * rt; x += NT) {
         const int i = x / rt, j = x - i * rt;
         if (j > i) continue;
         const bool io = i >= re, jo = j >= re;
@@ -232,13 +233,13 @@ struct LrGeom {
     int LDU, NPS;
     int o_u, o_ud, o_mp, o_xb, o_red, total;
 };
-__host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw) {
+__host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_global = false) {
     LrGeom G;
-    G.LDU = (r + 1) | 1;                   // column r: zeros (padding pairs point at it)
-    G.NPS = (r * (r + 1) / 2 + 1) | 1;     // packed lower triangle + one dummy slot
+    G.LDU = tab_global ? LR_RCAP : ((r + 1) | 1);  // column r: zeros (padding pairs point at it)
+    G.NPS = (r * (r + 1) / 2 + 2) | 1;     // packed lower triangle + a zero slot (padding pairs) + a trash slot
     G.o_u = 0;
-    G.o_ud = ntp * G.LDU;
-    G.o_mp = (2 * ntp * G.LDU + 1) & ~1;
+    G.o_ud = tab_global ? 0 : ntp * G.LDU;
+    G.o_mp = tab_global ? 0 : ((2 * ntp * G.LDU + 1) & ~1);
     G.o_xb = (G.o_mp + 16 * G.NPS + 1) & ~1;
     G.o_red = G.o_xb + nw * 64;
     G.total = G.o_red + nw * 32 + 2;
@@ -248,25 +249,49 @@ __host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw) {
 // One group of 16 segments (seg0 ... seg0 + 15, those >= M masked) of one evaluation, by a workgroup of NW waves.
 // RC: register class (rank <= RC); NK: depth steps (4 NK >= folded rows).  Returns the group's sums of tr and cs
 // in lane 0 of wave 0 (other threads: garbage).
-template <int RC, int NK, int NW>
+template <int RC, int NK, int NW, bool TABG = false>
 __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const LrMeta mt,
                                          const unsigned short* __restrict__ pairs_e, const double* __restrict__ w,
                                          const int64_t* __restrict__ off, int L, int l, int M, int T, double eps,
-                                         int seg0, double* lds, int lane, int wid, double& out_tr, double& out_cs) {
+                                         int seg0, double* lds, int lane, int wid, double& out_tr, double& out_cs,
+                                         unsigned long long* clk = nullptr) {
+    // debug (vlgp_debug_phase_clock): cycles per phase of one workgroup, thread 0
+    long long tck = clk ? clock64() : 0;
+    auto stamp = [&](int slot) {
+        if (clk && threadIdx.x == 0) {
+            const long long now = clock64();
+            atomicAdd(clk + slot, (unsigned long long)(now - tck));
+            tck = now;
+        }
+    };
     const int c = lane & 15, g = lane >> 4;
-    const int r = mt.r;
-    const LrGeom G = lr_geom(r, 4 * NK, NW);
-    double* Ul = lds + G.o_u;
-    double* Udl = lds + G.o_ud;
+    // wave-uniform by construction; said explicitly so that the rank guards below are scalar branches
+    const int r = __builtin_amdgcn_readfirstlane(mt.r);
+    const int ns_tiles = __builtin_amdgcn_readfirstlane(mt.ns_tiles), n_tiles = __builtin_amdgcn_readfirstlane(mt.n_tiles);
+    // TABG: the tables stay in global memory (L1 / L2: 13 KB per evaluation, shared by its 250 workgroups) and the LDS
+    // they would take goes to a third workgroup per CU (ranks 25 ... 31); needs a zero column, i.e. r < LR_RCAP
+    const LrGeom G = lr_geom(r, 4 * NK, NW, TABG);
+    const double* Ul = TABG ? tab_e : lds + G.o_u;
+    const double* Udl = TABG ? tab_e + LR_TROWS * LR_RCAP : lds + G.o_ud;
     double* Mp = lds + G.o_mp;
     double* xb = lds + G.o_xb + wid * 64;
     double* red = lds + G.o_red;
     const int LDU = G.LDU, NPS = G.NPS;
-    for (int x = threadIdx.x; x < 4 * NK * LDU; x += 64 * NW) {
-        const int tau = x / LDU, cc = x - tau * LDU;
-        const bool in = cc < r;
-        Ul[x] = in ? tab_e[tau * LR_RCAP + cc] : 0.0;
-        Udl[x] = in ? tab_e[LR_TROWS * LR_RCAP + tau * LR_RCAP + cc] : 0.0;
+    const int NPZ = r * (r + 1) / 2;  // the zero slot of a packed matrix; NPZ + 1: trash
+    if constexpr (!TABG) {
+        double* Uw = lds + G.o_u;
+        double* Udw = lds + G.o_ud;
+        for (int x = threadIdx.x; x < 4 * NK * LR_RCAP; x += 64 * NW) {  // (LR_RCAP = 32 columns per table row: shifts)
+            const int tau = x >> 5, cc = x & 31;
+            if (cc < LDU) {  // columns >= r of the table are zero already
+                Uw[tau * LDU + cc] = tab_e[x];
+                Udw[tau * LDU + cc] = tab_e[LR_TROWS * LR_RCAP + x];
+            }
+        }
+        if (LDU > LR_RCAP && threadIdx.x < 4 * NK) {  // full rank: the zero column lies beyond the table's
+            Uw[threadIdx.x * LDU + LR_RCAP] = 0.0;
+            Udw[threadIdx.x * LDU + LR_RCAP] = 0.0;
+        }
     }
     // ---- phase 0: folded weights of segment c at the depth positions of this lane ----
     // (evaluated before phase 1 and again before phase 3: 4 NK values that would otherwise sit in registers through the
@@ -298,80 +323,120 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     };
     weights();
     __syncthreads();
-    // ---- phase 1: M = I + U' diag(wt) U, 16 pairs x 16 segments per tile ----
-    for (int q = wid; q < mt.n_tiles; q += NW) {
+    stamp(0);
+    // ---- phase 1: M = I + U' diag(wt) U, 16 pairs x 16 segments per tile; two tiles of one kind at a time (two
+    // independent accumulate chains on the matrix pipe) ----
+    auto tile_codes = [&](int q, int& i, int& j, int& idx, double& dg) {
         const unsigned code = pairs_e[q * 16 + c];
         const bool valid = code != 0xffffu;
-        const int i = valid ? (int)(code >> 8) : r, j = valid ? (int)(code & 255u) : r;
-        const double* ui = Ul + g * LDU + i;
-        const double* uj = Ul + g * LDU + j;
-        hm_d4 acc = hm_d4{0.0, 0.0, 0.0, 0.0};
-        auto tile = [&](const double(&aw)[NK]) {
+        i = valid ? (int)(code >> 8) : r;
+        j = valid ? (int)(code & 255u) : r;
+        idx = valid ? i * (i + 1) / 2 + j : NPZ;
+        dg = (valid && i == j) ? 1.0 : 0.0;
+    };
+    auto phase1 = [&](int qb, int qe, const double(&aw)[NK]) {
+        for (int q = qb + wid; q < qe; q += 2 * NW) {
+            const bool two = q + NW < qe;
+            int i0, j0, x0, i1, j1, x1;
+            double g0, g1;
+            tile_codes(q, i0, j0, x0, g0);
+            tile_codes(two ? q + NW : q, i1, j1, x1, g1);
+            const double* u0i = Ul + g * LDU + i0;
+            const double* u0j = Ul + g * LDU + j0;
+            const double* u1i = Ul + g * LDU + i1;
+            const double* u1j = Ul + g * LDU + j1;
+            hm_d4 acc0 = hm_d4{0.0, 0.0, 0.0, 0.0}, acc1 = hm_d4{0.0, 0.0, 0.0, 0.0};
+            if (two) {
 #pragma unroll
-            for (int kk = 0; kk < NK; ++kk) {
-                const double b = ui[4 * kk * LDU] * uj[4 * kk * LDU];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], b, acc, 0, 0, 0);
+                for (int kk = 0; kk < NK; ++kk) {
+                    const int o = 4 * kk * LDU;
+                    const double b0 = u0i[o] * u0j[o], b1 = u1i[o] * u1j[o];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], b1, acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) {
+                    const int o = 4 * kk * LDU;
+                    const double b0 = u0i[o] * u0j[o];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], b0, acc0, 0, 0, 0);
+                }
             }
-        };
-        if (q >= mt.ns_tiles) tile(am);
-        else tile(ap);
-        const int idx = valid ? i * (i + 1) / 2 + j : NPS - 1;
-        const double dg = (valid && i == j) ? 1.0 : 0.0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) Mp[(g + 4 * p) * NPS + idx] = acc[p] + dg;
-    }
+            for (int p = 0; p < 4; ++p) Mp[(g + 4 * p) * NPS + x0] = acc0[p] + g0;
+            if (two) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Mp[(g + 4 * p) * NPS + x1] = acc1[p] + g1;
+            }
+        }
+    };
+    phase1(0, ns_tiles, ap);
+    phase1(ns_tiles, n_tiles, am);
     __syncthreads();
-    // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps, lane <-> row, SPP segments side by side ----
+    stamp(1);
+    // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps, lane <-> row, SPP segments side by side.  Sweep k: every
+    // lane hands its entry of column k (= row k, the matrix stays symmetric) to the others through `xs`; the lane that
+    // holds row k hands over 1 / pivot instead.  Rows beyond the rank idle.  A sweep is one dependent chain (column
+    // out through LDS, back in, row update, the next pivot's reciprocal): ~700 cycles for ~50 instructions
+    // (tools/lr_phase_clock.py); measured alternatives, all slower: the passes of a wave interleaved (two chains in
+    // flight: the register file does not hold two rows per lane plus the column entries in flight, 3x slower with the
+    // spills), blocks of four pivots (a quarter of the LDS round trips, but the 4 x 4 pivot block inverted by every
+    // lane and four dependent FMAs per entry: 1.6x slower), eight waves per workgroup (one pass each: faster alone,
+    // slower when the chip is full). ----
     {
-        constexpr int LPS = RC <= 16 ? 16 : 32, SPP = 64 / LPS;
+        constexpr int LPS = RC <= 16 ? 16 : 32, SPP = 64 / LPS, NPASS = 16 / SPP;
         const int sl = lane / LPS, row = lane % LPS;
         const bool rowok = row < r;
-        double* xs = xb + sl * LPS;
-        for (int P = wid; P < 16 / SPP; P += NW) {
+        for (int P = wid; P < NPASS; P += NW) {
             int rowv = row;  // opaque per pass: the packed indices of a row are not worth 2 RC registers across passes
             asm volatile("" : "+v"(rowv));
-            const int seg = P * SPP + sl;
-            double* Ms = Mp + seg * NPS;
+            double* Ms = Mp + (P * SPP + sl) * NPS;
+            double* xs = xb + sl * LPS;
             double a[RC];
 #pragma unroll
-            for (int j = 0; j < RC; ++j) {
+            for (int j = 0; j < RC; ++j) {  // (no branches: rows / columns beyond the rank read the zero slot)
                 const int hi = rowv > j ? rowv : j, lo = rowv > j ? j : rowv;
-                a[j] = (rowok && j < r) ? Ms[hi * (hi + 1) / 2 + lo] : 0.0;
+                a[j] = Ms[(rowok && j < r) ? hi * (hi + 1) / 2 + lo : NPZ];
             }
+            double nd = lr_rcp(a[0]);
 #pragma unroll
             for (int k = 0; k < RC; ++k) {
                 if (k < r) {
-                    xs[row] = a[k];  // column k = row k (symmetric): every lane contributes its entry
+                    xs[row] = row == k ? nd : a[k];
                     tri_wave_order();
-                    const double dinv = lr_rcp(xs[k]);
+                    const double dinv = xs[k];
                     const double f = row == k ? 1.0 - dinv : a[k] * dinv;
 #pragma unroll
-                    for (int j = 0; j < RC; j += 2) {
-                        if (j < r) {
-                            const double2 pv = *reinterpret_cast<const double2*>(xs + j);
-                            a[j] = fma(-f, pv.x, a[j]);
-                            if (j + 1 < RC) a[j + 1] = fma(-f, pv.y, a[j + 1]);
+                    for (int j0 = 0; j0 < RC; j0 += 8) {
+                        if (j0 < r) {
+#pragma unroll
+                            for (int j = j0; j < j0 + 8 && j < RC; j += 2) {
+                                const double2 pv = *reinterpret_cast<const double2*>(xs + j);
+                                a[j] = fma(-f, pv.x, a[j]);
+                                if (j + 1 < RC) a[j + 1] = fma(-f, pv.y, a[j + 1]);
+                            }
                         }
                     }
                     a[k] = row == k ? -dinv : f;
+                    if (k + 1 < RC) nd = lr_rcp(a[k + 1]);
                     tri_wave_order();
                 }
             }
             // a = -(M^-1)[row][:]; stored with the off-diagonal entries doubled: the contraction runs over i >= j
-            if (rowok) {
+            const int base = rowv * (rowv + 1) / 2;
 #pragma unroll
-                for (int j = 0; j < RC; ++j)
-                    if (j <= rowv) Ms[rowv * (rowv + 1) / 2 + j] = j == rowv ? -a[j] : -2.0 * a[j];
-            }
+            for (int j = 0; j < RC; ++j)  // (no branches: the upper half and the idle rows go to the trash slot)
+                if (j < r) Ms[(rowok && j <= rowv) ? base + j : NPZ + 1] = j == rowv ? -a[j] : -2.0 * a[j];
         }
     }
     __syncthreads();
+    stamp(2);
     // ---- phase 3: < M^-1, U' diag(wt d) U > and < M^-1, Ud' diag(wt) U + U' diag(wt) Ud > ----
     double ts[4] = {0.0, 0.0, 0.0, 0.0}, cs[4] = {0.0, 0.0, 0.0, 0.0};
     weights();
     dsum += __shfl_xor(dsum, 16, 64);
     dsum += __shfl_xor(dsum, 32, 64);
-    for (int q = wid; q < mt.n_tiles; q += NW) {
+    for (int q = wid; q < n_tiles; q += NW) {
         const unsigned code = pairs_e[q * 16 + c];
         const bool valid = code != 0xffffu;
         const int i = valid ? (int)(code >> 8) : r, j = valid ? (int)(code & 255u) : r;
@@ -391,9 +456,9 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                 accD = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], pd, accD, 0, 0, 0);
             }
         };
-        if (q >= mt.ns_tiles) tile(am, bm);
+        if (q >= ns_tiles) tile(am, bm);
         else tile(ap, bp);
-        const int idx = valid ? i * (i + 1) / 2 + j : NPS - 1;
+        const int idx = valid ? i * (i + 1) / 2 + j : NPZ;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const double m = Mp[(g + 4 * p) * NPS + idx];
@@ -431,4 +496,5 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
         out_tr = tA;
         out_cs = cv;
     }
+    stamp(3);
 }
