@@ -232,7 +232,8 @@ def main():
              ("prior", _lib.PROF_PRIOR), ("estep_ra16", _lib.PROF_ESTEP_RA16), ("estep_ra24", _lib.PROF_ESTEP_RA24),
              ("estep_ra32", _lib.PROF_ESTEP_RA32), ("estep_long", _lib.PROF_ESTEP_LONG),
              ("estep_generic", _lib.PROF_ESTEP_GENERIC), ("estep_pass", _lib.PROF_ESTEP_PASS),
-             ("estep_factor", _lib.PROF_ESTEP_FACTOR), ("estep_mean", _lib.PROF_ESTEP_MEAN))
+             ("estep_factor", _lib.PROF_ESTEP_FACTOR), ("estep_mean", _lib.PROF_ESTEP_MEAN),
+             ("hstep_lr", _lib.PROF_HSTEP_LR), ("hstep_tab", _lib.PROF_HSTEP_TAB))
     prof_live = {k: eng.profile_get(i) for k, i in kinds}
     # Kernel-timing pass.  In the timed region the M-step lane runs beside the H-step rounds: a HIP-event pair
     # then brackets the dispatch arbitration between the two lanes as well as the kernel (both lanes are
@@ -266,6 +267,7 @@ def main():
     omega = np.array(sess.params["omega"]).tolist()
     ranks_used = [int(r) for r in eng.prior_ranks(cfg["window"])]
     transport = eng.transport
+    hstat = [float(v) for v in eng.hstep_stats()]
     sess.close()
 
     if rank != 0:
@@ -366,9 +368,39 @@ def main():
             flops_per_launch_executed=fl, bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_h / n_h,
             pmc_key=hname, per_step_ms=ms_h / k_steps,
             avg_ms_overlapped=(prof_live["hstep"][1] / prof_live["hstep"][0]) if prof_live["hstep"][0] else None,
-            note="algorithmic count M (T^3 + 4 T^2) per evaluation (SURVEY 8d); the matrix-pipe kernel issues 78 "
-                 "v_mfma_f64_16x16x4 = 160 kflop per segment plus the panel eliminations; latency-bound: launch time = "
-                 "generations of 4096 resident waves x wave lifetime (~30 us)")
+            note="dense round (evaluations whose kernel matrix has numerical rank > 32): algorithmic count "
+                 "M (T^3 + 4 T^2) per evaluation (SURVEY 8d); the matrix-pipe kernel issues 78 "
+                 "v_mfma_f64_16x16x4 = 160 kflop per segment plus the panel eliminations")
+    n_l, ms_l, u_l = prof["hstep_lr"]
+    if n_l:
+        # the low-rank round: SURVEY 8(d)'s count M (T^3 + 4 T^2) is what the REFERENCE's algorithm needs per evaluation
+        # and stays the "algorithmic" figure; what the kernel executes is the Woodbury form at the numerical rank r of
+        # the kernel matrix: three pair-GEMMs (r (r + 1) / 2 columns x ceil(T / 2) depth, 2 flop per multiply-add) and
+        # a symmetric Gauss-Jordan inverse (r^3 multiply-adds in the lane-per-row layout) per segment
+        hs = hstat
+        r_mean = hs[1] / hs[0] if hs[0] else 0.0
+        nt = (T + 1) // 2
+        exe_seg = 3 * (r_mean * (r_mean + 1) / 2) * nt * 2 + 2 * r_mean ** 3
+        fl = work["hstep_flops_per_seg_eval"] * u_l / n_l
+        lname = "hstep_round_lr<%d, 4, RC>" % (50 if T <= 50 else 64)
+        kernels[lname] = entry(
+            n_l, ms_l, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_l / n_l,
+            flops_per_launch_executed=exe_seg * u_l / n_l, flops_per_launch_survey_count=fl,
+            achieved_executed=exe_seg * u_l / n_l / (ms_l / n_l * 1e-3) / 1e12,
+            frac_executed=exe_seg * u_l / n_l / (ms_l / n_l * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            mean_predicted_rank=r_mean, low_rank_evaluations=hs[0], dense_evaluations=hs[2], reruns=hs[3],
+            bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_l / n_l,
+            pmc_key="hstep_round_lr<", per_step_ms=ms_l / k_steps,
+            avg_ms_overlapped=(prof_live["hstep_lr"][1] / prof_live["hstep_lr"][0]) if prof_live["hstep_lr"][0] else None,
+            note="exact low-rank (Woodbury) round, hstep_lr.h: `achieved` / `frac` price the launch at SURVEY 8(d)'s "
+                 "count M (T^3 + 4 T^2) (the work of the reference's algorithm, which this kernel replaces); "
+                 "`achieved_executed` / `frac_executed` at the flops the low-rank form issues at the mean rank")
+        n_t, ms_t, u_t = prof["hstep_tab"]
+        if n_t:
+            kernels["hstep_lr_tables"] = {"launches": n_t, "avg_ms": ms_t / n_t, "total_ms": ms_t,
+                                          "per_step_ms": ms_t / k_steps,
+                                          "note": "pivoted Cholesky + omega-tangent of the folded kernel blocks, one block "
+                                                  "per evaluation, in front of every low-rank round"}
     n_p, ms_p, u_p = prof["prior"]
     if n_p:
         kernels["ichol_exact_kernel"] = {"launches": n_p, "avg_ms": ms_p / n_p, "total_ms": ms_p,
@@ -392,7 +424,9 @@ def main():
                     "hbm_gbs": kd.get("hbm_gbs"), "hbm_frac": kd.get("hbm_frac"),
                     "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"],
                     "units_per_launch": kd["units_per_launch"],
-                    "algorithmic_flops_per_launch": kd["flops_per_launch_executed"],
+                    "algorithmic_flops_per_launch": kd.get("flops_per_launch_survey_count", kd["flops_per_launch_executed"]),
+                    "executed_flops_per_launch": kd["flops_per_launch_executed"],
+                    "frac_executed": kd.get("frac_executed"),
                     "avg_launch_ms_overlapped_in_timed_region": kd.get("avg_ms_overlapped"),
                     "timing": kernel_timing,
                     "traffic_source": "replayed from the committed rocprofv3 --pmc passes of this command "
@@ -423,7 +457,10 @@ def main():
             "kernel_ms_per_step_beside_m_step": ms_live / args.steps,
             "non_kernel_ms_per_step": phase_ms["h"] - ms_live / args.steps,
             "non_kernel_us_per_round": 1e3 * (phase_ms["h"] - ms_live / args.steps) / max(n_live / args.steps, 1e-9),
-        })(prof_live["hstep"][0], prof_live["hstep"][1], (prof["hstep"][1] / prof["hstep"][0]) if prof["hstep"][0] else 0.0),
+        })(prof_live["hstep"][0] + prof_live["hstep_lr"][0],
+           prof_live["hstep"][1] + prof_live["hstep_lr"][1] + prof_live["hstep_tab"][1],
+           ((prof["hstep"][1] + prof["hstep_lr"][1] + prof["hstep_tab"][1]) / (prof["hstep"][0] + prof["hstep_lr"][0]))
+           if prof["hstep"][0] + prof["hstep_lr"][0] else 0.0),
         "effective_rank": ranks_used, "effective_rank_per_step": ranks_per_step, "omega_final": omega,
     }
     if not args.no_cpu_baseline and world == 1:

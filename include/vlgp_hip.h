@@ -228,7 +228,10 @@ int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n);
 #define VLGP_PROF_ESTEP_PASS 9     /* split E-step: one (T x N) pass over all rows (sampled: one sweep per call) */
 #define VLGP_PROF_ESTEP_FACTOR 10  /* split E-step: factor + variance launch, units = (unit, latent) tasks */
 #define VLGP_PROF_ESTEP_MEAN 11    /* split E-step: mean-update launch, units = (unit, latent) tasks */
-#define VLGP_PROF_KINDS 12
+#define VLGP_PROF_HSTEP_LR 12      /* H-step: the low-rank round kernel (hstep_round_lr), units = segment-evaluations;
+                                    * kind 2 then counts only the dense round kernel */
+#define VLGP_PROF_HSTEP_TAB 13     /* H-step: the tables kernel in front of a low-rank round, units = evaluations */
+#define VLGP_PROF_KINDS 14
 int vlgp_profile_enable(vlgp_ctx* ctx, int on);
 int vlgp_profile_reset(vlgp_ctx* ctx);
 /* launches, total milliseconds and work units recorded for `kind` since the last
@@ -262,6 +265,10 @@ int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
 #define VLGP_PATH_HSTEP_GENERIC 4  /* generic kernels (any window; the reference's omega retry) */
 #define VLGP_PATH_HSTEP_OLD 5      /* round-1 kernels behind their debug switches */
 int vlgp_debug_last_hstep_path(vlgp_ctx* ctx, int* path);
+/* Counters of the H-step objective calls since the handle was created: out[0] evaluations that took the low-rank round,
+ * out[1] the sum of their predicted ranks (even + odd block), out[2] evaluations that took the dense round,
+ * out[3] low-rank rounds re-run densely because a rank exceeded the prediction. */
+int vlgp_debug_hstep_stats(vlgp_ctx* ctx, double out[4]);
 
 #ifdef __cplusplus
 }

@@ -1182,6 +1182,13 @@ extern "C" int vlgp_debug_last_hstep_path(vlgp_ctx* ctx, int* path) {
     return VLGP_OK;
 }
 
+extern "C" int vlgp_debug_hstep_stats(vlgp_ctx* ctx, double out[4]) {
+    NEED_CTX(ctx);
+    if (!out) return vlgp_fail(ctx, VLGP_ERR_ARG, "null out");
+    for (int i = 0; i < 4; ++i) out[i] = ctx->hstat[i];
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const double* b, double* out) {
     NEED_CTX(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));

@@ -113,6 +113,7 @@ struct vlgp_ctx {
     struct LrThr { int T; double dt, tol; std::vector<double> om; };
     std::vector<LrThr> lr_thr;
     int last_hstep_path = 0;      // VLGP_PATH_HSTEP_* of the most recent H-step objective call
+    double hstat[4] = {0.0, 0.0, 0.0, 0.0};  // vlgp_debug_hstep_stats
 
     // profiling
     bool prof_on = false;

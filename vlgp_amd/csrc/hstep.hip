@@ -1898,8 +1898,14 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // (Measured: the tables built by blocks of the round kernel itself, the segment blocks waiting on a flag,
                 // is SLOWER than this extra launch -- 57 against 26 + 12 us for one evaluation: the waiting blocks fill
                 // the chip before the table blocks finish.)
+                vlgp_prof_begin(ctx, VLGP_PROF_HSTEP_TAB);
                 hipLaunchKernelGGL(hstep_lr_tables, dim3(n_eval), dim3(128), 0, ctx->stream, R);
+                vlgp_prof_end(ctx, VLGP_PROF_HSTEP_TAB, (double)n_eval);
                 HIPCHK(ctx, hipGetLastError());
+                ctx->hstat[0] += n_eval;
+                for (int e = 0; e < n_eval; ++e) ctx->hstat[1] += rcap[e];
+            } else if (mfma) {
+                ctx->hstat[2] += n_eval;
             }
             ctx->last_hstep_path = lr ? VLGP_PATH_HSTEP_LOWRANK : (mfma ? VLGP_PATH_HSTEP_DENSE : VLGP_PATH_HSTEP_OLD);
             // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
@@ -1907,7 +1913,8 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             // device all-reduce and a copy instead
             const bool mailbox = ctx->world == 1 || ctx->hx != nullptr;
             R.host = mailbox ? ctx->d_hres : nullptr;
-            vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
+            const int prof_kind = lr ? VLGP_PROF_HSTEP_LR : VLGP_PROF_HSTEP;
+            vlgp_prof_begin(ctx, prof_kind);
             if (padded)
                 hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
             else if (lean)
@@ -1966,7 +1973,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             else
                 hipLaunchKernelGGL((hstep_round_mfma<64, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
                                    ctx->stream, R);
-            vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
+            vlgp_prof_end(ctx, prof_kind, (double)n_eval * M);
             HIPCHK(ctx, hipGetLastError());
             if (mailbox) {
                 volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->h_hres + 48);
@@ -1994,6 +2001,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             lr_over = lr_over || hres[2 * n_eval + e] == 2.0;
         }
         // a rank beyond the host's prediction (never seen; the prediction runs at half the tolerance): dense round
+        if (all_ok && lr_over) ctx->hstat[3] += 1.0;
         if (all_ok && lr_over) return launch_hstep_impl(ctx, us, window, dt, n_eval, latent, logp, ll, dll, true);
         if (all_ok) {
             for (int e = 0; e < n_eval; ++e) {

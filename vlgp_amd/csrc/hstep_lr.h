@@ -71,6 +71,26 @@ __device__ __forceinline__ double lr_rcp(double x) {  // 1 / x for x >= 1 (no de
     return y;
 }
 
+// Wave-wide maximum, the same value in every lane.  Four row_shr steps on the DPP path leave the maximum of each row
+// of sixteen lanes in its last lane (a lane without a source keeps its own value); the four row results meet through
+// v_readlane.  About 100 cycles against ~400 for six ds_bpermute rounds: the pivot search is on the critical chain
+// of every step of the factorisation below.
+__device__ __forceinline__ double lr_wave_max(double v) {
+    union { double d; int i[2]; } a, b;
+#define LR_DPP_STEP(ctrl)                                                          \
+    a.d = v;                                                                       \
+    b.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], ctrl, 0xf, 0xf, false);   \
+    b.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], ctrl, 0xf, 0xf, false);   \
+    v = fmax(v, b.d);
+    LR_DPP_STEP(0x111)  // row_shr:1
+    LR_DPP_STEP(0x112)  // row_shr:2
+    LR_DPP_STEP(0x114)  // row_shr:4
+    LR_DPP_STEP(0x118)  // row_shr:8
+#undef LR_DPP_STEP
+    const double r0 = tri_readlane(v, 15), r1 = tri_readlane(v, 31), r2 = tri_readlane(v, 47), r3 = tri_readlane(v, 63);
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tables of one evaluation: pivoted Cholesky of the even and of the odd block of K_0 = exp(-omega D^2) (one wave
 // each, lane <-> folded time row, factor columns in registers, pivot row entries by v_readlane), differentiated
@@ -131,9 +151,7 @@ __device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, doub
     }
     int r = 0;
     auto wave_argmax = [&](double& bv, int& bi) {  // largest residual diagonal, lowest lane on ties; branch-free
-        bv = d;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) bv = fmax(bv, __shfl_xor(bv, o, 64));
+        bv = lr_wave_max(d);
         const unsigned long long m = __ballot(d == bv);
         bi = m ? __builtin_ctzll(m) : 0;
     };
@@ -204,16 +222,17 @@ __device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, doub
     const int rt = re + ro;
     const int n_ee = re * (re + 1) / 2, n_oo = ro * (ro + 1) / 2;
     const int ns16 = (n_ee + n_oo + 15) & ~15, nc16 = (re * ro + 15) & ~15;
-    for (int x = threadIdx.x; x < rt * rt; x += NT) {
-        const int i = x / rt, j = x - i * rt;
-        if (j > i) continue;
-        const bool io = i >= re, jo = j >= re;
-        int pos;
-        if (io == jo)
-            pos = io ? n_ee + (i - re) * (i - re + 1) / 2 + (j - re) : i * (i + 1) / 2 + j;
-        else
-            pos = ns16 + (i - re) * re + j;  // i odd block, j even block
-        pairs[pos] = (unsigned short)((i << 8) | j);
+    for (int i = par; i < rt; i += NT / 64) {  // row i by wave, column j by lane (no integer divisions)
+        const int j = lane;
+        if (j <= i) {
+            const bool io = i >= re, jo = j >= re;
+            int pos;
+            if (io == jo)
+                pos = io ? n_ee + (i - re) * (i - re + 1) / 2 + (j - re) : i * (i + 1) / 2 + j;
+            else
+                pos = ns16 + (i - re) * re + j;  // i odd block, j even block
+            pairs[pos] = (unsigned short)((i << 8) | j);
+        }
     }
     if (threadIdx.x == 0) {
         LrMeta m;

@@ -351,6 +351,12 @@ class Engine:
         self._ck(self.lib.vlgp_debug_last_hstep_path(self.h, C.byref(p)))
         return _lib.HSTEP_PATHS[p.value]
 
+    def hstep_stats(self):
+        """(low-rank evaluations, sum of their predicted ranks, dense evaluations, low-rank rounds re-run densely)."""
+        out = np.zeros(4)
+        self._ck(self.lib.vlgp_debug_hstep_stats(self.h, dptr(out)))
+        return out
+
     def profile_get(self, kind):
         n, ms, units = C.c_int64(0), C.c_double(0), C.c_double(0)
         self._ck(self.lib.vlgp_profile_get(self.h, int(kind), C.byref(n), C.byref(ms), C.byref(units)))
