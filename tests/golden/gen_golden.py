@@ -36,6 +36,9 @@ from vlgp.util import cut_trials  # noqa: E402
 
 from vlgp_amd import synth  # noqa: E402
 
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import golden_cases  # noqa: E402
+
 
 def _solve(a, b, sym_pos=False, **kw):
     if sym_pos:
@@ -473,9 +476,75 @@ def gen_init():
          mu=np.stack([t["mu"] for t in trials]), x_shape=np.array(trials[0]["x"].shape))
 
 
+def gen_branches():
+    """The branches the default configuration never takes (vlgp/core.py:366-416 constrain_loading / constrain_latent,
+    window != 50, all-Gaussian channels, history = 2): `fit` of the real reference on the seeded problems of
+    tests/golden_cases.py with a, b, mu injected; and api.transform (vlgp/api.py:171-184) on new trials."""
+    out = {}
+    for name in golden_cases.CASES:
+        fresh, a0, b0, lik, dims, history, run = golden_cases.case_inputs(name)
+        trials = fresh()
+        np.random.seed(1)  # initialize() draws the FactorAnalysis subsample (its result is overridden by a, b, mu)
+        kw = dict(a=a0.copy(), b=b0.copy(), lik=lik, **run)
+        if history:
+            kw["history"] = history
+        res = ref_api.fit(trials, dims[3], **kw)
+        p = res["params"]
+        for k in ("a", "b", "noise", "omega", "sigma"):
+            out["%s__%s" % (name, k)] = np.asarray(p[k])
+        out[name + "__it"] = res["config"]["runtime"]["it"]
+        out[name + "__G_rows"] = p["cholesky"][dims[1]][:, ::10]  # every tenth bin of the full-length factors
+        for k in ("mu", "v"):  # first and last trial (the fixture stays small)
+            out["%s__%s" % (name, k)] = np.stack([res["trials"][i][k] for i in (0, -1)])
+        print("  branch %-16s it %d omega %s" % (name, out[name + "__it"], np.array2string(p["omega"], precision=4)))
+    # transform: fit (FactorAnalysis initialisation, seeded) then infer new trials of a length the fit knows
+    fresh, a0, b0, lik, dims = golden_cases.small_problem(seed=7, n_trials=5, n_bins=100, N=12)
+    np.random.seed(2)
+    res = ref_api.fit([{"ID": t["ID"], "y": t["y"]} for t in fresh()], dims[3], max_iter=3, min_iter=3)
+    p, cfg = res["params"], res["config"]
+    new = synth.make_trials(3, 100, 12, dims[3], seed=8)
+    np.random.seed(3)
+    got = ref_api.transform([{"ID": t["ID"], "y": t["y"].copy()} for t in new], p, cfg)
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        out["transform__" + k] = np.asarray(p[k])
+    out["transform__G"] = p["cholesky"][100]
+    out["transform__max_iter"] = cfg["max_iter"]
+    out["transform__mu0"] = np.stack([p["transform"](t["y"]) for t in new])
+    for k in ("mu", "v", "w"):
+        out["transform__" + k] = np.stack([t[k] for t in got])
+    save("branches", **out)
+
+
+def gen_mstep_singular():
+    """core.mstep's fallback when the Newton system of a channel does not factor (vlgp/core.py:191-198)."""
+    d = golden_cases.singular_mstep_inputs()
+    T, N = d["y"].shape
+    L = d["mu"].shape[1]
+    out = {}
+    for n_it in (1, 3):
+        units = [{"y": d["y"].copy(), "x": d["x"].copy(), "mu": d["mu"].copy(), "v": d["v"].copy()}]
+        params = {"ydim": N, "zdim": L, "xdim": 1, "a": d["a"].copy(), "b": d["b"].copy(), "noise": np.ones(N),
+                  "likelihood": np.array(["poisson"] * N), "rank": 50, "gp_noise": 1e-4, "dt": 1,
+                  "sigma": np.ones(L), "omega": np.full(L, 5e-3)}
+        fill_params(params)
+        cfg = get_config(Mniter=n_it, eps=0.0, learning_rate=d["lr"])
+        core.mstep(units, params, cfg)
+        for k in ("a", "b", "da", "db", "noise"):
+            out["%s_%d" % (k, n_it)] = params[k]
+    # the solve really failed: the delta is learning_rate * grad for every channel at the first iteration
+    mu, v, y, a, b = d["mu"], d["v"], d["y"], d["a"], d["b"]
+    r = np.exp(mu @ a + b + 0.5 * v @ a ** 2)
+    grad = np.stack([mu.T @ y[:, n] - (mu + v * a[:, n]).T @ r[:, n] for n in range(N)], axis=1)
+    assert np.allclose(out["da_1"], np.clip(d["lr"] * grad, -5, 5), rtol=1e-12, atol=0), "the Newton solve did not fail"
+    save("mstep_singular", **out)
+
+
+ALL = ["ichol", "estep", "mstep", "mstep_singular", "hstep", "vem", "fit", "init", "fit_h1", "branches", "result",
+       "vem_c2", "vem_c3"]
+
 if __name__ == "__main__":
     os.chdir("/tmp")  # the reference writes vlgp.log into the cwd at import
     check_generator()
-    todo = sys.argv[1:] or ["ichol", "estep", "mstep", "hstep", "vem", "fit", "init", "fit_h1"]
+    todo = sys.argv[1:] or ALL  # a bare run regenerates EVERY fixture (vem_c3 last: a quarter of an hour)
     for name in todo:  # `gen_golden.py fit_h1` regenerates one fixture
         globals()["gen_" + name]()

@@ -267,3 +267,71 @@ def test_command_line_fit_and_result_file(V, tmp_path):
     want = V.fit([{"ID": t["ID"], "y": t["y"].copy()} for t in trials], 2, max_iter=3, min_iter=3, verbose=False)
     assert np.array_equal(res["params"]["a"], want["params"]["a"])
     assert np.array_equal(np.stack([t["mu"] for t in res["trials"]]), np.stack([t["mu"] for t in want["trials"]]))
+
+
+# ---- the same branches against the REAL reference (tests/golden/branches.npz, generated by gen_golden.py) ----
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))  # golden_cases
+import golden_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(golden_cases.CASES))
+def test_branches_against_reference_golden(V, golden, name):
+    """`fit` on the HIP path against `fit` of the real reference for every constrain_loading / constrain_latent mode
+    (vlgp/core.py:366-416), windows 25 / 40 / 100 (the generic, the padded and the long-window H-step kernels),
+    all-Gaussian channels and history = 2.  1e-6 as SURVEY 8(c) states for multi-iteration runs; window 25: 1e-5
+    (one latent's L-BFGS-B line search ends on rounding noise: the oracle itself is 4e-6 off the reference there,
+    tests/test_oracle_golden.py)."""
+    g = golden("branches")
+    fresh, a0, b0, lik, dims, history, run = golden_cases.case_inputs(name)
+    kw = dict(a=a0.copy(), b=b0.copy(), lik=lik, verbose=False, **run)
+    if history:
+        kw["history"] = history
+    got = V.fit(fresh(), dims[3], **kw)
+    assert got["config"]["runtime"]["it"] == int(g[name + "__it"])
+    tol = 1e-5 if name == "window_25" else TRAJ
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert relerr(got["params"][k], g["%s__%s" % (name, k)]) < tol, k
+    G = got["params"]["cholesky"][dims[1]]
+    if np.array_equal(G[:, ::10], g[name + "__G_rows"]):  # same pivots in the full-length factors
+        for k in ("mu", "v"):
+            assert relerr(np.stack([got["trials"][i][k] for i in (0, -1)]), g["%s__%s" % (name, k)]) < 1e-5, k
+
+
+def test_transform_against_reference_golden(V, golden):
+    """api.transform (vlgp/api.py:171-184) with the reference's own fitted parameters and prior factors: the
+    posterior of three new trials against what the reference's transform returned."""
+    from vlgp_amd import synth
+
+    g = golden("branches")
+    N, L, T = 12, 3, 100
+    new = synth.make_trials(3, T, N, L, seed=8)
+    params = {"ydim": N, "zdim": L, "xdim": 1, "rank": 50, "gp_noise": 1e-4, "dt": 1,
+              "a": g["transform__a"].copy(), "b": g["transform__b"].copy(), "noise": g["transform__noise"].copy(),
+              "omega": g["transform__omega"].copy(), "sigma": g["transform__sigma"].copy(),
+              "likelihood": np.array(["poisson"] * N), "cholesky": {T: g["transform__G"].copy()},
+              "transform": lambda y: (_ for _ in ()).throw(AssertionError("mu is given"))}
+    config = V.get_config(max_iter=int(g["transform__max_iter"]))
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": g["transform__mu0"][i].copy()} for i, t in enumerate(new)]
+    got = V.transform(trials, params, config)
+    for k in ("mu", "v", "w"):
+        assert relerr(np.stack([t[k] for t in got]), g["transform__" + k]) < STAGE, k
+
+
+@pytest.mark.parametrize("n_it", [1, 3])
+def test_mstep_gradient_step_when_the_newton_system_is_singular(V, golden, n_it):
+    """core.mstep's fallback (vlgp/core.py:191-198): a channel whose Hessian does not factor takes the step
+    learning_rate * grad.  Third latent mu = v = 0, jitter 0 -> a zero pivot in every Poisson channel."""
+    d = golden_cases.singular_mstep_inputs()
+    g = golden("mstep_singular")
+    T, N = d["y"].shape
+    L = d["mu"].shape[1]
+    units = [{"y": d["y"].copy(), "x": d["x"].copy(), "mu": d["mu"].copy(), "v": d["v"].copy(),
+              "w": np.zeros((T, L)), "dmu": np.zeros((T, L))}]
+    params = {"ydim": N, "zdim": L, "xdim": 1, "rank": 50, "a": d["a"].copy(), "b": d["b"].copy(), "noise": np.ones(N),
+              "likelihood": np.array(["poisson"] * N), "gp_noise": 1e-4, "dt": 1}
+    V.mstep(units, params, V.get_config(Mniter=n_it, eps=0.0, learning_rate=d["lr"]))
+    for k in ("a", "b", "da", "db", "noise"):
+        assert relerr(params[k], g["%s_%d" % (k, n_it)]) < STAGE, k

@@ -8,8 +8,13 @@ import numpy as np
 import pytest
 from scipy.linalg import toeplitz
 
+import os
+import sys
+
 from conftest import relerr
 from oracle import vlgp_oracle as O
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # golden_cases
 
 STAGE_TOL = 1e-12
 
@@ -147,3 +152,82 @@ def test_fit_golden(golden):
         assert relerr(np.stack([t[k] for t in trials]), g[k]) < STAGE_TOL
     assert relerr(params["a"], g["a"]) < STAGE_TOL
     assert np.array_equal(params["cholesky"][200], g["G200"])
+
+
+# ---- the non-default branches, pinned to the real reference (tests/golden/branches.npz, tests/golden_cases.py) ----
+def _oracle_branch_fit(name):
+    import golden_cases
+
+    fresh, a0, b0, lik, dims, history, run = golden_cases.case_inputs(name)
+    n_trials, n_bins, N, L = dims
+    ref = fresh()
+    xdim = max(history, 1)
+    for t in ref:
+        t["x"] = np.ones((n_bins, xdim, N))
+        t["w"] = np.zeros((n_bins, L))
+        t["v"] = np.zeros((n_bins, L))
+    cfg = O.make_config(**run)
+    params = O.make_params(ref, L, a=a0.copy(), b=b0.copy(), lik=lik, history=history, omega_bound=cfg["omega_bound"])
+    O.fit_given_init(ref, params, cfg)
+    return ref, params, cfg, dims
+
+
+BRANCHES = ["loading_svd", "loading_1", "loading_2", "loading_inf", "loading_off", "latent_location", "latent_scale",
+            "latent_both", "svd_and_both", "window_25", "window_40", "window_100", "all_gaussian", "history_2"]
+
+
+@pytest.mark.parametrize("name", BRANCHES)
+def test_branches_golden(golden, name):
+    """core.constrain_loading / constrain_latent in every mode (vlgp/core.py:366-416), windows 25 / 40 / 100,
+    all-Gaussian channels and history = 2: `fit` of the oracle against `fit` of the real reference."""
+    g = golden("branches")
+    ref, params, cfg, dims = _oracle_branch_fit(name)
+    assert cfg["runtime"]["it"] == int(g[name + "__it"])
+    # through L-BFGS-B: 1e-9 (measured 1e-14 ... 1e-11).  Two stated exceptions: at window 25 one latent's line search
+    # ends one evaluation apart (SciPy stops on a relative decrease of 2.2e-9 of the objective, which pins omega to a
+    # few 1e-6 at best; measured 4.4e-6 on omega, 6e-7 on a); with history = 2 the two regressors are both columns of
+    # ones, the 2 x 2 Newton system of b is singular up to the 1e-8 jitter and LAPACK's posv (the reference, through
+    # the sym_pos shim) and potrf + potrs (the oracle) differ by 6e-8 on b
+    tol = {"window_25": {"omega": 1e-5, "a": 1e-5, "b": 1e-5, "noise": 1e-5}, "history_2": {"b": 1e-6}}.get(name, {})
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert relerr(params[k], g["%s__%s" % (name, k)]) < tol.get(k, 1e-9), k
+    G = params["cholesky"][dims[1]]
+    if np.array_equal(G[:, ::10], g[name + "__G_rows"]):  # same pivots -> the end-to-end posterior is comparable
+        for k in ("mu", "v"):
+            assert relerr(np.stack([ref[i][k] for i in (0, -1)]), g["%s__%s" % (name, k)]) < (1e-4 if tol else 1e-8), k
+    else:
+        # a near-tie in the pivot search of a rank-exhausted factor (200-bin trials at rank 50) broken the other way by an
+        # omega that differs in its last digits: another, equally valid, incomplete factor (SURVEY section 7, "pivot
+        # hazard"); ichol_gauss itself is pinned bit for bit by test_ichol_golden, omega above.  Nothing to compare.
+        assert G.shape[0] == g[name + "__G_rows"].shape[0]
+
+
+def test_transform_golden(golden):
+    """api.transform (vlgp/api.py:171-184) = initialize (mu = transform(y), w = v = 0) + one core.infer."""
+    import golden_cases
+    from vlgp_amd import synth
+
+    g = golden("branches")
+    new = synth.make_trials(3, 100, 12, 3, seed=8)
+    N, L = 12, 3
+    gauss = np.zeros(N, bool)
+    for i, t in enumerate(new):
+        out = O.estep_unit(t["y"], np.ones((100, 1, N)), g["transform__mu0"][i], np.zeros((100, L)), np.zeros((100, L)),
+                           g["transform__a"], g["transform__b"], g["transform__noise"], gauss, g["transform__G"],
+                           int(g["transform__max_iter"]))
+        for k, arr in zip(("mu", "v", "w"), out):
+            assert relerr(arr, g["transform__" + k][i]) < STAGE_TOL, (k, i)
+
+
+@pytest.mark.parametrize("n_it", [1, 3])
+def test_mstep_singular_golden(golden, n_it):
+    """A Newton system that does not factor -> the gradient step learning_rate * grad (vlgp/core.py:191-198)."""
+    import golden_cases
+
+    d = golden_cases.singular_mstep_inputs()
+    g = golden("mstep_singular")
+    N = d["y"].shape[1]
+    a, b, da, db, noise = O.mstep_arrays(d["y"], d["x"], d["mu"], d["v"], d["a"].copy(), d["b"].copy(),
+                                         np.zeros(N, bool), n_it, use_hessian=True, eps=0.0, learning_rate=d["lr"])
+    for k, arr in zip(("a", "b", "da", "db", "noise"), (a, b, da, db, noise)):
+        assert relerr(arr, g["%s_%d" % (k, n_it)]) < STAGE_TOL, k
