@@ -1790,8 +1790,12 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     // the T = 50 kernels, identity-padded; below ~half the compiled size the padding costs more than the
     // generic kernels (measured: window 25 14 vs 24 ms per H-step, window 20 21 vs 13 ms)
     // windows 24..50 run the kernels compiled for 50, 51..64 those compiled for 64 (matrix-pipe round only)
+    // round 4: windows of 4 ... 23 bins take the round kernels too when the low-rank round runs (its cost follows the
+    // rank, not the compiled window; the K block pads to 50 as it always did): the generic kernels below 24 remain
+    // for the dense switches only
     const bool old_kernels = getenv("VLGP_HSTEP_UNFUSED") || getenv("VLGP_HSTEP_PADDED") || getenv("VLGP_HSTEP_LEAN");
-    const bool fast = T <= (old_kernels ? 50 : 64) && T >= 24 && !getenv("VLGP_HSTEP_GENERIC");
+    const bool lr_allowed = !old_kernels && !force_dense && !getenv("VLGP_HSTEP_DENSE") && !getenv("VLGP_HSTEP_TWOSET");
+    const bool fast = T <= (old_kernels ? 50 : 64) && T >= (lr_allowed ? 4 : 24) && !getenv("VLGP_HSTEP_GENERIC");
     const int TC = T <= 50 ? 50 : 64;  // compiled window
     const int64_t TT = fast ? (int64_t)TC * TC : (int64_t)T * T;
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
@@ -1820,6 +1824,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
         double* hres = hp + 4 * n_eval + 8;
         if (T == 50 && getenv("VLGP_HSTEP_UNFUSED")) {
+            ctx->last_hstep_path = VLGP_PATH_HSTEP_OLD;
             CHK(launch_fast<50>(ctx, F, n_eval, M));
             // red: [2 n_eval] (ll, dll) pairs, then [n_eval] "K factored" flags -> one device->host copy
             hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red,
@@ -2037,6 +2042,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
     const bool big = T > 64 && T <= 128 && !getenv("VLGP_HSTEP_GENERIC_SEG");  // hstep_prep_big / hstep_seg_big
+    ctx->last_hstep_path = big ? VLGP_PATH_HSTEP_BIG : VLGP_PATH_HSTEP_GENERIC;
     if (big) {
         const size_t lds_pb = (size_t)(4 * 64 * 66 + HmGeom<64>::TASK + 2 * 128) * 8;
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_big),
