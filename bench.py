@@ -267,6 +267,7 @@ def main():
     omega = np.array(sess.params["omega"]).tolist()
     ranks_used = [int(r) for r in eng.prior_ranks(cfg["window"])]
     transport = eng.transport
+    rccl_ranks = eng.rccl_ranks  # from ncclCommCount, not from WORLD_SIZE: what RCCL saw
     hstat = [float(v) for v in eng.hstep_stats()]
     sess.close()
 
@@ -444,7 +445,8 @@ def main():
                    "parallelism": "trials sharded over %d rank(s)%s" % (
                        world, "" if world == 1 else "; all-reduce of the M-step statistics and norms over " + transport +
                        ", H-step round sums added on the host (shared memory)"),
-                   "transport": transport, "rccl_ranks": world if transport == "rccl" else 0},
+                   "transport": transport, "rccl_ranks": int(rccl_ranks[0]), "rccl_ranks_m_lane": int(rccl_ranks[1]),
+                   "rccl_ranks_source": "ncclCommCount of the handle's communicators"},
         "ms_per_e_step": phase_ms["e"], "ms_per_m_step": phase_ms["m"], "ms_per_h_step": phase_ms["h"],
         "ms_per_step_per_rank": per_rank_ms,
         "roofline": roofline, "kernels": kernels,

@@ -205,6 +205,9 @@ int vlgp_comm_host_exchange(vlgp_ctx* ctx);
 /* Transport behind the handle's all-reduces: 0 none (single rank), 1 RCCL, 2 host shared memory
  * (VLGP_COMM_TRANSPORT=shm, a test vehicle: several ranks on one GPU). */
 int vlgp_comm_transport(vlgp_ctx* ctx);
+/* Ranks RCCL itself reports (ncclCommCount) for the handle's two communicators -- main lane and M-step lane; 0 when no
+ * RCCL communicator is attached (single rank, or the shared-memory test transport), -1 if the query failed. */
+int vlgp_comm_rccl_ranks(vlgp_ctx* ctx, int* main_lane, int* m_lane);
 /* In-place sum over ranks of n host doubles (staged through the device, on the
  * handle's stream, synchronous).  With no communicator attached it is a no-op.
  * n == 0 is a pure barrier. */

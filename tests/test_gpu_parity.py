@@ -744,6 +744,7 @@ def test_single_rank_rccl_allreduce_is_identity(V, golden, monkeypatch):
     units = [{k: g[k][m].copy() for k in ("y", "x", "mu", "v")} for m in range(M)]
     with V.Engine(20, 3, 1, 50, g["gauss"]) as eng:
         Comm(0, 1).attach(eng)
+        assert eng.transport == "rccl" and eng.rccl_ranks == (1, 1)  # ncclCommCount of both lanes' communicators
         buf = np.arange(5.0)
         eng.allreduce_host(buf)
         assert np.array_equal(buf, np.arange(5.0))

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "vlgp_sample_posterior": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _ip]),
     "vlgp_comm_host_exchange": (C.c_int, [_h]),
     "vlgp_comm_transport": (C.c_int, [_h]),
+    "vlgp_comm_rccl_ranks": (C.c_int, [_h, _ip, _ip]),
     "vlgp_project_units": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "vlgp_hstep_begin": (C.c_int, [_h, C.c_int, C.c_int]),
     "vlgp_hstep_end": (C.c_int, [_h]),

@@ -136,6 +136,7 @@ typedef int (*fn_initrank)(void**, int, rccl_uid, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(void*, int*);
 static struct {
     void* lib = nullptr;
     fn_getuid get_uid = nullptr;
@@ -143,6 +144,7 @@ static struct {
     fn_allreduce all_reduce = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
+    fn_count count = nullptr;  // ncclCommCount: what RCCL itself says the communicator spans
 } g_rccl;
 
 static int rccl_load(vlgp_ctx* ctx) {
@@ -156,6 +158,7 @@ static int rccl_load(vlgp_ctx* ctx) {
     g_rccl.all_reduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
     g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    g_rccl.count = (fn_count)dlsym(lib, "ncclCommCount");
     if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.all_reduce || !g_rccl.destroy)
         return vlgp_fail(ctx, VLGP_ERR_COMM, "librccl.so lacks an expected symbol");
     g_rccl.lib = lib;
@@ -402,6 +405,16 @@ extern "C" int vlgp_comm_init_aux(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BY
 
 extern "C" int vlgp_comm_host_exchange(vlgp_ctx* ctx) { return ctx && ctx->hx ? 1 : 0; }
 extern "C" int vlgp_comm_transport(vlgp_ctx* ctx) { return !ctx ? 0 : (ctx->comm ? 1 : (ctx->shm ? 2 : 0)); }
+
+extern "C" int vlgp_comm_rccl_ranks(vlgp_ctx* ctx, int* main_lane, int* m_lane) {
+    NEED_CTX(ctx);
+    if (!main_lane || !m_lane) return vlgp_fail(ctx, VLGP_ERR_ARG, "null out");
+    *main_lane = 0;
+    *m_lane = 0;
+    if (ctx->comm && g_rccl.count && g_rccl.count(ctx->comm, main_lane) != 0) *main_lane = -1;
+    if (ctx->comm_m && g_rccl.count && g_rccl.count(ctx->comm_m, m_lane) != 0) *m_lane = -1;
+    return VLGP_OK;
+}
 
 extern "C" int vlgp_comm_allreduce_host(vlgp_ctx* ctx, double* buf, int n) {
     NEED_CTX(ctx);

@@ -313,6 +313,13 @@ class Engine:
         """"none" (single rank), "rccl" or "shm" (the opt-in host shared-memory test transport)."""
         return ("none", "rccl", "shm")[int(self.lib.vlgp_comm_transport(self.h))]
 
+    @property
+    def rccl_ranks(self):
+        """(main lane, M-step lane): the rank counts RCCL reports for the two communicators (ncclCommCount); 0 without."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.vlgp_comm_rccl_ranks(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def allreduce_host(self, arr):
         """In-place sum over ranks of a float64 host array (no-op on one GPU)."""
         if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]):
