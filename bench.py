@@ -358,12 +358,7 @@ def main():
     n_h, ms_h, u_h = prof["hstep"]
     if n_h:
         fl = work["hstep_flops_per_seg_eval"] * u_h / n_h
-        if os.environ.get("VLGP_HSTEP_LEAN"):
-            hname = "hstep_round_lean<50>"
-        elif T <= 50:  # the instantiation that runs: one register set unless the two-set routine is forced
-            hname = "hstep_round_mfma<50, 4>" if os.environ.get("VLGP_HSTEP_TWOSET") else "hstep_round_mfma<50, 4, true>"
-        else:
-            hname = "hstep_round_mfma<64, 4>"
+        hname = "hstep_round_mfma<50, 4, true>" if T <= 50 else "hstep_round_mfma<64, 4>"
         kernels[hname] = entry(
             n_h, ms_h, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_h / n_h,
             flops_per_launch_executed=fl, bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_h / n_h,

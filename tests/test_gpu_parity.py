@@ -371,7 +371,7 @@ def test_hstep_objective_golden(V, golden):
 
 def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
     """vlgp_hstep_begin/_end only caches the second moments of mu: same numbers with and without the
-    bracket, through the three-launch form, and after the set changes inside a bracket-free sequence."""
+    bracket, through the dense and the generic kernels, and after the set changes inside a bracket-free sequence."""
     g = golden("hstep")
     M, T, L = g["mu"].shape
     rng = np.random.default_rng(5)
@@ -386,13 +386,21 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
         first = eng.hstep_objective(0, T, 1.0, lat, logp)
         again = eng.hstep_objective(0, T, 1.0, lat, logp + 0.0)
         eng.hstep_end()
-        monkeypatch.setenv("VLGP_HSTEP_UNFUSED", "1")
-        unfused = eng.hstep_objective(0, T, 1.0, lat, logp)
-        monkeypatch.delenv("VLGP_HSTEP_UNFUSED")
+        assert eng.last_hstep_path == "lowrank"
+        monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
+        dense = eng.hstep_objective(0, T, 1.0, lat, logp)
+        assert eng.last_hstep_path == "dense"
+        monkeypatch.delenv("VLGP_HSTEP_DENSE")
+        monkeypatch.setenv("VLGP_HSTEP_GENERIC", "1")
+        generic = eng.hstep_objective(0, T, 1.0, lat, logp)
+        assert eng.last_hstep_path == "generic"
+        monkeypatch.delenv("VLGP_HSTEP_GENERIC")
         for other in (first, again):
             assert np.array_equal(other[0], plain[0]) and np.array_equal(other[1], plain[1])
-        # two different factorisations of K (cond ~ 1e5): agreement to cond x eps, far inside the parity tolerance
-        assert relerr(unfused[0], plain[0]) < 1e-10 and relerr(unfused[1], plain[1]) < 1e-9
+        # three different algorithms (Woodbury form at the numerical rank, blocked elimination of the 50 x 50 matrices,
+        # the reference's literal K^-1 + W): agreement to cond(K) x eps, far inside the parity tolerance
+        assert relerr(dense[0], plain[0]) < 1e-11 and relerr(dense[1], plain[1]) < 1e-10
+        assert relerr(generic[0], plain[0]) < 1e-10 and relerr(generic[1], plain[1]) < 1e-9
         # new mu: the cached moments must not survive the upload
         for u in units:
             u["mu"] = u["mu"] + 0.1 * rng.standard_normal(u["mu"].shape)
@@ -407,38 +415,39 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
 
 
 def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
-    """The lean round kernel (no A in LDS, sliding register windows, eight waves per CU) against the padded
-    one and the three-launch form on 1203 segments (not a multiple of the four tasks of a block) and
-    curvatures spanning five decades: same (ll, dll) to rounding."""
+    """The low-rank round (one rank class per evaluation here: omega from 6e-4 to 1.5e-2), the dense matrix-pipe round
+    and the generic kernels on 1203 segments (not a multiple of the sixteen / four segments of a block) and
+    curvatures spanning five decades: same (ll, dll) to rounding; the low-rank and dense rounds repeat bit for bit."""
     rng = np.random.default_rng(8)
     M, T, L = 1203, 50, 3
     units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)),
               "w": 10.0 ** rng.uniform(-3, 2, (T, L)), "v": np.zeros((T, L))} for _ in range(M)]
     lat = np.array([0, 1, 2, 1, 0])
-    logp = np.log(np.array([[1.0, 2e-3, 1e-4], [0.8, 8e-3, 1e-4], [0.5, 4e-2, 1e-4], [1.0, 6e-4, 2e-4],
+    logp = np.log(np.array([[1.0, 2e-3, 1e-4], [0.8, 8e-3, 1e-4], [0.5, 1.5e-2, 1e-4], [1.0, 6e-4, 2e-4],
                             [0.3, 1e-2, 5e-5]]))
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
-        lean = eng.hstep_objective(0, T, 1.0, lat, logp)  # the default: matrix-pipe round, one register set
-        assert np.array_equal(lean[0], eng.hstep_objective(0, T, 1.0, lat, logp)[0])  # repeatable bit for bit
-        monkeypatch.setenv("VLGP_HSTEP_TWOSET", "1")   # two-register-set task routine (three waves per SIMD)
-        twoset = eng.hstep_objective(0, T, 1.0, lat, logp)
-        monkeypatch.delenv("VLGP_HSTEP_TWOSET")
-        monkeypatch.setenv("VLGP_HSTEP_LEAN", "1")     # round-1 register-row kernel
-        round1 = eng.hstep_objective(0, T, 1.0, lat, logp)
-        monkeypatch.delenv("VLGP_HSTEP_LEAN")
-        for other in (twoset, round1):
-            assert relerr(other[0], lean[0]) < 1e-11
-            assert relerr(other[1][:, 1], lean[1][:, 1]) < 1e-10
-        monkeypatch.setenv("VLGP_HSTEP_PADDED", "1")
-    with V.Engine(2, L, 1, 50) as eng:
-        eng.upload(0, units)
-        padded = eng.hstep_objective(0, T, 1.0, lat, logp)
-        monkeypatch.setenv("VLGP_HSTEP_UNFUSED", "1")
-        unfused = eng.hstep_objective(0, T, 1.0, lat, logp)
-    for other in (padded, unfused):
-        assert relerr(other[0], lean[0]) < 1e-10
-        assert relerr(other[1][:, 1], lean[1][:, 1]) < 1e-9
+        low = eng.hstep_objective(0, T, 1.0, lat, logp)
+        assert eng.last_hstep_path == "lowrank"
+        again = eng.hstep_objective(0, T, 1.0, lat, logp)
+        assert np.array_equal(low[0], again[0]) and np.array_equal(low[1], again[1])  # repeatable bit for bit
+        monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
+        dense = eng.hstep_objective(0, T, 1.0, lat, logp)
+        assert eng.last_hstep_path == "dense"
+        assert np.array_equal(dense[0], eng.hstep_objective(0, T, 1.0, lat, logp)[0])
+        monkeypatch.delenv("VLGP_HSTEP_DENSE")
+        monkeypatch.setenv("VLGP_HSTEP_GENERIC", "1")
+        generic = eng.hstep_objective(0, T, 1.0, lat, logp)
+        monkeypatch.delenv("VLGP_HSTEP_GENERIC")
+        # an evaluation above the rank the low-rank round takes sends the whole round to the dense kernel
+        rough = logp.copy()
+        rough[2, 1] = np.log(4e-2)
+        mixed = eng.hstep_objective(0, T, 1.0, lat, rough)
+        assert eng.last_hstep_path == "dense"
+        assert np.array_equal(mixed[0][[0, 1, 3, 4]], dense[0][[0, 1, 3, 4]])
+    for other in (dense, generic):
+        assert relerr(other[0], low[0]) < 1e-10
+        assert relerr(other[1][:, 1], low[1][:, 1]) < 1e-9
     t = np.arange(T) * 1.0
     want = O.gp_objective(logp[2], t, np.stack([u["mu"][:, 2] for u in units[:40]], 1),
                           np.stack([u["w"][:, 2] for u in units[:40]], 1))

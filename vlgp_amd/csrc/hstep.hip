@@ -588,235 +588,6 @@ struct HFastArgs {
     double* out;    // (n_eval, M, 2)
 };
 
-template <int T>
-constexpr int hstep_prep_lds() {
-    return tri_packed_size(T) > TriuOff<T>{}.v[T] ? tri_packed_size(T) : TriuOff<T>{}.v[T];
-}
-
-// One wave: K = sigma^2 exp(-omega d^2) + eps I -> K^-1, log det chol(K), first columns of K and dK.
-template <int T>
-__device__ __forceinline__ void hstep_prep_body(const HFastArgs& A, int e, int lane, double* Lp, double* kv,
-                                                double* dkv, double* Kl = nullptr) {
-    const double sigmasq = exp(A.logp[3 * e + 0]);
-    double omega = exp(A.logp[3 * e + 1]);
-    const double eps = exp(A.logp[3 * e + 2]);
-    double r[T];
-    double logdet = 0.0;
-    // No retry loop here: if K fails to factor (the reference then bumps omega,
-    // gp.py:128-135) the host re-runs the batch through the generic kernels.
-    {
-        const double d = lane * A.dt, d2 = d * d;
-        const double kk = sigmasq * exp(-omega * d2);
-        kv[lane] = kk + (lane == 0 ? eps : 0.0);
-        dkv[lane] = -kk * d2 * omega;
-    }
-    tri_wave_sync();
-    if (lane < T) {
-        const int my_off = tri_row_off(lane);
-        const bool real = lane < A.Tr;  // padding rows are unit vectors
-#pragma nounroll
-        for (int i = 0; i <= lane; ++i) Lp[my_off + i] = real ? kv[lane - i] : (i == lane ? 1.0 : 0.0);
-    }
-    tri_wave_sync();
-    __builtin_amdgcn_sched_barrier(0);
-    const bool ok = wave_chol_rows<T>(r, Lp, lane);
-    logdet = wave_tri_logdet<T>(Lp, lane);
-    double x[T];
-    wave_tri_inverse_cols<T>(Lp, x, lane);
-    tri_wave_sync();
-    wave_store_cols<T>(x, Lp, lane);
-    // K^-1 = X'X: lane i produces row i
-    constexpr TriuOff<T> off{};
-    double* Ki = A.kinv + (int64_t)e * T * T;
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-        const double* Xj = Lp + off.v[j];
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int k = j; k < T; k += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-            a0 = fma(x[k], v.x, a0);
-            if (k + 1 < T) a1 = fma(x[k + 1], v.y, a1);
-        }
-        if (lane < T) {
-            Ki[(int64_t)lane * T + j] = a0 + a1;
-            if (Kl) Kl[lane * T + j] = a0 + a1;  // LDS copy for the trace phase (both waves of the K block read it)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    A.kcol[(int64_t)e * 128 + lane] = kv[lane];
-    A.kcol[(int64_t)e * 128 + 64 + lane] = dkv[lane];
-    if (lane == 0) {
-        A.scal[4 * e + 0] = logdet;
-        A.scal[4 * e + 1] = 0.0;
-        A.scal[4 * e + 2] = omega;
-        A.scal[4 * e + 3] = ok ? 1.0 : 0.0;
-    }
-}
-
-template <int T>
-__global__ void __launch_bounds__(64, 3) hstep_prep_fast(HFastArgs A) {
-    __shared__ __attribute__((aligned(16))) double Lp[hstep_prep_lds<T>()];
-    __shared__ double kv[64], dkv[64];
-    hstep_prep_body<T>(A, blockIdx.x, threadIdx.x, Lp, kv, dkv);
-}
-
-
-// Two tasks per wave, two rows per lane (wave_tri.h "duo"): halves the LDS broadcast
-// traffic per FMA and drops the finished rows' upper-triangle work.
-template <int T>
-__global__ void __launch_bounds__(128, 2) hstep_seg_duo(HFastArgs A) {
-    constexpr int H = T / 2;
-    constexpr int PK = tri_packed_size(T);  // == upper-packed size for even T
-    constexpr int NW = 2;  // 2 waves x 2 tasks x 10.4 KB factors + vectors = 52 KB: three blocks per CU
-    __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PK];
-    __shared__ double vec_all[NW][2][5][64];
-    __shared__ double kv[64], dkv[64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int h = lane >> 5, q = lane & 31;
-    const int e = blockIdx.y;
-    const int seg = (blockIdx.x * NW + wid) * 2 + h;
-    if (threadIdx.x < 64) kv[threadIdx.x] = A.kcol[(int64_t)e * 128 + threadIdx.x];
-    else if (threadIdx.x < 128) dkv[threadIdx.x - 64] = A.kcol[(int64_t)e * 128 + threadIdx.x];
-    __syncthreads();
-    if ((blockIdx.x * NW + wid) * 2 >= A.M) return;  // whole wave idle
-    const bool valid = seg < A.M;
-    const bool in = q < H && valid;
-    double* Lp = Lp_all[wid][h];
-    double* sw = vec_all[wid][h][0];
-    double* muv = vec_all[wid][h][1];
-    double* alv = vec_all[wid][h][2];
-    double* invd = vec_all[wid][h][3];
-    double* stash = vec_all[wid][h][4];  // long-lived per-lane scalars parked in LDS (register pressure)
-    const int l = A.latent[e];
-    const int64_t r0row = A.off[valid ? seg : 0];
-    const double* Ki = A.kinv + (int64_t)e * T * T;
-
-    double mu0 = 0.0, mu1 = 0.0, w0 = 0.0, w1 = 0.0;
-    if (in) {
-        mu0 = A.mu[(r0row + q) * A.L + l];
-        mu1 = A.mu[(r0row + q + H) * A.L + l];
-        w0 = A.w[(r0row + q) * A.L + l];
-        w1 = A.w[(r0row + q + H) * A.L + l];
-    }
-    const double sw0 = sqrt(w0), sw1 = sqrt(w1);
-    if (q < H) {
-        sw[q] = sw0; sw[q + H] = sw1;
-        muv[q] = mu0; muv[q + H] = mu1;
-    }
-    tri_wave_sync();
-    // alpha = K^-1 mu for rows q and q + H (K^-1 symmetric: coalesced column reads)
-    double al0 = 0.0, al1 = 0.0;
-    if (in) {
-#pragma unroll 5
-        for (int j = 0; j < T; ++j) {
-            const double mj = muv[j];
-            al0 = fma(Ki[j * T + q], mj, al0);
-            al1 = fma(Ki[j * T + q + H], mj, al1);
-        }
-    }
-    if (q < H) { alv[q] = al0; alv[q + H] = al1; }
-    tri_wave_sync();
-    double quad = mu0 * al0 + mu1 * al1, gq = 0.0;
-    if (in) {
-        double g0 = 0.0, g1 = 0.0;
-#pragma unroll 5
-        for (int j = 0; j < T; ++j) {
-            const double aj = alv[j];
-            const int d0 = q > j ? q - j : j - q;
-            const int d1 = q + H > j ? q + H - j : j - q - H;
-            g0 = fma(dkv[d0], aj, g0);
-            g1 = fma(dkv[d1], aj, g1);
-        }
-        gq = g0 * al0 + g1 * al1;
-    }
-    stash[q] = quad;
-    stash[32 + q] = gq;
-    // rows q and q + H of A = I + W^1/2 K W^1/2 (lower parts) into packed LDS
-    if (q < H) {
-        const int o0 = tri_row_off(q), o1 = tri_row_off(q + H);
-#pragma nounroll
-        for (int i = 0; i <= q; ++i) Lp[o0 + i] = sw0 * sw[i] * kv[q - i] + (i == q ? 1.0 : 0.0);
-#pragma nounroll
-        for (int i = 0; i <= q + H; ++i) Lp[o1 + i] = sw1 * sw[i] * kv[q + H - i] + (i == q + H ? 1.0 : 0.0);
-    }
-    tri_wave_sync();
-    __builtin_amdgcn_sched_barrier(0);
-    bool ok;
-    {
-        double r0[H], r1[T];
-        ok = wave_chol_rows_duo<T>(r0, r1, Lp, invd, q, h);
-    }
-    double tr = 0.0, cacc = 0.0;
-    {
-        double x0[T], x1[H];
-        wave_tri_inverse_cols_duo<T>(Lp, invd, x0, x1, q);
-#pragma unroll
-        for (int k = 0; k < T; ++k) tr = fma(x0[k], x0[k], tr);
-#pragma unroll
-        for (int k = 0; k < H; ++k) tr = fma(x1[k], x1[k], tr);
-        tri_wave_sync();
-        // X columns -> upper-packed rows of X' (overwrites L)
-        if (q < H) {
-            const int my0 = triu_off_even(q, T), my1 = triu_off_even(q + H, T);
-#pragma unroll
-            for (int k = 0; k < T; ++k)
-                if (k >= q) Lp[my0 + k - q] = x0[k];
-            if ((T - q) & 1) Lp[my0 + T - q] = 0.0;
-#pragma unroll
-            for (int k = H; k < T; ++k)
-                if (k >= q + H) Lp[my1 + k - q - H] = x1[k - H];
-            if ((T - q - H) & 1) Lp[my1 + T - q - H] = 0.0;
-        }
-        tri_wave_sync();
-        __builtin_amdgcn_sched_barrier(0);
-        double c0acc = 0.0, c1acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const double* Xj = Lp + triu_off_even(j, T);
-            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-#pragma unroll
-            for (int k = j; k < T; k += 2) {
-                const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-                a0 = fma(x0[k], v.x, a0);
-                if (k + 1 < T) a1 = fma(x0[k + 1], v.y, a1);
-                if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
-                if (k + 1 >= H && k + 1 < T) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
-                if (((k - j) & 14) == 14) {
-                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            const double swj = sw[j];
-            const int d0 = q > j ? q - j : j - q;
-            const int d1 = q + H > j ? q + H - j : j - q - H;
-            c0acc = fma((a0 + a1) * swj, dkv[d0 & 63], c0acc);
-            c1acc = fma((b0 + b1) * swj, dkv[d1 & 63], c1acc);
-            asm volatile("" : "+v"(c0acc), "+v"(c1acc));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cacc = c0acc * sw[q < H ? q : 0] + c1acc * sw[q < H ? q + H : 0];
-    }
-    quad = stash[q];
-    gq = stash[32 + q];
-    if (!in) { tr = 0.0; cacc = 0.0; quad = 0.0; gq = 0.0; }
-    for (int o = 16; o > 0; o >>= 1) {  // reduce within each 32-lane half
-        quad += __shfl_xor(quad, o, 64);
-        gq += __shfl_xor(gq, o, 64);
-        tr += __shfl_xor(tr, o, 64);
-        cacc += __shfl_xor(cacc, o, 64);
-    }
-    if (q == 0 && valid) {
-        const double logdet = A.scal[4 * e + 0];
-        double ll = -0.5 * quad - 0.5 * tr - logdet;
-        double dll = 0.5 * (gq - cacc);
-        if (!ok) { ll = nan(""); dll = nan(""); }
-        A.out[((int64_t)e * A.M + seg) * 2 + 0] = ll;
-        A.out[((int64_t)e * A.M + seg) * 2 + 1] = dll;
-    }
-}
-
-
 // ---------------------------------------------------------------------------
 // Second moments of the latent means, C_l = sum_i mu_i[:, l] mu_i[:, l]' (T x T per
 // latent, summed over the set's units).  The quadratic terms of the objective depend
@@ -870,189 +641,10 @@ __global__ void __launch_bounds__(256) hstep_moment_reduce(int nchunk, int TT, c
     mom[(int64_t)l * TT + idx] = a;
 }
 
-// One wave, after hstep_prep_body: (tr(K^-1 C), tr(K^-1 dK K^-1 C)) -> qsum[2e], qsum[2e + 1].
-// Lane j owns row j of K^-1 (kj) and of C (cj); row b of K^-1 and dK are LDS broadcasts:
-//     gq = sum_j sum_b (C K^-1)[j][b] (K^-1 dK)[j][b].
-// Kl: T*T doubles of LDS, dk2: 128 doubles of LDS (dK mirrored: dk2[63 + d] = dK[|d|]).
-template <int T, bool KL_LDS = true>
-__device__ __forceinline__ void hstep_prep_moments(const HFastArgs& A, const double* mom, double* qsum, int e,
-                                                   int lane, double* Kl, double* dk2, const double* dkv) {
-    static_assert(T % 2 == 0 && T <= 64, "window must be even and at most 64");
-    const int row = lane < T ? lane : 0;
-    const double* Ki = A.kinv + (int64_t)e * T * T + (int64_t)row * T;
-    const double* Cj = mom + (int64_t)A.latent[e] * T * T + (int64_t)row * T;
-    double kj[T], cj[T];
-#pragma unroll
-    for (int k = 0; k < T; ++k) {
-        kj[k] = Ki[k];  // written by this very lane in hstep_prep_body
-        cj[k] = Cj[k];
-    }
-    if (KL_LDS && lane < T) {
-#pragma unroll
-        for (int k = 0; k < T; ++k) Kl[lane * T + k] = kj[k];
-    }
-    dk2[lane] = dkv[63 - lane];                                  // i = lane      -> |i - 63| = 63 - lane
-    dk2[64 + lane] = dkv[(lane + 1) & 63];                       // i = 64 + lane -> lane + 1 (entry 127 unused)
-    tri_wave_sync();
-    double quad = 0.0, gq = 0.0;
-#pragma unroll
-    for (int k = 0; k < T; ++k) quad = fma(kj[k], cj[k], quad);
-#pragma nounroll
-    for (int b = 0; b < T; ++b) {
-        // row b of K^-1: LDS copy, or (single-wave blocks, no room) the global one this wave just wrote
-        const double* Kb = KL_LDS ? Kl + b * T : A.kinv + (int64_t)e * T * T + b * T;
-        const double* Db = dk2 + (63 - b);  // Db[a] = dK[|a - b|]
-        double e0 = 0.0, e1 = 0.0, f0 = 0.0, f1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < T; k += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Kb + k);
-            e0 = fma(cj[k], v.x, e0);
-            e1 = fma(cj[k + 1], v.y, e1);
-            f0 = fma(kj[k], Db[k], f0);
-            f1 = fma(kj[k + 1], Db[k + 1], f1);
-        }
-        gq = fma(e0 + e1, f0 + f1, gq);
-    }
-    if (lane >= T) { quad = 0.0; gq = 0.0; }
-    for (int o = 32; o > 0; o >>= 1) {
-        quad += __shfl_xor(quad, o, 64);
-        gq += __shfl_xor(gq, o, 64);
-    }
-    if (lane == 0) {
-        qsum[2 * e + 0] = quad;
-        qsum[2 * e + 1] = gq;
-    }
-}
-
-// The trace phase of a K block spread over the NWV waves of the workgroup: every wave holds all rows of K^-1
-// (from the LDS copy `Kl` hstep_prep_body left) and of C_l in registers, and takes a contiguous share of the
-// rows b of the double sum; partial (quad, gq) per wave go to out2[wid] (quad from wave 0 only).
-template <int T, int NWV>
-__device__ __forceinline__ void hstep_prep_moments_split(const HFastArgs& A, const double* mom, int e, int lane, int wid,
-                                                         const double* Kl, double* dk2, const double* dkv, double* out2) {
-    static_assert(T % 2 == 0 && T <= 64, "window must be even and at most 64");
-    const int row = lane < T ? lane : 0;
-    const double* Cj = mom + (int64_t)A.latent[e] * T * T + (int64_t)row * T;
-    double kj[T], cj[T];
-#pragma unroll
-    for (int k = 0; k < T; k += 2) {
-        const double2 kk = *reinterpret_cast<const double2*>(Kl + row * T + k);
-        kj[k] = kk.x;
-        kj[k + 1] = kk.y;
-        cj[k] = Cj[k];
-        cj[k + 1] = Cj[k + 1];
-    }
-    dk2[lane] = dkv[63 - lane];                                  // i = lane      -> |i - 63| = 63 - lane
-    dk2[64 + lane] = dkv[(lane + 1) & 63];                       // i = 64 + lane -> lane + 1 (entry 127 unused)
-    tri_wave_sync();
-    double quad = 0.0, gq = 0.0;
-    if (wid == 0) {
-#pragma unroll
-        for (int k = 0; k < T; ++k) quad = fma(kj[k], cj[k], quad);
-    }
-    const int b_lo = (T * wid) / NWV, b_hi = (T * (wid + 1)) / NWV;
-#pragma nounroll
-    for (int b = b_lo; b < b_hi; ++b) {
-        const double* Kb = Kl + b * T;
-        const double* Db = dk2 + (63 - b);  // Db[a] = dK[|a - b|]
-        double e0 = 0.0, e1 = 0.0, f0 = 0.0, f1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < T; k += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Kb + k);
-            e0 = fma(cj[k], v.x, e0);
-            e1 = fma(cj[k + 1], v.y, e1);
-            f0 = fma(kj[k], Db[k], f0);
-            f1 = fma(kj[k + 1], Db[k + 1], f1);
-        }
-        gq = fma(e0 + e1, f0 + f1, gq);
-    }
-    if (lane >= T) { quad = 0.0; gq = 0.0; }
-    for (int o = 32; o > 0; o >>= 1) {
-        quad += __shfl_xor(quad, o, 64);
-        gq += __shfl_xor(gq, o, 64);
-    }
-    if (lane == 0) {
-        out2[2 * wid + 0] = quad;
-        out2[2 * wid + 1] = gq;
-    }
-}
-
-// The A_i part for one pair of tasks: factor A (packed in Lp), X = L^-1, returns
-// (tr(A^-1), sum_jk sqrt(w_j w_k) dK_jk (A^-1)_jk) per lane-partial (caller reduces
-// over the 32-lane half); x = NaN when A did not factor.  The empty asm statements pin
-// the load/FMA interleave and force the c*acc chain to be evaluated per row: without
-// them the compiler defers the chain and hoists whole rows of loads (2800 spilled VGPRs
-// measured when the quadratic part follows instead of precedes this code).
-template <int T>
-__device__ __forceinline__ double2 hstep_apart_duo(double* Lp, const double* sw, double* invd, const double* dkv, int q,
-                                                 int h) {
-    constexpr int H = T / 2;
-    bool ok;
-    {
-        double r0[H], r1[T];
-        ok = wave_chol_rows_duo<T>(r0, r1, Lp, invd, q, h);
-    }
-    double tr = 0.0, cacc = 0.0;
-    {
-        double x0[T], x1[H];
-        wave_tri_inverse_cols_duo<T>(Lp, invd, x0, x1, q);
-#pragma unroll
-        for (int k = 0; k < T; ++k) tr = fma(x0[k], x0[k], tr);
-#pragma unroll
-        for (int k = 0; k < H; ++k) tr = fma(x1[k], x1[k], tr);
-        tri_wave_sync();
-        // X columns -> upper-packed rows of X' (overwrites L)
-        if (q < H) {
-            const int my0 = triu_off_even(q, T), my1 = triu_off_even(q + H, T);
-#pragma unroll
-            for (int k = 0; k < T; ++k)
-                if (k >= q) Lp[my0 + k - q] = x0[k];
-            if ((T - q) & 1) Lp[my0 + T - q] = 0.0;
-#pragma unroll
-            for (int k = H; k < T; ++k)
-                if (k >= q + H) Lp[my1 + k - q - H] = x1[k - H];
-            if ((T - q - H) & 1) Lp[my1 + T - q - H] = 0.0;
-        }
-        tri_wave_sync();
-        __builtin_amdgcn_sched_barrier(0);
-        double c0acc = 0.0, c1acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const double* Xj = Lp + triu_off_even(j, T);
-            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-#pragma unroll
-            for (int k = j; k < T; k += 2) {
-                const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-                a0 = fma(x0[k], v.x, a0);
-                if (k + 1 < T) a1 = fma(x0[k + 1], v.y, a1);
-                if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
-                if (k + 1 >= H && k + 1 < T) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
-                if (((k - j) & 14) == 14) {
-                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            const double swj = sw[j];
-            const int d0 = q > j ? q - j : j - q;
-            const int d1 = q + H > j ? q + H - j : j - q - H;
-            c0acc = fma((a0 + a1) * swj, dkv[d0 & 63], c0acc);
-            c1acc = fma((b0 + b1) * swj, dkv[d1 & 63], c1acc);
-            asm volatile("" : "+v"(c0acc), "+v"(c1acc));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cacc = c0acc * sw[q < H ? q : 0] + c1acc * sw[q < H ? q + H : 0];
-    }
-    double2 out;
-    out.x = ok ? tr : nan("");
-    out.y = cacc;
-    return out;
-}
-
 // ---------------------------------------------------------------------------
 // One launch per L-BFGS-B round.  Blocks [0, n_eval) factor K and reduce the
-// moment matrices (hstep_prep_body + hstep_prep_moments, one wave); the others
-// take four segments each and compute only the A_i terms, which need nothing
-// from the K blocks (first columns of K and dK are recomputed inline), so all
+// moment matrices (hstep_round_kblock); the others take segments of one evaluation
+// and compute only the A_i terms, which need nothing from the K blocks, so all
 // blocks run concurrently.  Every block leaves one partial sum and takes a
 // ticket (release); the block that draws the last ticket adds the partials in a
 // fixed order and publishes (ll, dll, ok) per evaluation -- to mapped host memory
@@ -1076,344 +668,6 @@ struct HRoundArgs {
     int lr_ev[16];          // ... and which
     unsigned long long* clk;  // debug: per-phase cycle counters of the first segment block (vlgp_debug_phase_clock), or null
 };
-
-template <int T>
-__global__ void __launch_bounds__(128, 2) hstep_round_duo(HRoundArgs R) {
-    constexpr int NW = 2;
-    constexpr int H = T / 2;
-    constexpr int PK = tri_packed_size(T);
-    // two waves, four tasks, 47 KB -> three blocks per CU (six waves); superseded by hstep_round_lean,
-    // kept as the reference implementation of the padded layout (VLGP_HSTEP_PADDED=1)
-    constexpr int VS = 64;
-    static_assert(2 * NW * PK >= hstep_prep_lds<T>() + 2 + T * T, "K block scratch must fit");
-    __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PK];
-    __shared__ double sw_all[NW][2][VS];
-    __shared__ double invd_all[2 * NW][VS];
-    __shared__ double kv[VS], dkv[64];
-    __shared__ double part[2 * NW][2];
-    __shared__ int s_last;
-    const HFastArgs& A = R.F;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if ((int)blockIdx.x < R.n_eval) {
-        const int e = blockIdx.x;
-        if (wid == 0) {
-            double* base = &Lp_all[0][0][0];
-            double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);
-            hstep_prep_body<T>(A, e, lane, base, extra + T * T, extra + T * T + 64);
-            tri_wave_sync();
-            hstep_prep_moments<T, true>(A, R.mom, R.qsum, e, lane, extra, extra + T * T + 128, extra + T * T + 64);
-        }
-    } else {
-        const int b = blockIdx.x - R.n_eval;
-        const int e = b / R.nb, bx = b - e * R.nb;
-        const int h = lane >> 5, q = lane & 31;
-        const int seg = (bx * NW + wid) * 2 + h;
-        if (threadIdx.x < 64) {
-            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
-            const double d = lane * A.dt, d2 = d * d;
-            const double kk = sigmasq * exp(-omega * d2);
-            kv[lane] = kk + (lane == 0 ? eps : 0.0);
-            dkv[lane] = -kk * d2 * omega;
-        }
-        __syncthreads();
-        double tr = 0.0, cacc = 0.0;
-        if ((bx * NW + wid) * 2 < A.M) {
-            const bool valid = seg < A.M;
-            const bool in = q < H && valid;
-            double* Lp = Lp_all[wid][h];
-            double* sw = sw_all[wid][h];
-            double* invd = invd_all[wid * 2 + h];
-            const int l = A.latent[e];
-            const int64_t r0row = A.off[valid ? seg : 0];
-            double w0 = 0.0, w1 = 0.0;
-            if (in) {
-                w0 = A.w[(r0row + q) * A.L + l];
-                w1 = A.w[(r0row + q + H) * A.L + l];
-            }
-            const double sw0 = sqrt(w0), sw1 = sqrt(w1);
-            if (q < H) { sw[q] = sw0; sw[q + H] = sw1; }
-            tri_wave_sync();
-            // rows q and q + H of A = I + W^1/2 K W^1/2 (lower parts) into packed LDS
-            if (q < H) {
-                const int o0 = tri_row_off(q), o1 = tri_row_off(q + H);
-#pragma nounroll
-                for (int i = 0; i <= q; ++i) Lp[o0 + i] = sw0 * sw[i] * kv[q - i] + (i == q ? 1.0 : 0.0);
-#pragma nounroll
-                for (int i = 0; i <= q + H; ++i) Lp[o1 + i] = sw1 * sw[i] * kv[q + H - i] + (i == q + H ? 1.0 : 0.0);
-            }
-            tri_wave_sync();
-            __builtin_amdgcn_sched_barrier(0);
-            const double2 tc = hstep_apart_duo<T>(Lp, sw, invd, dkv, q, h);
-            tr = tc.x;  // NaN marks a failed factorisation and propagates into ll
-            cacc = tc.x == tc.x ? tc.y : tc.x;
-            if (!in) { tr = 0.0; cacc = 0.0; }
-            for (int o = 16; o > 0; o >>= 1) {  // reduce within each 32-lane half
-                tr += __shfl_xor(tr, o, 64);
-                cacc += __shfl_xor(cacc, o, 64);
-            }
-        }
-        if ((lane & 31) == 0) {
-            part[wid * 2 + (lane >> 5)][0] = tr;
-            part[wid * 2 + (lane >> 5)][1] = cacc;
-        }
-    }
-    // ---- completion: one partial per block, then the last block reduces and publishes ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if ((int)blockIdx.x >= R.n_eval) {
-            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
-            o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-            o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
-        }
-        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    constexpr int NT = 128;
-    double* rs = &Lp_all[0][0][0];  // 2 x 128 partials
-    for (int e = 0; e < R.n_eval; ++e) {
-        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int m = threadIdx.x; m < R.nb; m += NT) {
-            const double2 v = in[m];
-            s0 += v.x;
-            s1 += v.y;
-        }
-        __syncthreads();
-        rs[threadIdx.x] = s0;
-        rs[128 + threadIdx.x] = s1;
-        __syncthreads();
-        for (int o = NT / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                rs[threadIdx.x] += rs[threadIdx.x + o];
-                rs[128 + threadIdx.x] += rs[128 + threadIdx.x + o];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const double okf = A.scal[4 * e + 3];
-            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
-            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[128]);
-            R.red[2 * e + 0] = ll;
-            R.red[2 * e + 1] = dll;
-            R.red[2 * R.n_eval + e] = okf;
-            if (R.host) {
-                R.host[2 * e + 0] = ll;
-                R.host[2 * e + 1] = dll;
-                R.host[2 * R.n_eval + e] = okf;
-            }
-        }
-    }
-    if (threadIdx.x == 0) {
-        R.sync[16] = 0;  // next launch is stream-ordered after this one
-        if (R.host) {
-            __threadfence_system();
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-// The same round with the lean task layout (wave_tri.h): 10.2 KB of LDS per task and no
-// per-task vectors, so four blocks -- eight waves -- fit a CU instead of three.
-template <int T>
-__global__ void __launch_bounds__(128, 2) hstep_round_lean(HRoundArgs R) {
-    constexpr int H = T / 2;
-    constexpr int PKU = (tri_off_u(T) + 1) & ~1;  // unpadded packed triangle; even, so that every task buffer is 16-byte aligned
-    constexpr int NW = 2;
-    static_assert(2 * NW * PKU >= hstep_prep_lds<T>() + 2 + 256, "K block scratch must fit");
-    __shared__ __attribute__((aligned(16))) double Lp_all[NW][2][PKU];
-    __shared__ double part[2 * NW][2];
-    __shared__ int s_last;
-    const HFastArgs& A = R.F;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if ((int)blockIdx.x < R.n_eval) {
-        // K block.  Wave 0: K -> chol, K^-1 (serial chain); then BOTH waves share the traces against C_l, with
-        // K^-1 broadcast from an LDS copy (the round is only as short as this block: 100 -> 60 us for one evaluation)
-        const int e = blockIdx.x;
-        double* base = &Lp_all[0][0][0];
-        double* extra = base + ((hstep_prep_lds<T>() + 1) & ~1);  // kv64 | dkv64 | dk2 (128) | dk2' (128)
-        double* Kl = extra + 384;                                 // T x T copy of K^-1
-        static_assert(((hstep_prep_lds<T>() + 1) & ~1) + 384 + T * T <= 2 * NW * PKU, "K block scratch must fit");
-        if (wid == 0) hstep_prep_body<T>(A, e, lane, base, extra, extra + 64, Kl);
-        __syncthreads();
-        hstep_prep_moments_split<T, NW>(A, R.mom, e, lane, wid, Kl, extra + 128 + 128 * wid, extra + 64, &part[0][0]);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            R.qsum[2 * e + 0] = part[0][0];
-            R.qsum[2 * e + 1] = part[0][1] + part[1][1];
-        }
-    } else {
-        const int b = blockIdx.x - R.n_eval;
-        const int e = b / R.nb, bx = b - e * R.nb;
-        const int h = lane >> 5, q = lane & 31;
-        const int seg = (bx * NW + wid) * 2 + h;
-        double tr = 0.0, cacc = 0.0;
-        if ((bx * NW + wid) * 2 < A.M) {
-            const bool valid = seg < A.M;
-            const bool in = q < H && valid;
-            double* Lp = Lp_all[wid][h];
-            const int l = A.latent[e];
-            const int64_t r0row = A.off[valid ? seg : 0];
-            double w0 = 0.0, w1 = 0.0;
-            if (in) {  // rows >= Tr are identity padding: zero curvature
-                if (q < A.Tr) w0 = A.w[(r0row + q) * A.L + l];
-                if (q + H < A.Tr) w1 = A.w[(r0row + q + H) * A.L + l];
-            }
-            const double sw0 = sqrt(w0), sw1 = sqrt(w1);
-            // this lane's entries of the first columns of K and dK/dln omega (distances q and q + H)
-            const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
-            const double d0 = q * A.dt, d1 = (q + H) * A.dt;
-            const double kk0 = sigmasq * exp(-omega * d0 * d0), kk1 = sigmasq * exp(-omega * d1 * d1);
-            const double odt2 = omega * A.dt * A.dt;
-            const double g0 = exp(odt2 * (2 * q - 1)), g1 = exp(odt2 * (2 * (q + H) - 1)), gc = exp(-2.0 * odt2);
-            double dkw0 = -kk0 * d0 * d0 * omega, dkw1 = -kk1 * d1 * d1 * omega;
-            if (q < H) {  // s_k waits in the diagonal slot of row k until step k replaces it by 1 / L[k][k]
-                Lp[tri_off_u(q) + q] = sw0;
-                Lp[tri_off_u(q + H) + q + H] = sw1;
-            }
-            tri_wave_sync();
-            __builtin_amdgcn_sched_barrier(0);
-            bool ok;
-            {
-                double r0[H], r1[T];
-                ok = wave_chol_rows_duo_lean<T>(r0, r1, Lp, q, h, sw0, sw1, kk0, kk1, g0, g1, gc, eps);
-            }
-            {
-                double x0[T], x1[H];
-                wave_tri_inverse_cols_duo_lean<T>(Lp, x0, x1, q);
-#pragma unroll
-                for (int k = 0; k < T; ++k) tr = fma(x0[k], x0[k], tr);
-#pragma unroll
-                for (int k = 0; k < H; ++k) tr = fma(x1[k], x1[k], tr);
-                tri_wave_sync();
-                // X columns -> upper-packed rows of X' scaled by s (overwrites L)
-                if (q < H) {
-                    const int my0 = triu_off_u(q, T), my1 = triu_off_u(q + H, T);
-#pragma unroll
-                    for (int k = 0; k < T; ++k)
-                        if (k >= q) Lp[my0 + k - q] = sw0 * x0[k];
-#pragma unroll
-                    for (int k = H; k < T; ++k)
-                        if (k >= q + H) Lp[my1 + k - q - H] = sw1 * x1[k - H];
-                }
-                tri_wave_sync();
-                __builtin_amdgcn_sched_barrier(0);
-                // strictly lower half of sum_jk s_j s_k dK_jk (X'X)_jk; dK[row - j] slides like kv did.
-                // Rows q < H only meet columns j < H - 1: their sums are skipped (statically) beyond that.
-                double c0acc = 0.0, c1acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < T - 1; ++j) {
-                    const double* Xj = Lp + triu_off_u(j, T);
-                    const int st = triu_off_u(j, T) & 1;  // aligned pairs start at k = j + st
-                    const bool lo = j < H - 1;              // rows of the first half still have weight
-                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-                    if (st) {
-                        const double vx = Xj[0];
-                        if (lo) a0 = fma(x0[j], vx, a0);
-                        if (j >= H) b0 = fma(x1[j - H < 0 ? 0 : j - H], vx, b0);
-                    }
-#pragma unroll
-                    for (int k = j + st; k + 1 < T; k += 2) {
-                        const double2 v = *reinterpret_cast<const double2*>(Xj + (k - j));
-                        if (lo) {
-                            a0 = fma(x0[k], v.x, a0);
-                            a1 = fma(x0[k + 1], v.y, a1);
-                        }
-                        if (k >= H) b0 = fma(x1[k - H < 0 ? 0 : k - H], v.x, b0);
-                        if (k + 1 >= H) b1 = fma(x1[k + 1 - H < 0 ? 0 : k + 1 - H], v.y, b1);
-                        if (((k - j - st) & 14) == 14) {
-                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    if ((T - j - st) & 1) {  // last column left over
-                        const double vx = Xj[T - 1 - j];
-                        if (lo) a0 = fma(x0[T - 1], vx, a0);
-                        b0 = fma(x1[H - 1], vx, b0);
-                    }
-                    if (lo) c0acc = fma(a0 + a1, dkw0, c0acc);
-                    c1acc = fma(b0 + b1, dkw1, c1acc);
-                    tri_windows_step<H>(dkw0, dkw1, q, h, 0.0);
-                    asm volatile("" : "+v"(c0acc), "+v"(c1acc), "+v"(dkw0), "+v"(dkw1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                cacc = 2.0 * (c0acc * sw0 + c1acc * sw1);
-            }
-            if (!ok) { tr = nan(""); cacc = nan(""); }  // failed factorisation: propagates into ll, dll
-            if (!in) { tr = 0.0; cacc = 0.0; }
-            for (int o = 16; o > 0; o >>= 1) {  // reduce within each 32-lane half
-                tr += __shfl_xor(tr, o, 64);
-                cacc += __shfl_xor(cacc, o, 64);
-            }
-            if (valid) tr -= (double)(T - A.Tr);  // the identity padding's share of tr(A^-1)
-        }
-        if ((lane & 31) == 0) {
-            part[wid * 2 + (lane >> 5)][0] = tr;
-            part[wid * 2 + (lane >> 5)][1] = cacc;
-        }
-    }
-    // ---- completion: one partial per block, then the last block reduces and publishes ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if ((int)blockIdx.x >= R.n_eval) {
-            double* o = A.out + 2 * (int64_t)(blockIdx.x - R.n_eval);
-            o[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-            o[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
-        }
-        const unsigned ticket = __hip_atomic_fetch_add(&R.sync[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double* rs = &Lp_all[0][0][0];  // 2 x 128 partials
-    for (int e = 0; e < R.n_eval; ++e) {
-        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int m = threadIdx.x; m < R.nb; m += 128) {
-            const double2 v = in[m];
-            s0 += v.x;
-            s1 += v.y;
-        }
-        __syncthreads();
-        rs[threadIdx.x] = s0;
-        rs[128 + threadIdx.x] = s1;
-        __syncthreads();
-        for (int o = 64; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                rs[threadIdx.x] += rs[threadIdx.x + o];
-                rs[128 + threadIdx.x] += rs[128 + threadIdx.x + o];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const double okf = A.scal[4 * e + 3];
-            const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
-            const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[128]);
-            R.red[2 * e + 0] = ll;
-            R.red[2 * e + 1] = dll;
-            R.red[2 * R.n_eval + e] = okf;
-            if (R.host) {
-                R.host[2 * e + 0] = ll;
-                R.host[2 * e + 1] = dll;
-                R.host[2 * R.n_eval + e] = okf;
-            }
-        }
-    }
-    if (threadIdx.x == 0) {
-        R.sync[16] = 0;  // next launch is stream-ordered after this one
-        if (R.host) {
-            __threadfence_system();
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.host + 48), (unsigned long long)R.seq,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
 
 // K block of a round (shared by the dense and the low-rank round kernels): wave 0 takes K -> K^-1 and log det through
 // the blocked elimination of hstep_mfma.h (KMODE); then every wave takes block rows of the two products against the
@@ -1572,7 +826,7 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
 }
 
 // The round on the matrix pipe (hstep_mfma.h): one wave per segment, NW waves per block.  Blocks [0, n_eval) are
-// the K blocks as in hstep_round_lean (all NW waves share the trace phase).
+// the K blocks (all NW waves share the trace phase).
 // ONESET (T = 50 only): the one-register-set task routine hstep_task_mfma50 (buffer row = lane); else the two-set routine.
 template <int T, int NW, bool ONESET = false>
 __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3) : 2) : 1) hstep_round_mfma(HRoundArgs R) {
@@ -1680,17 +934,6 @@ __global__ void __launch_bounds__(64 * NW, RC <= 16 ? 4 : 3) hstep_round_lr(HRou
     hstep_round_finish<NW>(R, lds_dyn, part, &s_last, out_slot);
 }
 
-template <int T>
-static int launch_fast(vlgp_ctx* ctx, const HFastArgs& F, int n_eval, int M) {
-    hipLaunchKernelGGL((hstep_prep_fast<T>), dim3(n_eval), dim3(64), 0, ctx->stream, F);
-    HIPCHK(ctx, hipGetLastError());
-    vlgp_prof_begin(ctx, VLGP_PROF_HSTEP);
-    hipLaunchKernelGGL((hstep_seg_duo<T>), dim3((M + 3) / 4, n_eval), dim3(128), 0, ctx->stream, F);
-    vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
-    HIPCHK(ctx, hipGetLastError());
-    return VLGP_OK;
-}
-
 // ---- low-rank round: host side ------------------------------------------------------------------------------
 // Rank of the folded even / odd blocks of exp(-omega D^2) under the pivoted Cholesky of hstep_lr_tables (same pivot
 // rule, no tangent), used to predict the LDS a round needs; > LR_RCAP when a block exceeds the kernel's capacity.
@@ -1793,9 +1036,11 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     // round 4: windows of 4 ... 23 bins take the round kernels too when the low-rank round runs (its cost follows the
     // rank, not the compiled window; the K block pads to 50 as it always did): the generic kernels below 24 remain
     // for the dense switches only
-    const bool old_kernels = getenv("VLGP_HSTEP_UNFUSED") || getenv("VLGP_HSTEP_PADDED") || getenv("VLGP_HSTEP_LEAN");
-    const bool lr_allowed = !old_kernels && !force_dense && !getenv("VLGP_HSTEP_DENSE") && !getenv("VLGP_HSTEP_TWOSET");
-    const bool fast = T <= (old_kernels ? 50 : 64) && T >= (lr_allowed ? 4 : 24) && !getenv("VLGP_HSTEP_GENERIC");
+    // (round 4: the round-1 / round-2 kernels behind VLGP_HSTEP_UNFUSED / _PADDED / _LEAN / _TWOSET are gone; what is left
+    // is the low-rank round, the dense matrix-pipe round (VLGP_HSTEP_DENSE=1 forces it), and the generic kernels
+    // (VLGP_HSTEP_GENERIC=1), which also implement the reference's omega retry)
+    const bool lr_allowed = !force_dense && !getenv("VLGP_HSTEP_DENSE");
+    const bool fast = T <= 64 && T >= (lr_allowed ? 4 : 24) && !getenv("VLGP_HSTEP_GENERIC");
     const int TC = T <= 50 ? 50 : 64;  // compiled window
     const int64_t TT = fast ? (int64_t)TC * TC : (int64_t)T * T;
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
@@ -1823,17 +1068,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         for (int i = 0; i < 3 * n_eval; ++i) F.logp[i] = logp[i];
         F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
         double* hres = hp + 4 * n_eval + 8;
-        if (T == 50 && getenv("VLGP_HSTEP_UNFUSED")) {
-            ctx->last_hstep_path = VLGP_PATH_HSTEP_OLD;
-            CHK(launch_fast<50>(ctx, F, n_eval, M));
-            // red: [2 n_eval] (ll, dll) pairs, then [n_eval] "K factored" flags -> one device->host copy
-            hipLaunchKernelGGL(hstep_reduce_kernel, dim3(n_eval), dim3(256), 0, ctx->stream, M, W + o_out, W + o_red,
-                               W + o_scal, W + o_red + 2 * n_eval);
-            HIPCHK(ctx, hipGetLastError());
-            CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
-            HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        } else {
+        {
             if (!ctx->d_hsync) {
                 HIPCHK(ctx, hipMalloc(&ctx->d_hsync, 32 * sizeof(unsigned)));
                 HIPCHK(ctx, hipMemsetAsync(ctx->d_hsync, 0, 32 * sizeof(unsigned), ctx->stream));
@@ -1867,15 +1102,12 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             HRoundArgs R;
             R.F = F;
             constexpr int MFMA_NW = 4;  // waves (= segments) per block of the matrix-pipe round kernel
-            const bool padded = T == 50 && getenv("VLGP_HSTEP_PADDED") != nullptr;  // the 47 KB / block layout
-            const bool lean = getenv("VLGP_HSTEP_LEAN") != nullptr;                 // register-row kernel (round 1)
-            const bool mfma = !padded && !lean;
-            const bool twoset = getenv("VLGP_HSTEP_TWOSET") != nullptr;  // two-register-set task routine at window <= 50
+            const bool mfma = true;
             // the exact low-rank round (hstep_lr.h) when every evaluation's kernel matrix has numerical rank <= LR_RCAP
             // (omega below about 2e-2 on a 50-bin window); VLGP_HSTEP_DENSE=1 keeps the dense matrix-pipe round
             const bool lr_off = getenv("VLGP_HSTEP_DENSE") != nullptr;  // read per call: the tests switch it
             const double lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-12;
-            bool lr = mfma && !twoset && !lr_off && !force_dense;
+            bool lr = !lr_off && !force_dense;
             int rcap[16], rmax = 0;
             if (lr) {
                 const std::vector<double>& om = lr_thresholds(ctx, T, dt, 0.5 * lr_tol);
@@ -1888,7 +1120,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     if (rcap[e] > rmax) rmax = rcap[e];
                 }
             }
-            R.n_eval = n_eval; R.nb = lr ? (M + 15) / 16 : (mfma ? (M + MFMA_NW - 1) / MFMA_NW : (M + 3) / 4);
+            R.n_eval = n_eval; R.nb = lr ? (M + 15) / 16 : (M + MFMA_NW - 1) / MFMA_NW;
             R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
@@ -1912,7 +1144,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             } else if (mfma) {
                 ctx->hstat[2] += n_eval;
             }
-            ctx->last_hstep_path = lr ? VLGP_PATH_HSTEP_LOWRANK : (mfma ? VLGP_PATH_HSTEP_DENSE : VLGP_PATH_HSTEP_OLD);
+            ctx->last_hstep_path = lr ? VLGP_PATH_HSTEP_LOWRANK : VLGP_PATH_HSTEP_DENSE;
             // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
             // their sums on the host (vlgp_hx_allreduce); without the exchange segment the sums go through the
             // device all-reduce and a copy instead
@@ -1920,11 +1152,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             R.host = mailbox ? ctx->d_hres : nullptr;
             const int prof_kind = lr ? VLGP_PROF_HSTEP_LR : VLGP_PROF_HSTEP;
             vlgp_prof_begin(ctx, prof_kind);
-            if (padded)
-                hipLaunchKernelGGL((hstep_round_duo<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
-            else if (lean)
-                hipLaunchKernelGGL((hstep_round_lean<50>), dim3(n_eval + n_eval * R.nb), dim3(128), 0, ctx->stream, R);
-            else if (lr) {
+            if (lr) {
                 // one launch per rank class present in the round (registers and LDS are sized by the class: a smooth
                 // latent's segments must not run at the occupancy of a rough one's); the K blocks ride in the first
                 constexpr int NW = LR_NW;
@@ -1969,10 +1197,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     }
                     first = false;
                 }
-            } else if (TC == 50 && twoset)
-                hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
-                                   ctx->stream, R);
-            else if (TC == 50)
+            } else if (TC == 50)
                 hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW, true>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
                                    ctx->stream, R);
             else

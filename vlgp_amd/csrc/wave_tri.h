@@ -89,14 +89,6 @@ __device__ __forceinline__ bool wave_chol_rows(double (&r)[T], double* Lp, int l
     return bad == 0;
 }
 
-// sum_k log L[k][k] of a packed factor: one log per lane, then a wave reduction
-template <int T>
-__device__ __forceinline__ double wave_tri_logdet(const double* Lp, int lane) {
-    double v = lane < T ? log(Lp[tri_row_off(lane < T ? lane : 0) + (lane < T ? lane : 0)]) : 0.0;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // In: Lp = packed lower-triangular L.  Out: x[i] = (L^-1)[i][lane], i.e. lane c holds COLUMN c of X = L^-1 (zeros
 // above the diagonal).
 template <int T>
@@ -180,143 +172,6 @@ __host__ __device__ constexpr int triu_row_off(int c, int T) {
     for (int q = 0; q < c; ++q) s += (T - q + 1) & ~1;
     return s;
 }
-template <int T>
-struct TriuOff {
-    int v[T + 1];
-    constexpr TriuOff() : v() {
-        int s = 0;
-        for (int q = 0; q <= T; ++q) {
-            v[q] = s;
-            s += (T - q + 1) & ~1;
-        }
-    }
-};
-
-// Store column `lane` of X (registers) as packed row `lane` of X' in LDS.
-template <int T>
-__device__ __forceinline__ void wave_store_cols(const double (&x)[T], double* Xp, int lane) {
-    constexpr TriuOff<T> off{};
-    int my = 0;
-#pragma unroll
-    for (int q = 0; q < T; ++q)
-        if (q == lane) my = off.v[q];
-    if (lane < T) {
-#pragma unroll
-        for (int k = 0; k < T; ++k)
-            if (k >= lane) Xp[my + k - lane] = x[k];
-        if ((T - lane) & 1) Xp[my + T - lane] = 0.0;  // zero the pad so pair reads are exact
-    }
-    tri_wave_sync();
-}
-
-// ===========================================================================
-// "Duo" variants: ONE wavefront factors TWO matrices (task A in lanes 0..31,
-// task B in lanes 32..63) and every lane holds TWO rows of its matrix (row q and
-// row q + T/2, q = lane & 31).  Why: a wave-uniform pivot value read from LDS
-// serves one FMA per lane in the one-row scheme; the CU's single LDS pipe (one
-// broadcast ds_read_b128 = 4 LDS cycles for 2 doubles) then caps the four SIMDs
-// at half their fp64 FMA rate (measured: 53 % issue utilisation).  With two rows
-// per lane each broadcast value feeds two FMAs, the two halves read two
-// addresses per instruction at no extra LDS cost, and the static upper-triangle
-// work of rows < T/2 disappears for steps k >= T/2 (762 instead of 1225 FMA
-// instructions per matrix and phase).
-// ===========================================================================
-__device__ __forceinline__ double tri_pick_half(double v, int src_q, int h) {
-    // value of lane (32 h + src_q): two static readlanes and a per-half select
-    const double a = tri_readlane(v, src_q);
-    const double b = tri_readlane(v, 32 + src_q);
-    return h ? b : a;
-}
-
-// In: Lp = this lane's task buffer (packed lower, holds A).  Out: chol(A) in place,
-// r0[i] = L[q][i], r1[i] = L[q + T/2][i]; invd[k] = 1 / L[k][k] (per-task LDS array).
-// Returns per-lane ok flag (identical within a half).
-template <int T>
-__device__ __forceinline__ bool wave_chol_rows_duo(double (&r0)[T / 2], double (&r1)[T], double* Lp, double* invd,
-                                                   int q, int h) {
-    constexpr int H = T / 2;
-    const bool in = q < H;
-    const int off0 = tri_row_off(in ? q : 0), off1 = tri_row_off(in ? q + H : H);
-    int bad = 0;  // materialised every step (asm below): a lazily evaluated `ok &= d > 0` chain
-                  // keeps all T pivots alive to the end (measured: +74 VGPRs)
-#pragma unroll
-    for (int k = 0; k < T; ++k) {
-        const double* Lk = Lp + tri_row_off(k);
-        double s0 = (k < H) ? Lp[off0 + (k < H ? k : 0)] : 0.0, s0b = 0.0;  // A[q][k]
-        double s1 = Lp[off1 + k], s1b = 0.0;                              // A[q + H][k]
-#pragma unroll
-        for (int i = 0; i + 1 < k; i += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Lk + i);
-            if (k < H) {  // rows < H are finished once k >= H: no work for them (static)
-                s0 = fma(-r0[i < H ? i : 0], v.x, s0);
-                s0b = fma(-r0[i + 1 < H ? i + 1 : 0], v.y, s0b);
-            }
-            s1 = fma(-r1[i], v.x, s1);
-            s1b = fma(-r1[i + 1], v.y, s1b);
-            // bound the number of pivot-row loads in flight (registers): at most 8 b128 ahead
-            if ((i & 14) == 14) {
-                asm volatile("" : "+v"(s0), "+v"(s0b), "+v"(s1), "+v"(s1b) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (k & 1) {
-            const double lv = Lk[k - 1];
-            if (k < H) s0 = fma(-r0[k - 1 < H ? k - 1 : 0], lv, s0);
-            s1 = fma(-r1[k - 1], lv, s1);
-        }
-        s0 += s0b;
-        s1 += s1b;
-        const double d = tri_pick_half(k < H ? s0 : s1, k < H ? k : k - H, h);  // pivot of this half's matrix
-        bad |= (!(d > 0.0) || !(d < 1e300)) ? 1 : 0;
-        asm volatile("" : "+v"(bad));
-        double inv, sd;
-        tri_rsqrt(d, &inv, &sd);
-        if (k < H) {
-            r0[k < H ? k : 0] = (q == k) ? sd : s0 * inv;
-            if (in && q >= k) Lp[off0 + k] = r0[k < H ? k : 0];
-        }
-        r1[k] = (q + H == k) ? sd : s1 * inv;
-        if (in && q + H >= k) Lp[off1 + k] = r1[k];
-        if (q == 0) invd[k] = inv;
-        tri_wave_order();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return bad == 0;
-}
-
-// Columns q and q + T/2 of X = L^-1 in registers: x0[i] = X[i][q], x1[i - T/2] = X[i][q + T/2]
-// (the latter is zero for i < T/2 and not stored).
-template <int T>
-__device__ __forceinline__ void wave_tri_inverse_cols_duo(const double* Lp, const double* invd, double (&x0)[T],
-                                                          double (&x1)[T / 2], int q) {
-    constexpr int H = T / 2;
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-        const double* Li = Lp + tri_row_off(i);
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-#pragma unroll
-        for (int j = 0; j + 1 < i; j += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Li + j);
-            a0 = fma(v.x, x0[j], a0);
-            a1 = fma(v.y, x0[j + 1], a1);
-            if (j >= H) b0 = fma(v.x, x1[j - H < 0 ? 0 : j - H], b0);
-            if (j + 1 >= H) b1 = fma(v.y, x1[j + 1 - H < 0 ? 0 : j + 1 - H], b1);
-            if ((j & 14) == 14) {
-                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (i & 1) {
-            const double lv = Li[i - 1];
-            a0 = fma(lv, x0[i - 1], a0);
-            if (i - 1 >= H) b0 = fma(lv, x1[i - 1 - H < 0 ? 0 : i - 1 - H], b0);
-        }
-        const double di = invd[i];
-        x0[i] = ((q == i ? 1.0 : 0.0) - (a0 + a1)) * di;
-        if (i >= H) x1[i - H < 0 ? 0 : i - H] = ((q + H == i ? 1.0 : 0.0) - (b0 + b1)) * di;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 // ===========================================================================
 // "Lean" duo variants: the task's LDS footprint is the packed triangle and nothing else
@@ -338,143 +193,6 @@ __device__ __forceinline__ void wave_tri_inverse_cols_duo(const double* Lp, cons
 // ===========================================================================
 __host__ __device__ constexpr int tri_off_u(int i) { return i * (i + 1) / 2; }
 __host__ __device__ constexpr int triu_off_u(int c, int T) { return c * T - (c * (c - 1)) / 2; }
-
-__device__ __forceinline__ double tri_wave_shr1(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane i <- lane i - 1)
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// Moves both sliding windows one step: w0 (row q) <- lane q - 1, w1 (row q + H) <- lane q - 1, and lane
-// q = 0 of each half takes row H's next value from row H - 1 (w0 of lane H - 1), `fill0` for row 0.
-template <int H>
-__device__ __forceinline__ void tri_windows_step(double& w0, double& w1, int q, int h, double fill0) {
-    const double carry = tri_pick_half(w0, H - 1, h);
-    w0 = tri_wave_shr1(w0);
-    w1 = tri_wave_shr1(w1);
-    if (q == 0) {
-        w0 = fill0;
-        w1 = carry;
-    }
-}
-
-// Factor A = I + S K S without ever storing A.  sw0/sw1: sqrt(w) of rows q, q + T/2; kvw0/kvw1:
-// jitter-free first column of K, sigma^2 exp(-omega (d dt)^2), at distances d = q and q + T/2;
-// g0/g1 = exp(omega dt^2 (2 d - 1)) at those distances, gc = exp(-2 omega dt^2): the column obeys
-// kv0[d-1] = kv0[d] g_d with g_{d-1} = g_d gc, so every lane walks its own two values down to
-// distance zero (and symmetrically beyond) with two multiplies a step -- fifty steps cost ~1e-14
-// relative, far inside the parity tolerance; eps = the jitter on the diagonal of K.  The diagonal slot of
-// row k holds s_k on entry (the caller puts it there) and 1 / L[k][k] on exit; L strictly below the
-// diagonal (unpadded packed).  Unpadded rows start at even or odd offsets: the pivot-row pairs are
-// formed from index 0 or 1 accordingly (static), so that every pair is one aligned ds_read_b128
-// with an immediate offset.
-template <int T>
-__device__ __forceinline__ bool wave_chol_rows_duo_lean(double (&r0)[T / 2], double (&r1)[T], double* Lp, int q, int h,
-                                                        double sw0, double sw1, double kvw0, double kvw1,
-                                                        double g0, double g1, double gc, double eps) {
-    constexpr int H = T / 2;
-    const bool in = q < H;
-    const int off0 = tri_off_u(in ? q : 0), off1 = tri_off_u(in ? q + H : H);
-    int bad = 0;
-#pragma unroll
-    for (int k = 0; k < T; ++k) {
-        const double* Lk = Lp + tri_off_u(k);
-        const int st = tri_off_u(k) & 1;  // first index of the aligned pairs
-        const double sk = Lk[k];          // s_k, parked in the diagonal slot
-        double s0 = 0.0, s0b = 0.0, s1b = 0.0;
-        // A[row][k] = s_row s_k kv0[row - k] + (row == k) (1 + s_k^2 eps)
-        if (k < H) s0 = fma(sw0 * sk, kvw0, q == k ? fma(sw0 * sk, eps, 1.0) : 0.0);
-        double s1 = fma(sw1 * sk, kvw1, q + H == k ? fma(sw1 * sk, eps, 1.0) : 0.0);
-        if (st && k > 0) {
-            const double lv = Lk[0];
-            if (k < H) s0 = fma(-r0[0], lv, s0);
-            s1 = fma(-r1[0], lv, s1);
-        }
-#pragma unroll
-        for (int i = st; i + 1 < k; i += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Lk + i);
-            if (k < H) {
-                s0 = fma(-r0[i < H ? i : 0], v.x, s0);
-                s0b = fma(-r0[i + 1 < H ? i + 1 : 0], v.y, s0b);
-            }
-            s1 = fma(-r1[i], v.x, s1);
-            s1b = fma(-r1[i + 1], v.y, s1b);
-            if (((i - st) & 14) == 14) {
-                asm volatile("" : "+v"(s0), "+v"(s0b), "+v"(s1), "+v"(s1b) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (k > st && ((k - st) & 1)) {
-            const double lv = Lk[k - 1];
-            if (k < H) s0 = fma(-r0[k - 1 < H ? k - 1 : 0], lv, s0);
-            s1 = fma(-r1[k - 1], lv, s1);
-        }
-        s0 += s0b;
-        s1 += s1b;
-        const double d = tri_pick_half(k < H ? s0 : s1, k < H ? k : k - H, h);
-        bad |= (!(d > 0.0) || !(d < 1e300)) ? 1 : 0;
-        asm volatile("" : "+v"(bad));
-        double inv, sd;
-        tri_rsqrt(d, &inv, &sd);
-        if (k < H) {
-            r0[k < H ? k : 0] = s0 * inv;
-            if (in && q >= k) Lp[off0 + k] = (q == k) ? inv : r0[k < H ? k : 0];
-        }
-        r1[k] = s1 * inv;
-        if (in && q + H >= k) Lp[off1 + k] = (q + H == k) ? inv : r1[k];
-        // next distance: kv0[d - 1] = kv0[d] g_d, g_{d-1} = g_d e^{-2 omega dt^2} (each lane advances its own
-        // two window values; no cross-lane traffic)
-        if (k < H) {
-            kvw0 *= g0;
-            g0 *= gc;
-        }
-        kvw1 *= g1;
-        g1 *= gc;
-        asm volatile("" : "+v"(kvw0), "+v"(kvw1), "+v"(g0), "+v"(g1));
-        tri_wave_order();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return bad == 0;
-}
-
-// Columns q and q + T/2 of X = L^-1 from the lean factor (reciprocal diagonal in place).
-template <int T>
-__device__ __forceinline__ void wave_tri_inverse_cols_duo_lean(const double* Lp, double (&x0)[T], double (&x1)[T / 2],
-                                                               int q) {
-    constexpr int H = T / 2;
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-        const double* Li = Lp + tri_off_u(i);
-        const int st = tri_off_u(i) & 1;
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        if (st && i > 0) {
-            const double lv = Li[0];
-            a0 = fma(lv, x0[0], a0);
-        }
-#pragma unroll
-        for (int j = st; j + 1 < i; j += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(Li + j);
-            a0 = fma(v.x, x0[j], a0);
-            a1 = fma(v.y, x0[j + 1], a1);
-            if (j >= H) b0 = fma(v.x, x1[j - H < 0 ? 0 : j - H], b0);
-            if (j + 1 >= H) b1 = fma(v.y, x1[j + 1 - H < 0 ? 0 : j + 1 - H], b1);
-            if (((j - st) & 14) == 14) {
-                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (i > st && ((i - st) & 1)) {
-            const double lv = Li[i - 1];
-            a0 = fma(lv, x0[i - 1], a0);
-            if (i - 1 >= H) b0 = fma(lv, x1[i - 1 - H < 0 ? 0 : i - 1 - H], b0);
-        }
-        const double di = Li[i];  // 1 / L[i][i]
-        x0[i] = ((q == i ? 1.0 : 0.0) - (a0 + a1)) * di;
-        if (i >= H) x1[i - H < 0 ? 0 : i - H] = ((q + H == i ? 1.0 : 0.0) - (b0 + b1)) * di;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 // offset of row c in the upper-packed X' storage (rows padded to an even length), T even
 __host__ __device__ constexpr int triu_off_even(int c, int T) {
