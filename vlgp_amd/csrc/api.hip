@@ -362,6 +362,7 @@ extern "C" int vlgp_comm_init(vlgp_ctx* ctx, const char id[VLGP_UNIQUE_ID_BYTES]
     if (world < 1 || rank < 0 || rank >= world) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad rank/world %d/%d", rank, world);
     ctx->rank = rank;
     ctx->world = world;
+    for (auto& us : ctx->sets) us.rows_all_ranks = 0.0;  // row totals exchanged under another communicator are stale
     // a single rank needs no communicator; VLGP_FORCE_RCCL=1 builds one anyway so
     // that the RCCL plumbing can be exercised on a one-GPU box (tests)
     if (world == 1 && !getenv("VLGP_FORCE_RCCL")) return VLGP_OK;
