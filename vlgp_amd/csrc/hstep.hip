@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "ctx.h"
 #include "wave_tri.h"
 #include "hstep_mfma.h"
@@ -1168,6 +1170,8 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     Rc.lr_nev = 0;
                     int rm = rmax;
                     for (int e = 0; e < n_eval; ++e) Rc.lr_ev[Rc.lr_nev++] = e;
+                    // longest first: the workgroups of the highest ranks are dispatched before the cheap ones (shorter tail)
+                    std::stable_sort(Rc.lr_ev, Rc.lr_ev + Rc.lr_nev, [&](int x, int y) { return rcap[x] > rcap[y]; });
                     if (Rc.lr_nev == 0) continue;
                     Rc.k_blocks = first ? n_eval : 0;
                     // tables in LDS unless leaving them in global memory lets one more workgroup share a CU

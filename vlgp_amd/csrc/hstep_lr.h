@@ -91,6 +91,23 @@ __device__ __forceinline__ double lr_wave_max(double v) {
     return fmax(fmax(r0, r1), fmax(r2, r3));
 }
 
+// Sum over the sixteen lanes of a row, on the DPP path (row_shr 1, 2, 4, 8; a lane without a source adds 0): the total
+// ends up in lane 15 of each row.
+__device__ __forceinline__ double lr_row_sum_to15(double v) {
+    union { double d; int i[2]; } a, b;
+#define LR_DPP_ADD(ctrl)                                                           \
+    a.d = v;                                                                       \
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], ctrl, 0xf, 0xf, true);         \
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], ctrl, 0xf, 0xf, true);         \
+    v += b.d;
+    LR_DPP_ADD(0x111)
+    LR_DPP_ADD(0x112)
+    LR_DPP_ADD(0x114)
+    LR_DPP_ADD(0x118)
+#undef LR_DPP_ADD
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tables of one evaluation: pivoted Cholesky of the even and of the odd block of K_0 = exp(-omega D^2) (one wave
 // each, lane <-> folded time row, factor columns in registers, pivot row entries by v_readlane), differentiated
@@ -250,7 +267,7 @@ __device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, doub
 // LDS carve of a segment group (doubles), for rank r, ntp folded time rows, nw waves
 struct LrGeom {
     int LDU, NPS;
-    int o_u, o_ud, o_mp, o_xb, o_red, total;
+    int o_u, o_ud, o_mp, o_xb, o_red, o_codes, total;
 };
 __host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_global = false) {
     LrGeom G;
@@ -261,7 +278,8 @@ __host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_globa
     G.o_mp = tab_global ? 0 : ((2 * ntp * G.LDU + 1) & ~1);
     G.o_xb = (G.o_mp + 16 * G.NPS + 1) & ~1;
     G.o_red = G.o_xb + nw * 64;
-    G.total = G.o_red + nw * 32 + 2;
+    G.o_codes = G.o_red + nw * 32 + 2;        // pair codes of the evaluation (LR_NPAIR unsigned shorts)
+    G.total = G.o_codes + LR_NPAIR / 4;
     return G;
 }
 
@@ -289,12 +307,18 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     const int ns_tiles = __builtin_amdgcn_readfirstlane(mt.ns_tiles), n_tiles = __builtin_amdgcn_readfirstlane(mt.n_tiles);
     // TABG: the tables stay in global memory (L1 / L2: 13 KB per evaluation, shared by its 250 workgroups) and the LDS
     // they would take goes to a third workgroup per CU (ranks 25 ... 31); needs a zero column, i.e. r < LR_RCAP
+    const int h = T >> 1, nt = (T + 1) >> 1;
+    const int gs = seg0 + c;
+    const bool sval = gs < M;
+    const int64_t r0 = sval ? off[gs] : 0;
     const LrGeom G = lr_geom(r, 4 * NK, NW, TABG);
     const double* Ul = TABG ? tab_e : lds + G.o_u;
     const double* Udl = TABG ? tab_e + LR_TROWS * LR_RCAP : lds + G.o_ud;
     double* Mp = lds + G.o_mp;
     double* xb = lds + G.o_xb + wid * 64;
     double* red = lds + G.o_red;
+    unsigned short* codes = reinterpret_cast<unsigned short*>(lds + G.o_codes);
+    for (int x = threadIdx.x; x < 16 * n_tiles; x += 64 * NW) codes[x] = pairs_e[x];  // (the tile loops read them from LDS)
     const int LDU = G.LDU, NPS = G.NPS;
     const int NPZ = r * (r + 1) / 2;  // the zero slot of a packed matrix; NPZ + 1: trash
     if constexpr (!TABG) {
@@ -315,10 +339,6 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     // ---- phase 0: folded weights of segment c at the depth positions of this lane ----
     // (evaluated before phase 1 and again before phase 3: 4 NK values that would otherwise sit in registers through the
     // sweeps of phase 2, which need the room for the matrix rows)
-    const int h = T >> 1, nt = (T + 1) >> 1;
-    const int gs = seg0 + c;
-    const bool sval = gs < M;
-    const int64_t r0 = sval ? off[gs] : 0;
     double ap[NK], am[NK], bp[NK], bm[NK];
     double dsum = 0.0;
     auto weights = [&]() {
@@ -346,7 +366,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     // ---- phase 1: M = I + U' diag(wt) U, 16 pairs x 16 segments per tile; two tiles of one kind at a time (two
     // independent accumulate chains on the matrix pipe) ----
     auto tile_codes = [&](int q, int& i, int& j, int& idx, double& dg) {
-        const unsigned code = pairs_e[q * 16 + c];
+        const unsigned code = codes[q * 16 + c];
         const bool valid = code != 0xffffu;
         i = valid ? (int)(code >> 8) : r;
         j = valid ? (int)(code & 255u) : r;
@@ -456,7 +476,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     dsum += __shfl_xor(dsum, 16, 64);
     dsum += __shfl_xor(dsum, 32, 64);
     for (int q = wid; q < n_tiles; q += NW) {
-        const unsigned code = pairs_e[q * 16 + c];
+        const unsigned code = codes[q * 16 + c];
         const bool valid = code != 0xffffu;
         const int i = valid ? (int)(code >> 8) : r, j = valid ? (int)(code & 255u) : r;
         const double* ui = Ul + g * LDU + i;
@@ -487,14 +507,10 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            ts[p] += __shfl_xor(ts[p], o, 64);
-            cs[p] += __shfl_xor(cs[p], o, 64);
-        }
-        if (c == 0) {
-            red[(wid * 16 + g + 4 * p) * 2 + 0] = ts[p];
-            red[(wid * 16 + g + 4 * p) * 2 + 1] = cs[p];
+        const double tsum = lr_row_sum_to15(ts[p]), csum = lr_row_sum_to15(cs[p]);
+        if (c == 15) {
+            red[(wid * 16 + g + 4 * p) * 2 + 0] = tsum;
+            red[(wid * 16 + g + 4 * p) * 2 + 1] = csum;
         }
     }
     __syncthreads();
