@@ -438,29 +438,40 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                 a[j] = Ms[(rowok && j < r) ? hi * (hi + 1) / 2 + lo : NPZ];
             }
             double nd = lr_rcp(a[0]);
+            // (no rank guards inside a sweep: entries beyond the rank are zeros on both sides, and every guarded chunk of
+            // the column would cost its own LDS round trip; the sweeps themselves stop at the rank)
+            auto sweeps = [&]() {
 #pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                if (k < r) {
+                for (int k = 0; k < RC; ++k) {
+                    if (k >= r) return;
                     xs[row] = row == k ? nd : a[k];
                     tri_wave_order();
                     const double dinv = xs[k];
                     const double f = row == k ? 1.0 - dinv : a[k] * dinv;
+                    if (k + 1 < RC) {  // the next pivot first: its reciprocal is on the chain to the next sweep
+                        const double pn = xs[k + 1];
+                        a[k + 1] = fma(-f, pn, a[k + 1]);
+                    }
 #pragma unroll
-                    for (int j0 = 0; j0 < RC; j0 += 8) {
-                        if (j0 < r) {
-#pragma unroll
-                            for (int j = j0; j < j0 + 8 && j < RC; j += 2) {
-                                const double2 pv = *reinterpret_cast<const double2*>(xs + j);
-                                a[j] = fma(-f, pv.x, a[j]);
-                                if (j + 1 < RC) a[j + 1] = fma(-f, pv.y, a[j + 1]);
-                            }
-                        }
+                    for (int j = 0; j < RC; j += 2) {
+                        const double2 pv = *reinterpret_cast<const double2*>(xs + j);
+                        if (j != k + 1) a[j] = fma(-f, pv.x, a[j]);
+                        if (j + 1 < RC && j + 1 != k + 1) a[j + 1] = fma(-f, pv.y, a[j + 1]);
                     }
                     a[k] = row == k ? -dinv : f;
                     if (k + 1 < RC) nd = lr_rcp(a[k + 1]);
+                    // every LDS read of the sweep up front (ONE round trip), then the arithmetic: left alone the scheduler
+                    // recycles a handful of registers and takes six dependent round trips per sweep
+                    // (rank class 32: sixteen 16-byte reads in flight on top of the 32-entry row leave the allocator no
+                    // room -- measured 1.5x slower with the hint)
+                    if constexpr (RC <= 24) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, RC / 2 + 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4 * RC, 0);
+                    }
                     tri_wave_order();
                 }
-            }
+            };
+            sweeps();
             // a = -(M^-1)[row][:]; stored with the off-diagonal entries doubled: the contraction runs over i >= j
             const int base = rowv * (rowv + 1) / 2;
 #pragma unroll
