@@ -1163,7 +1163,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // ONE launch, compiled for the largest rank of the round.  (Measured: one launch per rank class --
                 // registers and LDS sized by the class -- serialises three under-filled launches, 137 us against
                 // 97 us for a steady-state round of C3.)
-                const int cls_of_max = rmax <= 16 ? 0 : (rmax <= 24 ? 1 : 2);
+                const int cls_of_max = rmax <= 16 ? 0 : (rmax <= 24 ? 1 : (rmax <= 28 ? 2 : 3));
                 bool first = true;
                 for (int ci = cls_of_max; ci <= cls_of_max; ++ci) {
                     HRoundArgs Rc = R;
@@ -1182,7 +1182,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                         return (160 * 1024) / (n * 8 + 256);
                     };
                     const int need_l = lr_geom(rm, 4 * NK, NW, false).total, need_g = lr_geom(rm, 4 * NK, NW, true).total;
-                    const bool tabg = ci == 2 && rm < LR_RCAP && wgs(need_g) > wgs(need_l) && wgs(need_l) < 3;
+                    const bool tabg = ci >= 2 && rm < LR_RCAP && wgs(need_g) > wgs(need_l) && wgs(need_l) < 3;
                     int need = tabg ? need_g : need_l;
                     if (first && need < kblk) need = kblk;
                     if (need < 2 * 64 * NW) need = 2 * 64 * NW;
@@ -1191,11 +1191,15 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     if (TC == 50) {
                         if (ci == 0) CHK((launch_round_lr<50, 16>(ctx, Rc, grid, lds_bytes)));
                         else if (ci == 1) CHK((launch_round_lr<50, 24>(ctx, Rc, grid, lds_bytes)));
+                        else if (ci == 2 && tabg) CHK((launch_round_lr<50, 28, true>(ctx, Rc, grid, lds_bytes)));
+                        else if (ci == 2) CHK((launch_round_lr<50, 28>(ctx, Rc, grid, lds_bytes)));
                         else if (tabg) CHK((launch_round_lr<50, 32, true>(ctx, Rc, grid, lds_bytes)));
                         else CHK((launch_round_lr<50, 32>(ctx, Rc, grid, lds_bytes)));
                     } else {
                         if (ci == 0) CHK((launch_round_lr<64, 16>(ctx, Rc, grid, lds_bytes)));
                         else if (ci == 1) CHK((launch_round_lr<64, 24>(ctx, Rc, grid, lds_bytes)));
+                        else if (ci == 2 && tabg) CHK((launch_round_lr<64, 28, true>(ctx, Rc, grid, lds_bytes)));
+                        else if (ci == 2) CHK((launch_round_lr<64, 28>(ctx, Rc, grid, lds_bytes)));
                         else if (tabg) CHK((launch_round_lr<64, 32, true>(ctx, Rc, grid, lds_bytes)));
                         else CHK((launch_round_lr<64, 32>(ctx, Rc, grid, lds_bytes)));
                     }
