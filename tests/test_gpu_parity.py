@@ -379,6 +379,7 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
               "v": np.zeros((T, L))} for m in range(M)]
     lat = np.arange(L)
     logp = np.tile(g["logp"][1], (L, 1))
+    monkeypatch.setenv("VLGP_HSTEP_LOWRANK", "1")  # (eight segments: the size rule would pick the dense round)
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
         plain = eng.hstep_objective(0, T, 1.0, lat, logp)
@@ -425,6 +426,7 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
     lat = np.array([0, 1, 2, 1, 0])
     logp = np.log(np.array([[1.0, 2e-3, 1e-4], [0.8, 8e-3, 1e-4], [0.5, 1.5e-2, 1e-4], [1.0, 6e-4, 2e-4],
                             [0.3, 1e-2, 5e-5]]))
+    monkeypatch.setenv("VLGP_HSTEP_LOWRANK", "1")  # (take the low-rank round whatever the size rule says)
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
         low = eng.hstep_objective(0, T, 1.0, lat, logp)
@@ -469,6 +471,7 @@ def test_hstep_objective_other_windows_vs_oracle(V, T, monkeypatch):
     units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": 2.0 * rng.random((T, L)),
               "v": np.zeros((T, L))} for _ in range(M)]
     logp = np.log(np.array([[1.0, 3e-3, 1e-4], [0.6, 2e-2, 1e-4]]))
+    monkeypatch.setenv("VLGP_HSTEP_LOWRANK", "1")  # (six segments: the size rule would pick the dense round from 24 bins)
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
         ll, dll = eng.hstep_objective(0, T, 1.0, np.arange(L), logp)

@@ -22,6 +22,7 @@ def run(T, M, L, omegas, wscale, seed=0, oracle=True):
             logp = np.tile(np.log([0.9, om, 1e-4]), (L, 1))
             logp[:, 1] += np.linspace(0, 0.3, L)
             os.environ.pop("VLGP_HSTEP_DENSE", None)
+            os.environ["VLGP_HSTEP_LOWRANK"] = "1"  # whatever the size rule says
             ll1, dll1 = eng.hstep_objective(0, T, 1.0, lat, logp)
             p1 = eng.last_hstep_path
             os.environ["VLGP_HSTEP_DENSE"] = "1"

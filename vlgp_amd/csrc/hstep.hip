@@ -1122,6 +1122,21 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     if (rcap[e] > rmax) rmax = rcap[e];
                 }
             }
+            if (lr && !getenv("VLGP_HSTEP_LOWRANK")) {
+                // Which round is faster depends on how much there is to do (measured on MI355X, tools/lr_round_bench.py,
+                // us per round over n = n_eval x M segment-evaluations, 4000 of them = one "generation"):
+                //   dense      41 + 28 (n / 4000 - 1): one wave per segment, 4096 resident waves, ~25 us wave lifetime
+                //   low-rank   13 (tables launch) + base + marg (n / 4000 - 1), by rank class 16 / 24 / 28 / 32:
+                //              base 26 / 35 / 46 / 50 (one workgroup's latency), marg 12 / 15 / 19 / 22
+                // A few hundred segments (C1, C2, the shard a rank holds at 8 GPUs) never fill the chip: the dense round's
+                // single launch wins there.  VLGP_HSTEP_LOWRANK=1 takes the low-rank round regardless (tests).
+                static const double base[4] = {26.0, 35.0, 46.0, 50.0}, marg[4] = {12.0, 15.0, 19.0, 22.0};
+                const int ci = rmax <= 16 ? 0 : (rmax <= 24 ? 1 : (rmax <= 28 ? 2 : 3));
+                const double gens = (double)n_eval * M / 4000.0;
+                const double extra = gens > 1.0 ? gens - 1.0 : 0.0;
+                const double t_dense = 41.0 + 28.0 * extra, t_lr = 13.0 + base[ci] + marg[ci] * extra;
+                if (T >= 24 && t_lr > 0.95 * t_dense) lr = false;
+            }
             R.n_eval = n_eval; R.nb = lr ? (M + 15) / 16 : (M + MFMA_NW - 1) / MFMA_NW;
             R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
