@@ -83,7 +83,7 @@ def pmc_traffic(kernel_key):
     else profiles/r1: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, plus WRITE_SIZE; separate
     passes).  None when no measurement is on file for that exact kernel name."""
     if not _PMC_CACHE:
-        for rnd in ("r1", "r2", "r3"):  # later rounds override
+        for rnd in ("r1", "r2", "r3", "r4"):  # later rounds override
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
                     _PMC_CACHE.update(json.load(f))
@@ -92,10 +92,9 @@ def pmc_traffic(kernel_key):
         _PMC_CACHE.setdefault("_", {})
     hit = _PMC_CACHE.get(kernel_key)
     if hit is None and kernel_key.endswith("*"):  # "name<5, 1, false*": the first kernel whose name starts like that
-        for k in sorted(_PMC_CACHE):
-            if k.startswith(kernel_key[:-1]):
-                hit = _PMC_CACHE[k]
-                break
+        cands = [k for k in sorted(_PMC_CACHE) if k.startswith(kernel_key[:-1])]
+        if cands:  # the instantiation the passes saw most often
+            hit = _PMC_CACHE[max(cands, key=lambda k: _PMC_CACHE[k].get("launches_fetch_pass", 0))]
     return (hit or {}).get("hbm_bytes_per_launch")
 
 
@@ -389,7 +388,7 @@ def main():
             frac_executed=exe_seg * u_l / n_l / (ms_l / n_l * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             mean_predicted_rank=r_mean, low_rank_evaluations=hs[0], dense_evaluations=hs[2], reruns=hs[3],
             bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_l / n_l,
-            pmc_key="hstep_round_lr<", per_step_ms=ms_l / k_steps,
+            pmc_key="hstep_round_lr<*", per_step_ms=ms_l / k_steps,
             avg_ms_overlapped=(prof_live["hstep_lr"][1] / prof_live["hstep_lr"][0]) if prof_live["hstep_lr"][0] else None,
             note="exact low-rank (Woodbury) round, hstep_lr.h: `achieved` / `frac` price the launch at SURVEY 8(d)'s "
                  "count M (T^3 + 4 T^2) (the work of the reference's algorithm, which this kernel replaces); "
