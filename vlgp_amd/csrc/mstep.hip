@@ -63,7 +63,10 @@ static inline int nstat_rt(int L, int P, int kind) {
 // spilled at the 128-register budget of four waves per SIMD; at ten latents, the 77 accumulators of a thread split over
 // two launches per Newton iteration (gradient sums + Hessian rows < 7 / rows >= 7 + r'v sums, both recomputing the
 // rate) to get from two to four waves per SIMD: a, a^2, mu, v, mt and q of ten latents are 120 registers before the
-// first accumulator, 130 registers spilled, C5's M-step 46 -> 270 ms.)
+// first accumulator, 130 registers spilled, C5's M-step 46 -> 270 ms; round 4: at ten latents one row at a time with only
+// a and mu + v a live across the Hessian update (a^2, q, v recomputed / re-read from LDS, bit-identical sums): no spill at
+// 256 registers but no second row in flight either, 36 -> 43 ms.  A 512-thread workgroup is two waves per SIMD whatever
+// the register count up to 256; more occupancy needs <= 128 registers, i.e. the accumulators of a channel split over lanes.)
 #define MS_GS 8
 template <int LT, int PT, int KIND, bool EXACT>
 // four waves per SIMD (128 VGPRs) up to five latents; the 2 L + L (L + 1) / 2 accumulators of more latents
