@@ -86,6 +86,18 @@ int vlgp_cut_units(vlgp_ctx* ctx, int src, int dst, int M_dst,
 /* Write mu and v of a cut set back into its source set (no-op when aliased;
  * with overlapping segments later segments win, in order). */
 int vlgp_merge_units(vlgp_ctx* ctx, int cut_set);
+/* Overlapping segments of a copied cut (trial lengths that are not multiples of the window).  In the reference they are
+ * NumPy VIEWS of the same trial rows (vlgp/util.py:482-496): core.estep runs them one after the other, segment k + 1
+ * starting from the mu, v that segment k left in the shared rows (vlgp/core.py:123-126), and an in-place constraint
+ * (vlgp/core.py:374-388,413-416) touches a shared row once per segment that holds it.  The caller orders the units of
+ * the cut STAGE-MAJOR (stage = position in a chain of overlapping neighbours; stage_start[n_stages + 1] unit indices)
+ * and lists the links (first unit, second unit, shared rows), sorted by the stage of their second unit
+ * (link_start[n_stages + 1]).  vlgp_estep then runs stage by stage, copying the shared rows forward before and back
+ * after each stage; vlgp_apply_latent_map applies its map a second time to the shared rows.  vlgp_unshare_mu: mu stops
+ * being shared (constrain_loading "svd" rebinds every segment's mu, vlgp/core.py:407-408); v stays shared. */
+int vlgp_set_overlaps(vlgp_ctx* ctx, int set, int n_stages, const int* stage_start, int n_links,
+                      const int* links, const int* link_start);
+int vlgp_unshare_mu(vlgp_ctx* ctx, int set);
 /* restore == 0: keep a device-side copy of the set's mu; restore != 0: write it back.  For the one place where
  * the reference DETACHES segments from their trials: constrain_loading == "svd" rebinds every segment's mu
  * (vlgp/core.py:407-408, `trial["mu"] = trial["mu"] @ us`), after which the parent trials keep the values they

@@ -539,7 +539,19 @@ def gen_mstep_singular():
     save("mstep_singular", **out)
 
 
-ALL = ["ichol", "estep", "mstep", "mstep_singular", "hstep", "vem", "fit", "init", "fit_h1", "branches", "result",
+def gen_ragged():
+    """Trial lengths that are not multiples of the window: the reference's segments are overlapping VIEWS of the trial
+    arrays (vlgp/util.py:482-496), updated one after the other in place."""
+    fresh, a0, b0, (lengths, N, L), run = golden_cases.ragged_window_inputs()
+    np.random.seed(4)
+    res = ref_api.fit(fresh(), L, a=a0.copy(), b=b0.copy(), **run)
+    p = res["params"]
+    save("ragged_window", a=p["a"], b=p["b"], noise=p["noise"], omega=p["omega"], sigma=p["sigma"],
+         it=res["config"]["runtime"]["it"], mu0=res["trials"][0]["mu"], v0=res["trials"][0]["v"],
+         mu3=res["trials"][3]["mu"])
+
+
+ALL = ["ichol", "estep", "mstep", "mstep_singular", "ragged", "hstep", "vem", "fit", "init", "fit_h1", "branches", "result",
        "vem_c2", "vem_c3"]
 
 if __name__ == "__main__":

@@ -75,3 +75,23 @@ def singular_mstep_inputs():
     x = np.ones((T, 1, N))
     y = rng.poisson(np.exp(mu @ a + b)).astype(float)
     return dict(y=y, x=x, mu=mu, v=v, a=a, b=b, lr=1e-3)
+
+
+def ragged_window_inputs():
+    """Trial lengths that are NOT multiples of the window (vlgp/util.py:482-496: the surplus becomes random overlaps of
+    neighbouring segments, which in the reference are NumPy views of the same trial rows)."""
+    from vlgp_amd import synth
+
+    lengths = [130, 170, 230, 90, 110]
+    N, L = 12, 3
+    trials = synth.make_trials(len(lengths), max(lengths), N, L, seed=21, lengths=lengths)
+    rng = np.random.default_rng(121)
+    a0 = 0.3 * rng.standard_normal((L, N))
+    ycat = np.concatenate([t["y"] for t in trials])
+    b0 = np.log(np.maximum(ycat.mean(0, keepdims=True), 1e-8))
+    mu0 = [0.2 * rng.standard_normal((n, L)) for n in lengths]
+
+    def fresh():
+        return [{"ID": i, "y": t["y"].copy(), "mu": m.copy()} for i, (t, m) in enumerate(zip(trials, mu0))]
+
+    return fresh, a0, b0, (lengths, N, L), dict(max_iter=2, min_iter=2, omega_bound=(1e-3, 1e-2))

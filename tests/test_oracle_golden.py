@@ -231,3 +231,26 @@ def test_mstep_singular_golden(golden, n_it):
                                          np.zeros(N, bool), n_it, use_hessian=True, eps=0.0, learning_rate=d["lr"])
     for k, arr in zip(("a", "b", "da", "db", "noise"), (a, b, da, db, noise)):
         assert relerr(arr, g["%s_%d" % (k, n_it)]) < STAGE_TOL, k
+
+
+def test_ragged_window_golden(golden):
+    """Trial lengths that are not multiples of the window (vlgp/util.py:482-496): overlapping segments as views of the
+    trial arrays, updated one after the other in place, with the reference's own multinomial draw of the overlaps."""
+    import golden_cases
+
+    g = golden("ragged_window")
+    fresh, a0, b0, (lengths, N, L), run = golden_cases.ragged_window_inputs()
+    ref = fresh()
+    for t in ref:
+        n = t["y"].shape[0]
+        t["x"] = np.ones((n, 1, N))
+        t["w"] = np.zeros((n, L))
+        t["v"] = np.zeros((n, L))
+    cfg = O.make_config(**run)
+    params = O.make_params(ref, L, a=a0.copy(), b=b0.copy(), omega_bound=cfg["omega_bound"])
+    np.random.seed(4)
+    np.random.choice(sum(lengths), max(sum(lengths) // 10, 50))  # initialize() draws its subsample first (preprocess.py:14)
+    O.fit_given_init(ref, params, cfg)
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert relerr(params[k], g[k]) < 1e-9, k
+    assert relerr(ref[0]["mu"], g["mu0"]) < 1e-8 and relerr(ref[3]["mu"], g["mu3"]) < 1e-8

@@ -75,6 +75,8 @@ _SIGNATURES = {
     "vlgp_hstep_begin": (C.c_int, [_h, C.c_int, C.c_int]),
     "vlgp_hstep_end": (C.c_int, [_h]),
     "vlgp_apply_latent_map": (C.c_int, [_h, C.c_int, _dp, _dp]),
+    "vlgp_set_overlaps": (C.c_int, [_h, C.c_int, C.c_int, _ip, C.c_int, _ip, _ip]),
+    "vlgp_unshare_mu": (C.c_int, [_h, C.c_int]),
     "vlgp_norms": (C.c_int, [_h, C.c_int, _dp]),
     "vlgp_latent_moments": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "vlgp_comm_unique_id": (C.c_int, [C.c_char_p]),

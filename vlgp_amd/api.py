@@ -45,8 +45,34 @@ def _segments(trials, window, eng):
         block = np.zeros((len(segs), window, segs[0]["mu"].shape[1]))
         for i, sg in enumerate(segs):
             sg["dmu"] = block[i]
-    eng.cut(SET_TRIALS, SET_SEGMENTS, np.asarray(starts, dtype=np.int64), window)
-    return E.DeviceTrials(segs, eng, SET_SEGMENTS, parent_set=SET_TRIALS)
+    starts = np.asarray(starts, dtype=np.int64)
+    # Overlapping neighbours (a trial length that is not a multiple of the window, vlgp/util.py:482-496): in the reference
+    # they are views of the same rows, visited one after the other.  The device keeps independent copies, stored
+    # stage-major (stage = position in a chain of overlapping neighbours) so that the E-step can run stage by stage with
+    # the shared rows handed over in between (vlgp_set_overlaps); `unit_of` maps a segment of this list to its unit.
+    n = len(segs)
+    over = np.zeros(n, dtype=np.int64)          # rows segment i shares with segment i - 1
+    if n > 1:
+        gap = starts[1:] - starts[:-1]
+        over[1:] = np.where((gap > 0) & (gap < window), window - gap, 0)
+    if not over.any():
+        eng.cut(SET_TRIALS, SET_SEGMENTS, starts, window)
+        return E.DeviceTrials(segs, eng, SET_SEGMENTS, parent_set=SET_TRIALS)
+    stage = np.zeros(n, dtype=np.int64)
+    for i in range(1, n):
+        stage[i] = stage[i - 1] + 1 if over[i] else 0
+    order = np.argsort(stage, kind="stable")    # unit u holds segment order[u]
+    unit_of = np.empty(n, dtype=np.int64)
+    unit_of[order] = np.arange(n)
+    n_stages = int(stage.max()) + 1
+    stage_start = np.searchsorted(stage[order], np.arange(n_stages + 1)).astype(np.int32)
+    linked = np.flatnonzero(over)               # segment i shares over[i] rows with segment i - 1
+    linked = linked[np.argsort(stage[linked], kind="stable")]
+    links = np.stack([unit_of[linked - 1], unit_of[linked], over[linked]], axis=1).astype(np.int32)
+    link_start = np.searchsorted(stage[linked], np.arange(n_stages + 1)).astype(np.int32)
+    eng.cut(SET_TRIALS, SET_SEGMENTS, starts[order], window)
+    eng.set_overlaps(SET_SEGMENTS, stage_start, links, link_start)
+    return E.DeviceTrials(segs, eng, SET_SEGMENTS, parent_set=SET_TRIALS, unit_of=unit_of)
 
 
 class FitSession:

@@ -460,6 +460,7 @@ static void free_set(vlgp_ctx* ctx, UnitSet& us) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     if (!us.alias) { fr(us.y); fr(us.x); fr(us.mu); fr(us.v); fr(us.w); }
     fr(us.dmu); fr(us.d_off); fr(us.d_src_start); fr(us.d_unit_prior); fr(us.d_xb); fr(us.d_scratch); fr(us.d_mu_stash);
+    fr(us.d_links);
     us = UnitSet();
 }
 
@@ -969,6 +970,41 @@ extern "C" int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed) {
     return end_count(ctx, n_failed);
 }
 
+// core.estep over overlapping segments, as the reference's sequential loop over VIEWS does it (vlgp/core.py:123-126 with
+// vlgp/util.py:482-496): stage by stage; before a stage the shared rows (mu while it is still shared, v) come over from
+// the previous stage's units, after it they go back, so that both copies of a shared row always hold what the
+// reference's single row holds.  A stage is a contiguous range of equal-length units: a view of the set.
+static int estep_staged(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bound, int vb) {
+    const int W = us.Tmax, N = ctx->N, L = ctx->L, P = ctx->P;
+    CHK(vlgp_bind_priors(ctx, us));
+    const int n_stages = (int)us.stage_start.size() - 1;
+    for (int s = 0; s < n_stages; ++s) {
+        const int u0 = us.stage_start[s], cnt = us.stage_start[s + 1] - u0;
+        if (cnt < 1) continue;
+        CHK(launch_links_copy(ctx, us, us.link_start[s], us.link_start[s + 1], 0));
+        UnitSet v;
+        v.valid = true; v.M = cnt; v.rows = (int64_t)cnt * W; v.Tmax = v.Tmin = W;
+        v.off.resize(cnt + 1);
+        for (int m = 0; m <= cnt; ++m) v.off[m] = (int64_t)m * W;
+        v.d_off = us.d_off;  // 0, W, 2 W, ...: the first cnt + 1 entries serve any range of equal-length units
+        const int64_t r0 = (int64_t)u0 * W;
+        v.y = us.y + r0 * N; v.x = us.x ? us.x + r0 * P * N : nullptr;
+        v.mu = us.mu + r0 * L; v.v = us.v + r0 * L; v.w = us.w + r0 * L; v.dmu = us.dmu + r0 * L;
+        v.x_ones = us.x_ones; v.alias = true;  // (owns nothing)
+        v.d_unit_prior = us.d_unit_prior + u0; v.prior_epoch = us.prior_epoch;
+        if (!us.x_ones) {
+            if (!us.d_xb) HIPCHK(ctx, hipMalloc(&us.d_xb, (size_t)us.rows * N * sizeof(double)));
+            v.d_xb = us.d_xb + r0 * N;
+        }
+        v.d_scratch = us.d_scratch; v.scratch_len = us.scratch_len;  // the stages run one after the other
+        const int rc = launch_estep(ctx, v, mode, n_iter, dmu_bound, vb);
+        us.d_scratch = v.d_scratch; us.scratch_len = v.scratch_len;  // (re)allocated inside: stays with the set
+        if (rc != VLGP_OK) return rc;
+        CHK(launch_links_copy(ctx, us, us.link_start[s], us.link_start[s + 1], 1));
+    }
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb, int* n_failed) {
     NEED_CTX(ctx);
     ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
@@ -981,8 +1017,50 @@ extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, 
     if (n_iter < 1) return VLGP_OK;  // core.py:24-25
     if (!(dmu_bound > 0)) return vlgp_fail(ctx, VLGP_ERR_ARG, "dmu_bound must be positive");
     CHK(begin_count(ctx));
-    CHK(launch_estep(ctx, *us, EM_FACTOR0 | EM_MEAN | EM_W | (vb ? EM_V : 0), n_iter, dmu_bound, vb ? 1 : 0));
+    const int mode = EM_FACTOR0 | EM_MEAN | EM_W | (vb ? EM_V : 0);
+    if (us->stage_start.size() > 2) CHK(estep_staged(ctx, *us, mode, n_iter, dmu_bound, vb ? 1 : 0));
+    else CHK(launch_estep(ctx, *us, mode, n_iter, dmu_bound, vb ? 1 : 0));
     return end_count(ctx, n_failed);
+}
+
+extern "C" int vlgp_set_overlaps(vlgp_ctx* ctx, int set, int n_stages, const int* stage_start, int n_links,
+                                 const int* links, const int* link_start) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (us->alias || us->Tmin != us->Tmax)
+        return vlgp_fail(ctx, VLGP_ERR_STATE, "overlaps belong to a copied cut of equal-length units");
+    if (n_stages < 1 || !stage_start || stage_start[0] != 0 || stage_start[n_stages] != us->M || n_links < 0 ||
+        (n_links > 0 && (!links || !link_start)))
+        return vlgp_fail(ctx, VLGP_ERR_ARG, "bad overlap description");
+    for (int s = 0; s < n_stages; ++s)
+        if (stage_start[s + 1] < stage_start[s]) return vlgp_fail(ctx, VLGP_ERR_ARG, "stages must be ordered");
+    for (int k = 0; k < n_links; ++k) {
+        const int a = links[3 * k], b = links[3 * k + 1], o = links[3 * k + 2];
+        if (a < 0 || a >= us->M || b < 0 || b >= us->M || o < 1 || o >= us->Tmax)
+            return vlgp_fail(ctx, VLGP_ERR_ARG, "bad overlap link %d", k);
+    }
+    us->stage_start.assign(stage_start, stage_start + n_stages + 1);
+    us->link_start.assign(n_links > 0 ? link_start : stage_start, (n_links > 0 ? link_start : stage_start) + n_stages + 1);
+    if (n_links == 0) us->link_start.assign(n_stages + 1, 0);
+    if (us->d_links) HIPCHK(ctx, hipFree(us->d_links));
+    us->d_links = nullptr;
+    us->n_links = n_links;
+    us->share_mu = true;
+    if (n_links > 0) {
+        HIPCHK(ctx, hipMalloc(&us->d_links, sizeof(int) * 3 * n_links));
+        HIPCHK(ctx, hipMemcpy(us->d_links, links, sizeof(int) * 3 * n_links, hipMemcpyHostToDevice));
+    }
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_unshare_mu(vlgp_ctx* ctx, int set) {
+    NEED_CTX(ctx);
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    us->share_mu = false;
+    return VLGP_OK;
 }
 
 extern "C" int vlgp_mstep_begin(vlgp_ctx* ctx, int set, int n_iter, int use_hessian, double eps, double lr,
@@ -1074,6 +1152,9 @@ extern "C" int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, 
     if (shift) memcpy(ctx->h_pinned + L * L, shift, sizeof(double) * L);
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_pinned, sizeof(double) * (L * L + L), hipMemcpyHostToDevice, ctx->stream));
     CHK(launch_latent_map(ctx, *us, ctx->d_work, shift ? ctx->d_work + L * L : nullptr));
+    // the set's units are independent copies: an IN-PLACE constraint of the reference (everything but "svd", which
+    // rebinds mu) visits a row shared by two overlapping segments twice -- the caller says so with vlgp_unshare_mu
+    CHK(launch_links_map(ctx, *us, ctx->d_work, shift ? ctx->d_work + L * L : nullptr));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // workspace and pinned buffer are reused
     return VLGP_OK;
 }

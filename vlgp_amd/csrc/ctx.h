@@ -44,6 +44,16 @@ struct UnitSet {
     double* d_scratch = nullptr;  // long-unit E-step scratch
     int64_t scratch_len = 0;
     double rows_all_ranks = 0.0;  // sum of `rows` over the ranks (M-step noise), exchanged on first use; 0 = unknown
+    // Overlapping segments of a non-aliased cut (trial lengths that are not multiples of the window, vlgp/util.py:482-496).
+    // In the reference they are VIEWS of the same trial rows: segment k + 1 starts its E-step from the mu, v that segment k
+    // left in the shared rows, and an in-place constraint touches a shared row once per segment that holds it.  Here the
+    // units are independent copies stored STAGE-MAJOR (stage = position in a chain of overlapping neighbours), the E-step
+    // runs stage by stage and the shared rows are copied forward before and back after each stage (vlgp_set_overlaps).
+    std::vector<int> stage_start;   // unit index of the first unit of each stage, + M at the end; empty: no overlaps
+    std::vector<int> link_start;    // per stage s: links [link_start[s], link_start[s + 1]) have their second unit in s
+    int* d_links = nullptr;         // (n_links, 3): first unit, second unit, shared rows
+    int n_links = 0;
+    bool share_mu = true;           // false once the segments' mu was rebound (constrain_loading "svd")
 };
 
 struct ProfSlot {
@@ -188,6 +198,10 @@ int launch_sample_posterior(vlgp_ctx* ctx, int T, int n, const double* d_mu, con
 int launch_npx_probe(vlgp_ctx* ctx, int kind, int64_t n, const double* d_a, const double* d_b, double* d_out);
 int launch_xb(vlgp_ctx* ctx, UnitSet& us);
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
+// shared rows of overlapping segments: dir 0 copies first unit's tail -> second unit's head (mu if share_mu, v), dir 1 back,
+// for the links [l0, l1); launch_links_map applies the latent map once more to both copies of every shared row
+int launch_links_copy(vlgp_ctx* ctx, UnitSet& us, int l0, int l1, int dir);
+int launch_links_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
 int launch_moments(vlgp_ctx* ctx, UnitSet& us);  // tri(L) gram | sum mu | sum v | sum mu^2 | |dmu|^2 at ctx->d_work
 int launch_project(vlgp_ctx* ctx, UnitSet& us, const double* d_proj, const double* d_shift, double* d_part,
                    double* d_out);  // mu = y proj - shift; d_out = column sums of y

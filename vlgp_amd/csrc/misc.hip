@@ -88,6 +88,71 @@ int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const dou
     return VLGP_OK;
 }
 
+// ---- shared rows of overlapping segments (UnitSet::d_links) ----
+__global__ void __launch_bounds__(256)
+links_copy_kernel(const int* links, int l0, int l1, int window, int L, int dir, int do_mu, double* mu, double* v) {
+    for (int k = l0 + blockIdx.x; k < l1; k += gridDim.x) {
+        const int ua = links[3 * k], ub = links[3 * k + 1], o = links[3 * k + 2];
+        const int64_t ra = ((int64_t)ua * window + window - o) * L, rb = (int64_t)ub * window * L;  // tail of a, head of b
+        for (int i = threadIdx.x; i < o * L; i += 256) {
+            if (dir == 0) {
+                if (do_mu) mu[rb + i] = mu[ra + i];
+                v[rb + i] = v[ra + i];
+            } else {
+                if (do_mu) mu[ra + i] = mu[rb + i];
+                v[ra + i] = v[rb + i];
+            }
+        }
+    }
+}
+
+// the latent map once more on both copies of every shared row (an in-place constraint of the reference visits a shared
+// row once per segment that holds it: vlgp/core.py:374-388,413-416)
+__global__ void __launch_bounds__(256)
+links_map_kernel(const int* links, int n_links, int window, int L, const double* map, const double* shift, double* mu) {
+    extern __shared__ double sm[];
+    double* m_s = sm;
+    double* s_s = sm + L * L;
+    for (int i = threadIdx.x; i < L * L; i += 256) m_s[i] = map[i];
+    for (int i = threadIdx.x; i < L; i += 256) s_s[i] = shift ? shift[i] : 0.0;
+    __syncthreads();
+    for (int k = blockIdx.x; k < n_links; k += gridDim.x) {
+        const int ua = links[3 * k], ub = links[3 * k + 1], o = links[3 * k + 2];
+        for (int t = threadIdx.x; t < 2 * o; t += 256) {
+            const int64_t row = t < o ? (int64_t)ua * window + window - o + t : (int64_t)ub * window + (t - o);
+            double in[16], out[16];
+            for (int l = 0; l < L; ++l) in[l] = mu[row * L + l] - s_s[l];
+            for (int c = 0; c < L; ++c) {
+                double acc = 0.0;
+                for (int l = 0; l < L; ++l) acc = fma(in[l], m_s[l * L + c], acc);
+                out[c] = acc;
+            }
+            for (int c = 0; c < L; ++c) mu[row * L + c] = out[c];
+        }
+    }
+}
+
+int launch_links_copy(vlgp_ctx* ctx, UnitSet& us, int l0, int l1, int dir) {
+    if (l1 <= l0) return VLGP_OK;
+    const int window = us.Tmax;
+    int g = l1 - l0;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(links_copy_kernel, dim3(g), dim3(256), 0, ctx->stream, us.d_links, l0, l1, window, ctx->L, dir,
+                       us.share_mu ? 1 : 0, us.mu, us.v);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
+int launch_links_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift) {
+    if (us.n_links < 1 || !us.share_mu) return VLGP_OK;
+    const int L = ctx->L;
+    int g = us.n_links > 1024 ? 1024 : us.n_links;
+    hipLaunchKernelGGL(links_map_kernel, dim3(g), dim3(256), (size_t)(L * L + L) * 8, ctx->stream, us.d_links, us.n_links,
+                       us.Tmax, L, d_map, d_shift, us.mu);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
 int launch_gather(vlgp_ctx* ctx, UnitSet& src, UnitSet& dst, int window) {
     const int N = ctx->N, L = ctx->L, P = ctx->P;
     const int M = dst.M;

@@ -139,6 +139,17 @@ class Engine:
         off = np.arange(len(starts) + 1, dtype=np.int64) * int(window)
         self.sets[dst] = (len(starts), int(off[-1]), off)
 
+    def set_overlaps(self, set_id, stage_start, links, link_start):
+        """Overlapping units of a copied cut: see vlgp_set_overlaps (include/vlgp_hip.h)."""
+        stage_start = np.ascontiguousarray(stage_start, dtype=np.int32)
+        links = np.ascontiguousarray(links, dtype=np.int32).reshape(-1, 3)
+        link_start = np.ascontiguousarray(link_start, dtype=np.int32)
+        self._ck(self.lib.vlgp_set_overlaps(self.h, set_id, len(stage_start) - 1, iptr(stage_start), len(links),
+                                            iptr(links), iptr(link_start)))
+
+    def unshare_mu(self, set_id):
+        self._ck(self.lib.vlgp_unshare_mu(self.h, set_id))
+
     def merge(self, cut_set):
         self.state_epoch += 1
         self._ck(self.lib.vlgp_merge_units(self.h, cut_set))
@@ -387,12 +398,13 @@ class DeviceTrials(list):
     mu/v/w/dmu are refreshed only by :meth:`pull` (callbacks, end of fit).
     """
 
-    def __init__(self, trials, engine, set_id, parent_set=None):
+    def __init__(self, trials, engine, set_id, parent_set=None, unit_of=None):
         super().__init__(trials)
         self.engine = engine
         self.set_id = set_id
         self.parent_set = parent_set  # segments: the set of the trials they were cut from
         self.detached = False         # True once the segments' mu stopped writing through (constrain_loading "svd")
+        self.unit_of = unit_of        # overlapping segments are stored stage-major: list index -> unit of the set
 
     def pull(self, keys=("mu", "v", "w", "dmu")):
         """Copy device state into the dicts: mu, v, dmu in place, w rebound
@@ -400,7 +412,8 @@ class DeviceTrials(list):
         got = self.engine.download(self.set_id, keys)
         _, _, off = self.engine.sets[self.set_id]
         for i, tr in enumerate(self):
-            sl = slice(int(off[i]), int(off[i + 1]))
+            u = i if self.unit_of is None else int(self.unit_of[i])
+            sl = slice(int(off[u]), int(off[u + 1]))
             for k in keys:
                 if k == "w" or tr.get(k) is None or tr[k].shape != got[k][sl].shape:
                     tr[k] = got[k][sl].copy()
@@ -627,6 +640,8 @@ def constrain_loading(trials, params, config):
             # starts from it).  Keep that copy; FitSession.finish puts it back after the merge.
             trials.engine.stash_mu(trials.parent_set)
             trials.detached = True
+            if trials.unit_of is not None:  # overlapping segments stop sharing their mu rows (v stays shared)
+                trials.engine.unshare_mu(trials.set_id)
         trials.engine.apply_latent_map(trials.set_id, mat)
         trials.engine.set_loading(params["a"])  # b and noise are untouched by this constraint
     else:
@@ -661,7 +676,13 @@ def constrain_latent(trials, params, config):
         scale = 1.0 / std
         params["a"] *= std[:, None]
     if isinstance(trials, DeviceTrials):
-        trials.engine.apply_latent_map(trials.set_id, np.diag(scale), shift)
+        if trials.unit_of is not None and kind == "both":
+            # overlapping segments: the reference shifts every segment, THEN scales every segment (core.py:377-388); a
+            # shared row sees each pass twice, so the two passes cannot be folded into one affine map
+            trials.engine.apply_latent_map(trials.set_id, np.eye(L), shift)
+            trials.engine.apply_latent_map(trials.set_id, np.diag(scale))
+        else:
+            trials.engine.apply_latent_map(trials.set_id, np.diag(scale), shift)
         _push_params(trials.engine, params)
     else:
         for tr in trials:
