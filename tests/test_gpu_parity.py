@@ -916,10 +916,10 @@ def test_deferred_initialisation_matches_host(V):
 
 
 def test_overlapping_cut_and_merge(V):
-    """Trial lengths that are not multiples of the window: segments overlap at random offsets
-    (util.cut_trial's multinomial draw), the device set is a gathered copy, and merging scatters the
-    segments back in order (the later segment wins an overlap, as sequential in-place updates of the
-    reference's views would leave it)."""
+    """Trial lengths that are not multiples of the window: segments overlap at random offsets (util.cut_trial's
+    multinomial draw).  The device set holds gathered copies, stored stage-major (`unit_of` maps a segment of the list to
+    its unit); an in-place latent map touches a row shared by two segments twice, in both copies, as the reference's
+    views would (vlgp/core.py:413-416); merging scatters the segments back."""
     from vlgp_amd.api import SET_SEGMENTS, SET_TRIALS, _segments
 
     rng = np.random.default_rng(4)
@@ -928,6 +928,7 @@ def test_overlapping_cut_and_merge(V):
                "v": rng.random((T, L)), "w": rng.random((T, L))} for T in lengths]
     for tr in trials:
         tr["x"] = np.ones((tr["y"].shape[0], 1, N))
+    mat, shift = np.array([[2.0, 0.5], [0.0, -1.0]]), np.array([0.25, -0.5])
     with V.Engine(N, L, 1, 50) as eng:
         eng.upload(SET_TRIALS, trials)
         np.random.seed(21)
@@ -936,24 +937,30 @@ def test_overlapping_cut_and_merge(V):
         np.random.seed(21)
         starts = [segment_starts(T, window) for T in lengths]
         assert len(segs) == sum(len(s) for s in starts) == 5 + 4 + 1 + 3
+        assert segs.unit_of is not None and sorted(segs.unit_of) == list(range(len(segs)))
         got = eng.download(SET_SEGMENTS, keys=("mu", "v", "w"))
+        unit_rows = np.concatenate([np.arange(u * window, (u + 1) * window) for u in segs.unit_of])
         want = {k: np.concatenate([tr[k][int(s):int(s) + window] for tr, st in zip(trials, starts) for s in st])
                 for k in ("mu", "v", "w")}
         for k in want:
-            assert np.array_equal(got[k], want[k]), k
-        # change the segments on the device, merge, and compare with the host emulation of the scatter
-        eng.apply_latent_map(SET_SEGMENTS, np.array([[2.0, 0.5], [0.0, -1.0]]), np.array([0.25, -0.5]))
-        seg_mu = eng.download(SET_SEGMENTS, keys=("mu",))["mu"]
+            assert np.array_equal(got[k][unit_rows], want[k]), k
+        eng.apply_latent_map(SET_SEGMENTS, mat, shift)
+        seg_mu = eng.download(SET_SEGMENTS, keys=("mu",))["mu"][unit_rows]
         eng.merge(SET_SEGMENTS)
         merged = eng.download(SET_TRIALS, keys=("mu",))["mu"]
-    expect = np.concatenate([tr["mu"] for tr in trials])
-    row0, i = 0, 0
-    for T, st in zip(lengths, starts):
-        for s in st:
-            expect[row0 + int(s):row0 + int(s) + window] = seg_mu[i * window:(i + 1) * window]
+    # host emulation with real views: every segment in turn, in place
+    host = [tr["mu"].copy() for tr in trials]
+    for mu_t, st in zip(host, starts):
+        for s_ in st:
+            view = mu_t[int(s_):int(s_) + window]
+            view[...] = (view - shift) @ mat
+    expect = np.concatenate(host)
+    assert relerr(merged, expect) < 1e-14
+    i = 0
+    for mu_t, st in zip(host, starts):  # and both copies of a shared row hold the view's value
+        for s_ in st:
+            assert relerr(seg_mu[i * window:(i + 1) * window], mu_t[int(s_):int(s_) + window]) < 1e-14
             i += 1
-        row0 += T
-    assert np.array_equal(merged, expect)
     with pytest.raises(ValueError, match="shorter than window"):
         with V.Engine(N, L, 1, 50) as eng:
             short = [{"y": np.zeros((30, N)), "mu": np.zeros((30, L)), "v": np.zeros((30, L)), "w": np.zeros((30, L)),
