@@ -161,7 +161,8 @@ int vlgp_mstep_end(vlgp_ctx* ctx, int* n_failed, double* device_ms);
  * n_eval independent evaluations in one call: evaluation e uses latent
  * latent[e] and log-parameters logp[3e..3e+2] = log(sigma^2, omega, eps).
  * Outputs the UN-negated ll[e] and dll[3e..3e+2] summed over all units of the
- * set (and over ranks).  Every unit must have exactly `window` rows, window <= 128
+ * set (and over ranks).  Every unit must have exactly `window` rows, window <= 1024 (4 ... 64: low-rank
+ * or dense round kernels; 65 ... 128: workgroup-per-segment kernels; above: generic kernels, matrices in global memory)
  * (windows <= 50 -- 50 is the reference's default -- share a dedicated kernel). */
 int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_eval,
                          const int* latent, const double* logp, double* ll,

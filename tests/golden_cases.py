@@ -47,6 +47,8 @@ CASES = {
     "window_100": dict(problem=dict(seed=9, n_bins=200, N=12), history=0, run=dict(max_iter=3, min_iter=3, window=100)),
     "all_gaussian": dict(problem=dict(seed=9, n_bins=200, N=12, n_gauss=12), history=0,
                          run=dict(max_iter=3, min_iter=3)),
+    "window_200": dict(problem=dict(seed=9, n_trials=3, n_bins=400, N=8), history=0,
+                       run=dict(max_iter=2, min_iter=2, window=200, omega_bound=(5e-4, 5e-3))),
     "history_2": dict(problem=dict(seed=5, n_trials=4, n_bins=100, N=10), history=2,
                       run=dict(max_iter=2, min_iter=2, omega_bound=(1e-3, 2e-2))),
 }

@@ -460,12 +460,13 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
     assert abs(got[1][0, 1] - want[1][1]) <= STAGE * max(abs(want[1][1]), 1e-3 * abs(want[0]))
 
 
-@pytest.mark.parametrize("T", [4, 7, 12, 20, 25, 40, 56, 64, 65, 80, 100, 127, 128])
+@pytest.mark.parametrize("T", [4, 7, 12, 20, 25, 40, 56, 64, 65, 80, 100, 127, 128, 129, 150, 200])
 def test_hstep_objective_other_windows_vs_oracle(V, T, monkeypatch):
     """Windows other than 50: up to 64 bins the low-rank round (any window from 4 bins; the K block compiled for 50 /
     64 with identity padding) or, above rank 32, the dense matrix-pipe round; 65..128 the workgroup-per-segment
     kernels (hstep_prep_big / hstep_seg_big: A split at row 64, both 64 x 64 inverses and the four products on the
-    matrix pipe): (ll, dll) against gp.obj_func's restatement; above 64 also against the generic kernels."""
+    matrix pipe); above 128 (round 4) the generic kernels with their matrices in global memory (any window, slow):
+    (ll, dll) against gp.obj_func's restatement; 65 ... 128 also against the generic kernels."""
     rng = np.random.default_rng(T)
     M, L = 6, 2
     units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": 2.0 * rng.random((T, L)),
@@ -475,14 +476,14 @@ def test_hstep_objective_other_windows_vs_oracle(V, T, monkeypatch):
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
         ll, dll = eng.hstep_objective(0, T, 1.0, np.arange(L), logp)
-        assert eng.last_hstep_path == ("big" if T > 64 else ("lowrank" if T < 56 else eng.last_hstep_path))
+        assert eng.last_hstep_path == ("generic" if T > 128 else "big" if T > 64 else ("lowrank" if T < 56 else eng.last_hstep_path))
     t = np.arange(T) * 1.0
     for l in range(L):
         want_ll, want_dll = O.gp_objective(logp[l], t, np.stack([u["mu"][:, l] for u in units], 1),
                                            np.stack([u["w"][:, l] for u in units], 1))
         assert abs(ll[l] - want_ll) <= STAGE * abs(want_ll), (T, l)
         assert abs(dll[l, 1] - want_dll[1]) <= 1e-7 * max(abs(want_dll[1]), 1e-3 * abs(want_ll)), (T, l)
-    if T > 64:
+    if 64 < T <= 128:
         monkeypatch.setenv("VLGP_HSTEP_GENERIC_SEG", "1")
         with V.Engine(2, L, 1, 50) as eng:
             eng.upload(0, units)

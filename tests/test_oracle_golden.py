@@ -173,7 +173,7 @@ def _oracle_branch_fit(name):
 
 
 BRANCHES = ["loading_svd", "loading_1", "loading_2", "loading_inf", "loading_off", "latent_location", "latent_scale",
-            "latent_both", "svd_and_both", "window_25", "window_40", "window_100", "all_gaussian", "history_2"]
+            "latent_both", "svd_and_both", "window_25", "window_40", "window_100", "window_200", "all_gaussian", "history_2"]
 
 
 @pytest.mark.parametrize("name", BRANCHES)

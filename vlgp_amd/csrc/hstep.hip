@@ -22,7 +22,8 @@
 #include "hstep_mfma.h"
 #include "hstep_lr.h"
 
-#define HS_MAXT 128  // generic kernels: rows are lane-strided, one T x T matrix per wave in LDS
+#define HS_MAXT 1024  // generic kernels: rows are lane-strided; one T x T matrix per wave, in LDS while it fits (T <= 128),
+                      // else in global memory (round 4: any window; slow, but the reference's own cost is T^3 per segment too)
 
 struct HPrepArgs {
     int T;
@@ -33,6 +34,7 @@ struct HPrepArgs {
     double* dk;          // (n_eval, T, T)
     double* scal;        // (n_eval, 4): logdet, tr(Kinv dK), omega_used, ok
     double* tm;          // (n_eval, T, T) scratch for K^-1 dK when the four matrices do not fit LDS, else null
+    double* km;          // (n_eval, T, T | 1) the factor's matrix in global memory when even it does not fit LDS, else null
 };
 
 __device__ __forceinline__ void hs_wave_sync() {
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(256) hstep_prep_kernel(HPrepArgs A) {
     const int T = A.T, ls = T | 1;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t base = (int64_t)e * T * T;
-    double* Km = smem;            // T x ls : K, then chol, then X
+    double* Km = A.km ? A.km + (int64_t)e * T * ls : smem;  // T x ls : K, then chol, then X
     // small windows keep all four matrices in LDS; large ones work on the output buffers in L2
     double* Ki = A.tm ? A.kinv + base : Km + T * ls;     // T x T  : K^-1
     double* Dk = A.tm ? A.dk + base : Ki + T * T;        // T x T  : dK/dln omega
@@ -174,6 +176,7 @@ struct HSegArgs {
     const double* dk;
     const double* scal;
     double* out;         // (n_eval, M, 2)
+    double* bmat;        // (n_eval, M, T, T | 1) one matrix per (evaluation, segment) in global memory, or null: LDS
 };
 
 // one wavefront per (segment, evaluation)
@@ -184,9 +187,9 @@ __global__ void __launch_bounds__(256) hstep_seg_kernel(HSegArgs A) {
     const int seg = blockIdx.x * nw + wid;
     const int e = blockIdx.y;
     if (seg >= A.M) return;
-    double* B = smem + (int64_t)wid * (T * ls + 2 * HS_MAXT);
-    double* muv = B + T * ls;
-    double* alv = muv + HS_MAXT;
+    double* B = A.bmat ? A.bmat + ((int64_t)e * A.M + seg) * T * ls : smem + (int64_t)wid * (T * ls + 2 * T);
+    double* muv = A.bmat ? smem + (int64_t)wid * 2 * T : B + T * ls;
+    double* alv = muv + T;
     const int l = A.latent[e];
     const int64_t r0 = A.off[seg];
     const double* Ki = A.kinv + (int64_t)e * T * T;
@@ -1030,6 +1033,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                              const double* logp, double* ll, double* dll, bool force_dense) {
     const int T = window, L = ctx->L, M = us.M;
     if (T > HS_MAXT) return vlgp_fail(ctx, VLGP_ERR_ARG, "H-step kernel supports window <= %d, got %d", HS_MAXT, T);
+    const bool huge = (size_t)(T * (T | 1)) * 8 > 150 * 1024;  // (T > ~138): not even one matrix per workgroup fits LDS
     if (us.Tmin != T || us.Tmax != T)
         return vlgp_fail(ctx, VLGP_ERR_STATE, "H-step needs every unit to have exactly window=%d rows", T);
     // the T = 50 kernels, identity-padded; below ~half the compiled size the padding costs more than the
@@ -1051,7 +1055,9 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     const int64_t o_lat = o_logp + 3 * n_eval, o_qsum = o_lat + n_eval + 8, o_mpart = o_qsum + 2 * n_eval + 2;
     const int64_t o_tm = o_mpart + (fast ? (int64_t)L * 64 * TT : 0);
     // low-rank round: tables | meta | pair codes (doubles; each region 16-byte aligned)
-    const int64_t o_lrtab = (o_tm + (T > 64 ? n_eval * TT : 0) + 1) & ~1LL;
+    const int64_t o_km = o_tm + (T > 64 ? n_eval * TT : 0);
+    const int64_t o_bmat = o_km + (huge ? (int64_t)n_eval * T * (T | 1) : 0);
+    const int64_t o_lrtab = (o_bmat + (huge ? (int64_t)n_eval * M * T * (T | 1) : 0) + 1) & ~1LL;
     const int64_t o_lrmeta = o_lrtab + (fast ? (int64_t)n_eval * 2 * LR_TROWS * LR_RCAP : 0);
     const int64_t o_lrpairs = o_lrmeta + (fast ? (int64_t)n_eval * 4 : 0);
     const int64_t total = o_lrpairs + (fast ? ((int64_t)n_eval * LR_NPAIR * 2 + 7) / 8 : 0);
@@ -1282,9 +1288,14 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     P.scal = W + o_scal;
     size_t lds_prep = (size_t)(T * (T | 1) + 3 * TT) * 8;
     P.tm = nullptr;
+    P.km = nullptr;
     if (lds_prep > 150 * 1024) {  // large window: only the factor stays in LDS
         P.tm = W + o_tm;
         lds_prep = (size_t)(T * (T | 1)) * 8;
+    }
+    if (huge) {  // ... and beyond ~138 bins it works in global memory as well
+        P.km = W + o_km;
+        lds_prep = 0;
     }
     if (lds_prep > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_kernel),
@@ -1302,7 +1313,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     HIPCHK(ctx, hipGetLastError());
 
     HSegArgs S;
-    S.T = T; S.L = L; S.M = M; S.off = us.d_off; S.mu = us.mu; S.w = us.w;
+    S.T = T; S.L = L; S.M = M; S.off = us.d_off; S.mu = us.mu; S.w = us.w; S.bmat = nullptr;
     S.latent = reinterpret_cast<const int*>(W + o_lat);
     S.kinv = W + o_kinv; S.q = W + o_q; S.dk = W + o_dk; S.scal = W + o_scal; S.out = W + o_out;
     if (big) {  // one workgroup per segment, matrix pipe (hstep_seg_big)
@@ -1316,8 +1327,9 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         vlgp_prof_end(ctx, VLGP_PROF_HSTEP, (double)n_eval * M);
         HIPCHK(ctx, hipGetLastError());
     } else {
-    const int nw = (size_t)2 * (T * (T | 1) + 2 * HS_MAXT) * 8 <= 160 * 1024 ? 2 : 1;
-    const size_t lds_seg = (size_t)nw * (T * (T | 1) + 2 * HS_MAXT) * 8;
+    S.bmat = huge ? W + o_bmat : nullptr;
+    const int nw = huge ? 4 : ((size_t)2 * (T * (T | 1) + 2 * T) * 8 <= 160 * 1024 ? 2 : 1);
+    const size_t lds_seg = huge ? (size_t)nw * 2 * T * 8 : (size_t)nw * (T * (T | 1) + 2 * T) * 8;
     if (lds_seg > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_seg_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
