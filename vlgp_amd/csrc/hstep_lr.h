@@ -277,7 +277,7 @@ __host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_globa
     G.o_ud = tab_global ? 0 : ntp * G.LDU;
     G.o_mp = tab_global ? 0 : ((2 * ntp * G.LDU + 1) & ~1);
     G.o_xb = (G.o_mp + 16 * G.NPS + 1) & ~1;
-    G.o_red = G.o_xb + nw * 64;
+    G.o_red = G.o_xb + nw * 7 * 36;   // exchange buffers of phase 2: up to six segments (+ one idle slot) of <= 36 entries per wave
     G.o_codes = G.o_red + nw * 32 + 2;        // pair codes of the evaluation (LR_NPAIR unsigned shorts)
     G.total = G.o_codes + LR_NPAIR / 4;
     return G;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     const double* Ul = TABG ? tab_e : lds + G.o_u;
     const double* Udl = TABG ? tab_e + LR_TROWS * LR_RCAP : lds + G.o_ud;
     double* Mp = lds + G.o_mp;
-    double* xb = lds + G.o_xb + wid * 64;
+    double* xb = lds + G.o_xb + wid * 7 * 36;
     double* red = lds + G.o_red;
     unsigned short* codes = reinterpret_cast<unsigned short*>(lds + G.o_codes);
     for (int x = threadIdx.x; x < 16 * n_tiles; x += 64 * NW) codes[x] = pairs_e[x];  // (the tile loops read them from LDS)
@@ -413,6 +413,91 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     phase1(ns_tiles, n_tiles, am);
     __syncthreads();
     stamp(1);
+#ifndef LR_ROWWISE
+    // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps on the LOWER BLOCK TRIANGLE, six segments side by side.  The
+    // matrix is cut into 4 x 4 blocks of BS x BS entries (BS = RC / 4); lane <-> one of the ten blocks (I >= J) of one
+    // segment, its BS^2 entries in registers (diagonal blocks hold both triangles).  Sweep k (block K = k / BS, local
+    // index kl): the lanes of block column K / block row K hand column k (= row k) to the others through `xs`, then every
+    // lane updates its block with the BS multipliers of its rows and the BS pivot-row entries of its columns:
+    // BS^2 FMAs and 2 BS LDS reads per lane and sweep for SIX segments, against RC FMAs and RC reads for two in the
+    // lane-per-row layout this replaces (LR_ROWWISE), and one pass per wave instead of two. ----
+    {
+        // GB x GB blocks of BS x BS entries: four blocks a side up to rank 24 (ten lanes per segment, six segments per
+        // wave), five above (fifteen lanes, four segments: a 7 x 7 or 8 x 8 block per lane does not fit the registers)
+        constexpr int GB = RC <= 16 ? 4 : 5, BS = (RC + GB - 1) / GB, LPS = GB * (GB + 1) / 2, SPW = 64 / LPS;
+        const int sg = lane / LPS, li = lane - sg * LPS;
+        int I = 0;
+#pragma unroll
+        for (int q = 1; q < GB; ++q) I += li >= q * (q + 1) / 2 ? 1 : 0;
+        const int J = li - I * (I + 1) / 2;
+        for (int P = wid; P * SPW < 16; P += NW) {
+            int seg = P * SPW + sg;
+            const bool act = sg < SPW && seg < 16;
+            if (!act) seg = 0;
+            int iv = BS * I, jv = BS * J;  // opaque per pass: the packed indices are not worth registers across the sweeps
+            asm volatile("" : "+v"(iv), "+v"(jv));
+            double* Ms = Mp + seg * NPS;
+            double* xs = xb + (act ? sg : SPW) * (GB * BS);
+            double blk[BS][BS];
+#pragma unroll
+            for (int a_ = 0; a_ < BS; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < BS; ++b_) {
+                    const int i = iv + a_, j = jv + b_;
+                    const int hi = i > j ? i : j, lo = i > j ? j : i;
+                    const double v = Ms[(hi < r) ? hi * (hi + 1) / 2 + lo : NPZ];
+                    blk[a_][b_] = hi >= r ? (i == j ? 1.0 : 0.0) : v;  // unit diagonal beyond the rank
+                }
+            auto sweeps = [&]() {
+#pragma unroll
+                for (int k = 0; k < GB * BS; ++k) {
+                    if (k >= r) return;
+                    constexpr int dummy = 0;
+                    const int K = k / BS, kl = k % BS;
+                    const bool wc = J == K;            // this block holds column k for its rows (local column kl)
+                    const bool wr = I == K && J < K;   // this block holds row k for its columns (local row kl)
+                    if (wc || wr) {
+                        double* dst = xs + (wc ? BS * I : BS * J);
+#pragma unroll
+                        for (int a_ = 0; a_ < BS; ++a_) dst[a_] = wc ? blk[a_][kl] : blk[kl][a_];
+                    }
+                    tri_wave_order();
+                    const double dinv = lr_rcp(xs[k]);
+                    double f[BS], pc[BS];
+#pragma unroll
+                    for (int a_ = 0; a_ < BS; ++a_) {
+                        f[a_] = xs[BS * I + a_] * dinv;
+                        pc[a_] = xs[BS * J + a_];
+                    }
+                    if (I == K) f[kl] = 1.0 - dinv;    // the pivot row: a_kj - (1 - d) a_kj = d a_kj
+#pragma unroll
+                    for (int a_ = 0; a_ < BS; ++a_)
+#pragma unroll
+                        for (int b_ = 0; b_ < BS; ++b_) blk[a_][b_] = fma(-f[a_], pc[b_], blk[a_][b_]);
+                    if (wc) {
+#pragma unroll
+                        for (int a_ = 0; a_ < BS; ++a_) blk[a_][kl] = f[a_];
+                        if (I == K) blk[kl][kl] = -dinv;
+                    }
+                    tri_wave_order();
+                    (void)dummy;
+                }
+            };
+            sweeps();
+            // blk = -(M^-1) block; stored with the off-diagonal entries doubled: the contraction runs over i >= j
+            if (act) {
+#pragma unroll
+                for (int a_ = 0; a_ < BS; ++a_)
+#pragma unroll
+                    for (int b_ = 0; b_ < BS; ++b_) {
+                        const int i = iv + a_, j = jv + b_;
+                        const bool keep = i >= j && i < r;
+                        Ms[keep ? i * (i + 1) / 2 + j : NPZ + 1] = i == j ? -blk[a_][b_] : -2.0 * blk[a_][b_];
+                    }
+            }
+        }
+    }
+#else
     // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps, lane <-> row, SPP segments side by side.  Sweep k: every
     // lane hands its entry of column k (= row k, the matrix stays symmetric) to the others through `xs`; the lane that
     // holds row k hands over 1 / pivot instead.  Rows beyond the rank idle.  A sweep is one dependent chain (column
@@ -479,6 +564,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                 if (j < r) Ms[(rowok && j <= rowv) ? base + j : NPZ + 1] = j == rowv ? -a[j] : -2.0 * a[j];
         }
     }
+#endif
     __syncthreads();
     stamp(2);
     // ---- phase 3: < M^-1, U' diag(wt d) U > and < M^-1, Ud' diag(wt) U + U' diag(wt) Ud > ----
