@@ -42,6 +42,10 @@ extern "C" {
 
 #define VLGP_ABI_VERSION 1
 #define VLGP_MAX_SETS 4
+#define VLGP_MAX_L 64             /* latents per handle.  The reference has no bound (vlgp/core.py:76,106; gp.py:82);
+                                     up to 10 the specialised kernels run, up to 16 the register-resident generic
+                                     ones, above that loop-based fallbacks (slow, same results) */
+#define VLGP_MAX_XDIM 64          /* regressors per channel (1 + history, vlgp/preprocess.py:53): up to 8 specialised */
 #define VLGP_MAX_RANK 64          /* R <= 64 (the reference hard-codes 50, preprocess.py:75) */
 #define VLGP_UNIQUE_ID_BYTES 128
 

@@ -41,7 +41,7 @@ def _oracle_fit(fresh, a0, b0, lik, dims, xdim=1, **cfg_kw):
     n_trials, n_bins, N, L = dims
     ref = fresh()
     for t in ref:
-        t["x"] = np.ones((n_bins, xdim, N))
+        t.setdefault("x", np.ones((n_bins, xdim, N)))
         t["w"] = np.zeros((n_bins, L))
         t["v"] = np.zeros((n_bins, L))
     cfg = O.make_config(**cfg_kw)
@@ -161,6 +161,49 @@ def test_fit_with_history_two_regressors(V):
     assert got["params"]["xdim"] == 2 and got["params"]["b"].shape == (2, dims[2])
     assert got["trials"][0]["x"].shape == (dims[1], 2, dims[2])
     ref, params, _ = _oracle_fit(fresh, a0, b2, lik, dims, xdim=2, **run)
+    for k in ("a", "b", "noise", "omega"):
+        assert relerr(got["params"][k], params[k]) < TRAJ, k
+
+
+def test_fit_twenty_latents_vs_oracle(V):
+    """zdim = 20: the reference loops `for l in range(zdim)` with no bound (vlgp/core.py:76,106; gp.py:82).  Beyond
+    sixteen latents the loop-based fallbacks run (generic E-step with spilled per-latent arrays, mstep_*_gen, the
+    H-step's evaluations in slices of sixteen): two EM iterations with the H-step on against the oracle."""
+    fresh, a0, b0, lik, dims = _small_problem(seed=11, n_trials=4, n_bins=100, N=30, L=20)
+    run = dict(max_iter=2, min_iter=2, omega_bound=(1e-3, 1e-2))
+    got = V.fit(fresh(), 20, a=a0.copy(), b=b0.copy(), lik=lik, verbose=False, **run)
+    ref, params, _ = _oracle_fit(fresh, a0, b0, lik, dims, **run)
+    for k in ("a", "b", "noise", "omega", "sigma"):
+        assert relerr(got["params"][k], params[k]) < TRAJ, k
+    for tg, tr in zip(got["trials"], ref):
+        assert relerr(tg["mu"], tr["mu"]) < 1e-5
+        assert relerr(tg["w"], tr["w"]) < 1e-5
+
+
+def test_fit_with_eleven_regressors_and_gaussian_channels(V):
+    """history = 11 -> xdim = 11 > 8 (vlgp/preprocess.py:53), the trials bringing their own x (a constant column and
+    ten random regressors; preprocess.py:43-44 keeps a trial's x): the M-step's loop-based fallback with a general x --
+    Poisson Newton systems of 11 unknowns for b and the Gaussian channels' least squares, solved in global memory."""
+    fresh0, a0, b0, lik, dims = _small_problem(seed=12, n_trials=4, n_bins=100, N=10, n_gauss=3)
+    n_trials, n_bins, N, L = dims
+    xs = []
+    rng = np.random.default_rng(99)
+    for _ in range(n_trials):
+        x = 0.1 * rng.standard_normal((n_bins, 11, N))
+        x[:, 0, :] = 1.0
+        xs.append(x)
+
+    def fresh():
+        out = fresh0()
+        for t, x in zip(out, xs):
+            t["x"] = x.copy()
+        return out
+
+    b11 = np.vstack([b0] + [np.zeros_like(b0)] * 10)
+    run = dict(max_iter=2, min_iter=2, omega_bound=(1e-3, 2e-2))
+    got = V.fit(fresh(), L, a=a0.copy(), b=b11.copy(), lik=lik, history=11, verbose=False, **run)
+    assert got["params"]["xdim"] == 11 and got["params"]["b"].shape == (11, N)
+    ref, params, _ = _oracle_fit(fresh, a0, b11, lik, dims, xdim=11, **run)
     for k in ("a", "b", "noise", "omega"):
         assert relerr(got["params"][k], params[k]) < TRAJ, k
 

@@ -215,6 +215,8 @@ def test_estep_zero_iterations_is_noop(V, golden):
 
 def _random_problem(rng, lengths, N, L, P, n_gauss, rank=50):
     a = 0.4 * rng.standard_normal((L, N))
+    if L > 10:  # keep eta = mu a in the range of the few-latent cases (the E-step's Newton sweeps amplify rounding ~1e3
+        a *= 5.0 / L  # per sweep once rates reach e^7: 1e-12 after one sweep, 1e-6 after four, on either side)
     b = np.log(0.3) + 0.2 * rng.standard_normal((P, N))
     noise = 0.5 + rng.random(N)
     gauss = np.zeros(N, dtype=bool)
@@ -253,6 +255,10 @@ def _random_problem(rng, lengths, N, L, P, n_gauss, rank=50):
     dict(lengths=[65, 128, 1200], N=18, L=8, P=1, g=0),  # long-unit kernel, eight latents, just above 64 bins
 ])
 def test_estep_random_vs_oracle(V, case, estep_path):
+    _estep_case_vs_oracle(V, case, estep_path)
+
+
+def _estep_case_vs_oracle(V, case, estep_path):
     import zlib
     rng = np.random.default_rng(zlib.crc32(str(sorted(case.items())).encode()))
     units, params, gauss = _random_problem(rng, case["lengths"], case["N"], case["L"], case["P"], case["g"])
@@ -261,10 +267,24 @@ def test_estep_random_vs_oracle(V, case, estep_path):
                          params["noise"], gauss, params["cholesky"][u["y"].shape[0]], 4)
             for u in units]
     V.estep(units, params, cfg)
-    _ran(V, estep_path, "estep")
+    if estep_path is not None:
+        _ran(V, estep_path, "estep")
     for u, ref in zip(units, want):
         for k, r in zip(("mu", "v", "w", "dmu"), ref):
             assert relerr(u[k], r) < STAGE, (k, u["y"].shape)
+
+
+@pytest.mark.parametrize("case", [
+    dict(lengths=[50, 37, 120], N=26, L=20, P=1, g=3),   # twenty latents: the generic kernel compiled for 32
+    dict(lengths=[50, 50], N=12, L=40, P=2, g=0),        # forty latents (compiled for 64), regressors
+])
+def test_estep_more_than_sixteen_latents_vs_oracle(V, case):
+    """zdim > 16 (no bound in vlgp/core.py:68-113): the generic E-step kernel with its per-latent register arrays
+    compiled for 32 / 64 (they spill; same arithmetic)."""
+    from vlgp_amd import engine as E
+
+    _estep_case_vs_oracle(V, case, None)
+    assert E.TRACE.get("estep") == "generic"
 
 
 @pytest.mark.parametrize("omega,lo,hi", [(1.6e-2, 17, 20), (3e-2, 21, 24), (4.5e-2, 25, 32)])
@@ -331,6 +351,27 @@ def test_mstep_golden(V, golden, tag, key):
 def test_mstep_random_vs_oracle(V):
     rng = np.random.default_rng(11)
     units, params, gauss = _random_problem(rng, [50, 120, 64, 50, 50], 70, 5, 2, 9)
+    cat = lambda k: np.concatenate([u[k] for u in units], axis=0)
+    want = O.mstep_arrays(cat("y"), cat("x"), cat("mu"), cat("v"), params["a"], params["b"], gauss, 6)
+    V.mstep(units, params, V.get_config(Mniter=6))
+    for k, r in zip(("a", "b", "da", "db", "noise"), want):
+        assert relerr(params[k], r) < STAGE, k
+
+
+@pytest.mark.parametrize("tag", ["p1", "p3", "mixed"])
+def test_mstep_golden_through_the_loop_based_kernels(V, golden, tag, monkeypatch):
+    """The M-step fallback for more than 16 latents / 8 regressors (mstep_cache_gen, mstep_accum_gen, latent_moments_gen,
+    Newton systems in global memory), forced at the golden sizes: same reference fixtures, same tolerance."""
+    monkeypatch.setenv("VLGP_MSTEP_GENERIC", "1")
+    for key in ("H_25", "G_1"):
+        test_mstep_golden(V, golden, tag, key)
+
+
+@pytest.mark.parametrize("L,P", [(20, 1), (5, 11), (33, 9)])
+def test_mstep_many_latents_or_regressors_vs_oracle(V, L, P):
+    """zdim > 16 and xdim > 8 (no bound in vlgp/core.py:174-235): six Newton iterations against the oracle."""
+    rng = np.random.default_rng(100 + L + P)
+    units, params, gauss = _random_problem(rng, [50, 120, 64, 50, 50], 70, L, P, 9)
     cat = lambda k: np.concatenate([u[k] for u in units], axis=0)
     want = O.mstep_arrays(cat("y"), cat("x"), cat("mu"), cat("v"), params["a"], params["b"], gauss, 6)
     V.mstep(units, params, V.get_config(Mniter=6))

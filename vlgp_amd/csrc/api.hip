@@ -469,7 +469,8 @@ extern "C" int vlgp_create(int device, int N, int L, int P, int R, const uint8_t
     *out = nullptr;
     if (N < 1 || L < 1 || P < 1 || R < 1) return vlgp_fail(nullptr, VLGP_ERR_ARG, "N, L, P, R must be positive");
     if (R > VLGP_MAX_RANK) return vlgp_fail(nullptr, VLGP_ERR_ARG, "rank %d exceeds VLGP_MAX_RANK=%d", R, VLGP_MAX_RANK);
-    if (L > 16) return vlgp_fail(nullptr, VLGP_ERR_ARG, "at most 16 latents supported, got %d", L);
+    if (L > VLGP_MAX_L) return vlgp_fail(nullptr, VLGP_ERR_ARG, "at most %d latents supported, got %d", VLGP_MAX_L, L);
+    if (P > VLGP_MAX_XDIM) return vlgp_fail(nullptr, VLGP_ERR_ARG, "at most %d regressors supported, got %d", VLGP_MAX_XDIM, P);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1)

@@ -402,7 +402,10 @@ static int launch_l(vlgp_ctx* ctx, const EstepArgs& A, int M, int nthr, size_t l
     if (L <= 8) return launch_t<SMALL, 8>(ctx, A, M, nthr, lds);
     if (L <= 10) return launch_t<SMALL, 10>(ctx, A, M, nthr, lds);
     if (L <= 16) return launch_t<SMALL, 16>(ctx, A, M, nthr, lds);
-    return vlgp_fail(ctx, VLGP_ERR_ARG, "E-step kernel supports at most 16 latents, got %d", L);
+    // beyond sixteen latents the per-latent register arrays of the (T x N) passes spill: slow, same arithmetic
+    if (L <= 32) return launch_t<SMALL, 32>(ctx, A, M, nthr, lds);
+    if (L <= 64) return launch_t<SMALL, 64>(ctx, A, M, nthr, lds);
+    return vlgp_fail(ctx, VLGP_ERR_ARG, "E-step kernel supports at most 64 latents, got %d", L);
 }
 
 static int pick_rg(int T, int N, int nthr) {
@@ -443,7 +446,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     lcsz = (lcsz + 1) & ~1LL;
 
     const int64_t LDS_MAX = 160 * 1024;
-    const int LTl = L <= 2 ? 2 : (L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : (L <= 10 ? 10 : 16))));  // as launch_l dispatches
+    const int LTl = L <= 2 ? 2 : (L <= 3 ? 3 : (L <= 5 ? 5 : (L <= 8 ? 8 : (L <= 10 ? 10 : (L <= 16 ? 16 : (L <= 32 ? 32 : 64))))));  // as launch_l dispatches
     const int64_t common = 2LL * LTl * N + 2LL * N + ((L + 1) & ~1);
     const int64_t ints = ((int64_t)N + 4 * L + 1) / 2 + 1;
 

@@ -25,7 +25,7 @@ latent_map_kernel(int64_t rows, int L, const double* map, const double* shift, d
     for (int i = threadIdx.x; i < L; i += 256) s_s[i] = shift ? shift[i] : 0.0;
     __syncthreads();
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
-        double in[16], out[16];
+        double in[VLGP_MAX_L], out[VLGP_MAX_L];
         for (int l = 0; l < L; ++l) in[l] = mu[t * L + l] - s_s[l];
         for (int c = 0; c < L; ++c) {
             double s = 0.0;
@@ -81,7 +81,6 @@ int launch_xb(vlgp_ctx* ctx, UnitSet& us) {
 
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift) {
     const int L = ctx->L;
-    if (L > 16) return vlgp_fail(ctx, VLGP_ERR_ARG, "latent map supports at most 16 latents");
     hipLaunchKernelGGL(latent_map_kernel, dim3(grid_for(us.rows)), dim3(256), (size_t)(L * L + L) * 8, ctx->stream,
                        us.rows, L, d_map, d_shift, us.mu);
     HIPCHK(ctx, hipGetLastError());
@@ -120,7 +119,7 @@ links_map_kernel(const int* links, int n_links, int window, int L, const double*
         const int ua = links[3 * k], ub = links[3 * k + 1], o = links[3 * k + 2];
         for (int t = threadIdx.x; t < 2 * o; t += 256) {
             const int64_t row = t < o ? (int64_t)ua * window + window - o + t : (int64_t)ub * window + (t - o);
-            double in[16], out[16];
+            double in[VLGP_MAX_L], out[VLGP_MAX_L];
             for (int l = 0; l < L; ++l) in[l] = mu[row * L + l] - s_s[l];
             for (int c = 0; c < L; ++c) {
                 double acc = 0.0;

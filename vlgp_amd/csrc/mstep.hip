@@ -340,6 +340,171 @@ latent_moments_kernel(int L, int64_t rows, const double* mu, const double* v, co
     emit(ke, acc[k]);
 }
 
+
+// ---- loop-based fallbacks: more than 16 latents or more than 8 regressors --------------------------------------
+// The kernels above keep a channel's 2 L + L (L + 1) / 2 + ... sums in registers, unrolled over the compiled (LT, PT):
+// fine up to sixteen latents / eight regressors, hopeless at sixty-four (2 200 sums).  The reference has no bound on
+// either (vlgp/core.py:181-220 works on whole arrays), so beyond the compiled sizes the same sums are formed
+// eight at a time: a first pass leaves the quantity every Newton / noise sum shares -- the rate exp(eta + v a^2 / 2),
+// or the residual y - eta -- in a (rows x N) cache, then each (row block, channel tile, group of eight statistics)
+// workgroup walks its rows once.  A statistic is a product of up to three per-(row, channel) factors, named by a code.
+// Same partial-sum layout as mstep_accum, so the fixed-order reduction and the solve kernels follow unchanged.
+enum { T_ONE = 0, T_MU, T_V, T_MT, T_X, T_Y, T_C };
+#define MG_CH 8
+
+// k-th lower-triangle pair in row-major order: k = i (i + 1) / 2 + j, j <= i
+__device__ __forceinline__ void tri_ij(int k, int& i, int& j) {
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= k) ++r;
+    i = r;
+    j = k - r * (r + 1) / 2;
+}
+
+__device__ void mg_stat_code(int kind, int L, int P, int k, int& t1, int& i1, int& t2, int& i2, int& t3) {
+    t1 = T_ONE; i1 = 0; t2 = T_ONE; i2 = 0; t3 = T_ONE;
+    if (kind == K_PREP) {  // mu'y | x'y | x'mu | x'x
+        if (k < L) { t1 = T_MU; i1 = k; t2 = T_Y; return; }
+        k -= L;
+        if (k < P) { t1 = T_X; i1 = k; t2 = T_Y; return; }
+        k -= P;
+        if (k < P * L) { t1 = T_X; i1 = k / L; t2 = T_MU; i2 = k % L; return; }
+        k -= P * L;
+        t1 = T_X; t2 = T_X;
+        tri_ij(k, i1, i2);
+    } else if (kind == K_NEWTON) {  // (mu + v a)'r | (mu + v a)' diag(r) (mu + v a) | v'r | x'r | x' diag(r) x
+        t3 = T_C;
+        if (k < L) { t1 = T_MT; i1 = k; return; }
+        k -= L;
+        if (k < tri(L)) { t1 = T_MT; t2 = T_MT; tri_ij(k, i1, i2); return; }
+        k -= tri(L);
+        if (k < L) { t1 = T_V; i1 = k; return; }
+        k -= L;
+        if (k < P) { t1 = T_X; i1 = k; return; }
+        k -= P;
+        t1 = T_X; t2 = T_X;
+        tri_ij(k, i1, i2);
+    } else if (kind == K_NOISE1) {
+        t1 = T_C;
+    } else {
+        t1 = T_C; t2 = T_C;
+    }
+}
+
+// cache[row, n] = rate (K_NEWTON; core.py:183) or y - eta (- mean[n]) (K_NOISE1 / K_NOISE2; core.py:177)
+__global__ void __launch_bounds__(256) mstep_cache_gen(MArgs A, int kind, double* cache) {
+    const int N = A.N, L = A.L, P = A.P;
+    const int64_t total = A.rows * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / N;
+        const int n = (int)(e - row * N);
+        double eta = 0.0, lin = 0.0;
+        for (int j = 0; j < P; ++j) eta = fma(A.x ? A.x[(row * P + j) * N + n] : 1.0, A.b[(int64_t)j * N + n], eta);
+        for (int l = 0; l < L; ++l) {
+            const double al = A.a[(int64_t)l * N + n];
+            eta = fma(A.mu[row * L + l], al, eta);
+            lin = fma(A.v[row * L + l], al * al, lin);
+        }
+        double out;
+        if (kind == K_NEWTON) out = A.gauss[n] ? 0.0 : fast_exp(clamp10(fma(0.5, lin, eta)));
+        else out = A.y[e] - eta - (kind == K_NOISE2 ? A.mean[n] : 0.0);
+        cache[e] = out;
+    }
+}
+
+// grid (row blocks, channel tiles of 256, groups of MG_CH statistics); thread <-> channel
+__global__ void __launch_bounds__(256) mstep_accum_gen(MArgs A, int kind, int K, const double* cache) {
+    __shared__ int code[MG_CH][5];
+    const int N = A.N, L = A.L, P = A.P;
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    const int k0 = blockIdx.z * MG_CH;
+    if (threadIdx.x < MG_CH) {
+        int t1, i1, t2, i2, t3;
+        const int k = k0 + threadIdx.x;
+        mg_stat_code(kind, L, P, k < K ? k : 0, t1, i1, t2, i2, t3);
+        int* c = code[threadIdx.x];
+        c[0] = t1; c[1] = i1; c[2] = t2; c[3] = i2; c[4] = t3;
+    }
+    __syncthreads();
+    const int64_t c0 = (int64_t)blockIdx.x * A.rows_per_wg;
+    int64_t c1 = c0 + A.rows_per_wg;
+    if (c1 > A.rows) c1 = A.rows;
+    if (n >= N) return;
+    double acc[MG_CH];
+#pragma unroll
+    for (int c = 0; c < MG_CH; ++c) acc[c] = 0.0;
+    const bool skip = kind == K_NEWTON && A.gauss[n] != 0;  // Gaussian channels need no rate statistics
+    auto fetch = [&](int t, int i, int64_t row) -> double {
+        switch (t) {
+            case T_MU: return A.mu[row * L + i];
+            case T_V: return A.v[row * L + i];
+            case T_MT: return fma(A.v[row * L + i], A.a[(int64_t)i * N + n], A.mu[row * L + i]);
+            case T_X: return A.x ? A.x[(row * P + i) * N + n] : 1.0;
+            case T_Y: return A.y[row * N + n];
+            case T_C: return cache[row * N + n];
+            default: return 1.0;
+        }
+    };
+    if (!skip) {
+        for (int64_t row = c0; row < c1; ++row) {
+#pragma unroll
+            for (int c = 0; c < MG_CH; ++c) {
+                const int* cd = code[c];
+                const double f1 = fetch(cd[0], cd[1], row), f2 = fetch(cd[2], cd[3], row), f3 = fetch(cd[4], 0, row);
+                acc[c] = fma(f1 * f3, f2, acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MG_CH; ++c)
+        if (k0 + c < K) A.partial[((int64_t)blockIdx.x * K + k0 + c) * N + n] = acc[c];
+}
+
+// latent_moments_kernel for any L: grid (G, groups of MG_CH statistics), same row striding and partial layout
+__global__ void __launch_bounds__(256)
+latent_moments_gen(int L, int64_t rows, const double* mu, const double* v, const double* dmu, double* partial) {
+    __shared__ double red[256];
+    const int K = tri(L) + 3 * L + 1;
+    const int k0 = blockIdx.y * MG_CH;
+    double acc[MG_CH];
+#pragma unroll
+    for (int c = 0; c < MG_CH; ++c) acc[c] = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < MG_CH; ++c) {
+            int k = k0 + c;
+            if (k >= K) continue;
+            double val;
+            if (k < tri(L)) {
+                int i, j;
+                tri_ij(k, i, j);
+                val = mu[t * L + i] * mu[t * L + j];
+            } else if ((k -= tri(L)) < L) {
+                val = mu[t * L + k];
+            } else if ((k -= L) < L) {
+                val = v ? v[t * L + k] : 0.0;
+            } else if ((k -= L) < L) {
+                val = mu[t * L + k] * mu[t * L + k];
+            } else {
+                val = 0.0;
+                if (dmu)
+                    for (int l = 0; l < L; ++l) val = fma(dmu[t * L + l], dmu[t * L + l], val);
+            }
+            acc[c] += val;
+        }
+    }
+    for (int c = 0; c < MG_CH; ++c) {
+        if (k0 + c >= K) break;
+        __syncthreads();
+        red[threadIdx.x] = acc[c];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * K + k0 + c] = red[0];
+    }
+}
+
 // ---- per-channel Newton / least-squares update -----------------------------
 #define SOLVE_MAXD 16
 // in-place Cholesky solve of the packed-lower SPD system H x = g (dimension d);
@@ -380,11 +545,20 @@ struct SolveArgs {
     const int* gauss;
     double *a, *b, *da, *db;
     int* fail;
+    double* hws;          // systems beyond SOLVE_MAXD: per channel D (D + 3) doubles of global workspace, else null
 };
 
 __device__ void mstep_solve_channel(const SolveArgs& A, int n) {
     const int N = A.N, L = A.L, P = A.P;
-    double H[SOLVE_MAXD * SOLVE_MAXD], g[SOLVE_MAXD];
+    double Hl[SOLVE_MAXD * SOLVE_MAXD], gl[SOLVE_MAXD], gsl[SOLVE_MAXD], anl[SOLVE_MAXD];
+    double *H = Hl, *g = gl, *gs = gsl, *an = anl;
+    if (A.hws) {  // (L or P beyond the register-sized arrays)
+        const int D = L > P ? L : P;
+        H = A.hws + (int64_t)n * D * (D + 3);
+        g = H + (int64_t)D * D;
+        gs = g + D;
+        an = gs + D;
+    }
     const double* MtY = A.prep;                       // L rows
     const double* XtY = A.prep + (int64_t)L * N;      // P rows
     const double* XtM = XtY + (int64_t)P * N;         // P*L rows: [j*L + l]
@@ -403,7 +577,6 @@ __device__ void mstep_solve_channel(const SolveArgs& A, int n) {
             for (int i = 0; i < L; ++i)
                 for (int j = 0; j <= i; ++j, ++k) H[i * L + j] = Hs[(int64_t)k * N + n];
             for (int l = 0; l < L; ++l) H[l * L + l] += rv[(int64_t)l * N + n] + A.eps;
-            double gs[SOLVE_MAXD];
             for (int l = 0; l < L; ++l) gs[l] = g[l];
             if (chol_solve_small(L, H, gs)) {
                 for (int l = 0; l < L; ++l) g[l] = gs[l];
@@ -426,7 +599,6 @@ __device__ void mstep_solve_channel(const SolveArgs& A, int n) {
             for (int i = 0; i < P; ++i)
                 for (int j = 0; j <= i; ++j, ++k) H[i * P + j] = Hb[(int64_t)k * N + n];
             for (int j = 0; j < P; ++j) H[j * P + j] += A.eps;
-            double gs[SOLVE_MAXD];
             for (int j = 0; j < P; ++j) gs[j] = g[j];
             if (chol_solve_small(P, H, gs)) {
                 for (int j = 0; j < P; ++j) g[j] = gs[j];
@@ -460,7 +632,6 @@ __device__ void mstep_solve_channel(const SolveArgs& A, int n) {
             return;
         }
         for (int l = 0; l < L; ++l) A.a[(int64_t)l * N + n] = g[l];
-        double an[SOLVE_MAXD];
         for (int l = 0; l < L; ++l) an[l] = g[l];
         k = 0;
         for (int i = 0; i < P; ++i)
@@ -719,8 +890,26 @@ static int launch_accum_p(vlgp_ctx* ctx, int kind, const Geometry& g, const MArg
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }
-static int launch_accum(vlgp_ctx* ctx, int kind, const Geometry& g, const MArgs& A) {
+// the loop-based fallback (mstep_cache_gen + mstep_accum_gen): cache = (rows x N) doubles of the M-step workspace
+// (VLGP_MSTEP_GENERIC=1 takes it at any size: the tests compare it with the specialised kernels)
+static bool mstep_generic(int L, int P) { return L > 16 || P > 8 || getenv("VLGP_MSTEP_GENERIC") != nullptr; }
+static int launch_accum_gen(vlgp_ctx* ctx, int kind, const Geometry& g, const MArgs& A, double* cache) {
+    hipStream_t st = ctx->mstream;
+    if (kind != K_PREP) {
+        int64_t blocks = (A.rows * A.N + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(mstep_cache_gen, dim3((unsigned)blocks), dim3(256), 0, st, A, kind, cache);
+    }
+    const int K = nstat_rt(A.L, A.P, kind);
+    hipLaunchKernelGGL(mstep_accum_gen, dim3(g.G, (A.N + 255) / 256, (K + MG_CH - 1) / MG_CH), dim3(256), 0, st, A, kind, K,
+                       cache);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
+static int launch_accum(vlgp_ctx* ctx, int kind, const Geometry& g, const MArgs& A, double* cache = nullptr) {
     const int L = A.L;
+    if (mstep_generic(A.L, A.P)) return launch_accum_gen(ctx, kind, g, A, cache);
     if (L <= 2) return launch_accum_p<2>(ctx, kind, g, A);
     if (L <= 3) return launch_accum_p<3>(ctx, kind, g, A);
     if (L <= 5) return launch_accum_p<5>(ctx, kind, g, A);
@@ -744,13 +933,15 @@ static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double*
     if (G > 256) G = 256;
     if (G < 1) G = 1;
     const int K = tri(L) + 3 * L + 1;
-    if (L <= 2) launch_lat_t<2>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
+    if (L > 16 || getenv("VLGP_MSTEP_GENERIC"))
+        hipLaunchKernelGGL(latent_moments_gen, dim3(G, (K + MG_CH - 1) / MG_CH), dim3(256), 0, st, L, us.rows, us.mu, us.v,
+                           us.dmu, d_partial);
+    else if (L <= 2) launch_lat_t<2>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     else if (L <= 3) launch_lat_t<3>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     else if (L <= 5) launch_lat_t<5>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     else if (L <= 8) launch_lat_t<8>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     else if (L <= 10) launch_lat_t<10>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else if (L <= 16) launch_lat_t<16>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
-    else return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 latents supported, got %d", L);
+    else launch_lat_t<16>(st, G, L, us.rows, us.mu, us.v, us.dmu, d_partial);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 63) / 64), dim3(512), 0, st, d_partial, G,
                        (int64_t)K, d_out);
@@ -771,8 +962,7 @@ int launch_moments(vlgp_ctx* ctx, UnitSet& us) {
 int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double eps, double lr,
                  double da_bound, double db_bound) {
     const int N = ctx->N, L = ctx->L, P = ctx->P;
-    if (L > SOLVE_MAXD || P > 8)
-        return vlgp_fail(ctx, VLGP_ERR_ARG, "M-step supports L <= 16 and xdim <= 8");
+    const bool gen = mstep_generic(L, P);  // beyond the compiled sizes: loop-based kernels, solves in global memory
     const Geometry g = plan(ctx, us.rows);
     const int Kp = nstat_rt(L, P, K_PREP), Kn = nstat_rt(L, P, K_NEWTON);
     const int Kl = tri(L) + 3 * L + 1;
@@ -782,11 +972,14 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     const int64_t o_s1 = o_lat + Kl + 8, o_mean = o_s1 + N, o_tick = o_mean + N, o_part = o_tick + 2;
     int64_t part_len = (int64_t)g.G * Kmax * N;
     if (part_len < 256LL * Kl) part_len = 256LL * Kl;
-    CHK(vlgp_ensure_work_m(ctx, o_part + part_len));
+    const int Dg = L > P ? L : P;
+    const int64_t o_cache = o_part + part_len, o_hws = o_cache + (gen ? us.rows * N : 0);
+    CHK(vlgp_ensure_work_m(ctx, o_hws + (gen ? (int64_t)N * Dg * (Dg + 3) : 0)));
     double* W = ctx->d_work_m;
     hipStream_t st = ctx->mstream;
     double *d_prep = W + o_prep, *d_stats = W + o_stats, *d_lat = W + o_lat, *d_s1 = W + o_s1,
            *d_mean = W + o_mean, *d_part = W + o_part;
+    double* d_cache = gen ? W + o_cache : nullptr;
     unsigned* d_ticket = reinterpret_cast<unsigned*>(W + o_tick);
 
     // Single rank, no per-launch timing: record the whole sequence once and replay it (see ctx.h).
@@ -827,7 +1020,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     };
 
     // sweep-invariant moments
-    CHK(launch_accum(ctx, K_PREP, g, A));
+    CHK(launch_accum(ctx, K_PREP, g, A, d_cache));
     CHK(reduce_to(Kp, d_prep));
     CHK(latent_moments(ctx, us, d_part, d_lat, true));
     double total_rows = (double)us.rows;
@@ -850,16 +1043,17 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     S.da_bound = da_bound; S.db_bound = db_bound;
     S.prep = d_prep; S.stats = d_stats; S.lat = d_lat; S.gauss = ctx->d_gauss;
     S.a = ctx->d_a; S.b = ctx->d_b; S.da = ctx->d_da; S.db = ctx->d_db; S.fail = ctx->d_fail_m;
+    S.hws = gen ? W + o_hws : nullptr;
 
     const bool any_poisson = ctx->n_gauss < N;
     for (int it = 0; it < n_iter; ++it) {
         if (it == n_iter - 1) {
             // noise = var(y - eta) with the parameters entering the last iteration (core.py:177)
-            CHK(launch_accum(ctx, K_NOISE1, g, A));
+            CHK(launch_accum(ctx, K_NOISE1, g, A, d_cache));
             CHK(reduce_to(1, d_s1));
             hipLaunchKernelGGL(noise_mean_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N,
                                total_rows, d_s1, d_mean);
-            CHK(launch_accum(ctx, K_NOISE2, g, A));
+            CHK(launch_accum(ctx, K_NOISE2, g, A, d_cache));
             CHK(reduce_to(1, d_s1));
             hipLaunchKernelGGL(noise_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N,
                                total_rows, d_s1, ctx->d_noise);
@@ -867,7 +1061,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
         }
         if (any_poisson) {
             vlgp_prof_begin(ctx, VLGP_PROF_MSTEP, st);
-            int rc = launch_accum(ctx, K_NEWTON, g, A);
+            int rc = launch_accum(ctx, K_NEWTON, g, A, d_cache);
             vlgp_prof_end(ctx, VLGP_PROF_MSTEP, (double)us.rows, st);
             CHK(rc);
             if (ctx->world == 1) {  // no all-reduce between the sum and the solves: one launch for both

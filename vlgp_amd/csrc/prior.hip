@@ -18,7 +18,7 @@
 
 struct IcholArgs {
     int T, R, L;
-    double omega[16], sigma[16];
+    double omega[VLGP_MAX_L], sigma[VLGP_MAX_L];
     double* full;        // (L, T, R) as the reference lays it out
     double* compact;     // latent l at l*T*R, (T, rank_l) row-major
     int* rl_table;       // (L) row of the device prior table, or null
@@ -246,12 +246,12 @@ prior_compact_kernel(int T, int R, const double* G, const int* rl, double* out) 
 
 static int ensure_mailbox(vlgp_ctx* ctx) {
     if (ctx->h_prior_mb) return VLGP_OK;
-    const size_t bytes = sizeof(int) * VLGP_PRIOR_SLOTS * 16 + 64;
+    const size_t bytes = sizeof(int) * VLGP_PRIOR_SLOTS * VLGP_MAX_L + 64;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prior_mb), bytes, hipHostMallocMapped));
     memset(ctx->h_prior_mb, 0, bytes);
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_prior_mb_host), ctx->h_prior_mb, 0));
-    HIPCHK(ctx, hipMalloc(&ctx->d_prior_mb, sizeof(int) * VLGP_PRIOR_SLOTS * 16 + 64));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_prior_mb, 0, sizeof(int) * VLGP_PRIOR_SLOTS * 16 + 64, ctx->stream));
+    HIPCHK(ctx, hipMalloc(&ctx->d_prior_mb, sizeof(int) * VLGP_PRIOR_SLOTS * VLGP_MAX_L + 64));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_prior_mb, 0, sizeof(int) * VLGP_PRIOR_SLOTS * VLGP_MAX_L + 64, ctx->stream));
     return VLGP_OK;
 }
 
@@ -270,12 +270,11 @@ static int launch_ichol_t(vlgp_ctx* ctx, const IcholArgs& A, size_t lds) {
 int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
                      bool in_table) {
     const int L = ctx->L, R = ctx->R;
-    if (L > 16) return vlgp_fail(ctx, VLGP_ERR_ARG, "at most 16 latents");
     CHK(ensure_mailbox(ctx));
-    int* flag_words = ctx->h_prior_mb + VLGP_PRIOR_SLOTS * 16;
+    int* flag_words = ctx->h_prior_mb + VLGP_PRIOR_SLOTS * VLGP_MAX_L;
     volatile unsigned long long* h_flag = reinterpret_cast<volatile unsigned long long*>(flag_words);
-    unsigned long long* d_flag = reinterpret_cast<unsigned long long*>(ctx->d_prior_mb_host + VLGP_PRIOR_SLOTS * 16);
-    unsigned* d_ticket = reinterpret_cast<unsigned*>(ctx->d_prior_mb + VLGP_PRIOR_SLOTS * 16);
+    unsigned long long* d_flag = reinterpret_cast<unsigned long long*>(ctx->d_prior_mb_host + VLGP_PRIOR_SLOTS * VLGP_MAX_L);
+    unsigned* d_ticket = reinterpret_cast<unsigned*>(ctx->d_prior_mb + VLGP_PRIOR_SLOTS * VLGP_MAX_L);
     // global scratch for the lengths whose residuals / pivots do not fit LDS
     int64_t gw = 0;
     for (Prior* pr : prs)
@@ -291,8 +290,8 @@ int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double
             for (int l = 0; l < L; ++l) { A.omega[l] = omega[l]; A.sigma[l] = sigma[l]; }
             A.full = pr.d_full; A.compact = pr.d_compact;
             A.rl_table = (in_table && ctx->d_prior_rl && pr.index >= 0) ? ctx->d_prior_rl + (int64_t)pr.index * L : nullptr;
-            A.rank_dev = ctx->d_prior_mb + j * 16;
-            A.rank_host = ctx->d_prior_mb_host + j * 16;
+            A.rank_dev = ctx->d_prior_mb + j * VLGP_MAX_L;
+            A.rank_host = ctx->d_prior_mb_host + j * VLGP_MAX_L;
             A.flag_host = d_flag;
             A.seq = last = ++ctx->prior_seq;
             A.ticket = d_ticket;
@@ -323,7 +322,7 @@ int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         for (size_t j = 0; j < cnt; ++j) {
             Prior& pr = *prs[base + j];
-            pr.rl.assign(ctx->h_prior_mb + j * 16, ctx->h_prior_mb + j * 16 + L);
+            pr.rl.assign(ctx->h_prior_mb + j * VLGP_MAX_L, ctx->h_prior_mb + j * VLGP_MAX_L + L);
         }
     }
     return VLGP_OK;

@@ -262,6 +262,10 @@ class Engine:
     def hstep_objective(self, set_id, window, dt, latents, logp):
         """Batched (ll, dll) for evaluations (latents[e], logp[e, :3])."""
         n = len(latents)
+        if n > 16:  # a call takes at most 16 evaluations (more than 16 latents in lock-step): in slices
+            logp = np.reshape(logp, (n, 3))
+            parts = [self.hstep_objective(set_id, window, dt, latents[i:i + 16], logp[i:i + 16]) for i in range(0, n, 16)]
+            return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         hb = self._hbuf
         if hb is None or hb[0] < n:  # persistent argument buffers: this is called ~40 times per EM iteration
             cap = max(16, n)
