@@ -302,15 +302,37 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
         }
     };
     const int c = lane & 15, g = lane >> 4;
+    // ---- loads that do not depend on the evaluation's meta record go out first: the weights' rows of w and (tables in
+    // LDS) the table entries this thread will copy.  The meta record, the tables and w are three global round trips
+    // (~1.5 us each with the chip full) that used to run one after the other in a workgroup that lives ~30 us. ----
+    const int h = T >> 1, nt = (T + 1) >> 1;
+    const int gs = seg0 + c;
+    const bool sval = gs < M;
+    const int64_t r0 = sval ? (int64_t)gs * T : 0;  // (every unit has T rows: off[m] = m T, no load)
+    (void)off;
+    double wpre1[NK], wpre2[NK];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        const int tau = 4 * kk + g;
+        wpre1[kk] = (sval && tau < nt) ? w[(r0 + tau) * L + l] : 0.0;
+        wpre2[kk] = (sval && tau < h) ? w[(r0 + T - 1 - tau) * L + l] : 0.0;
+    }
+    constexpr int TPRE = TABG ? 1 : (4 * NK * LR_RCAP + 64 * NW - 1) / (64 * NW);
+    double tpre[TPRE][2];
+    if constexpr (!TABG) {
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) {
+            const int x = threadIdx.x + q * 64 * NW;
+            const bool ok = x < 4 * NK * LR_RCAP;
+            tpre[q][0] = ok ? tab_e[x] : 0.0;
+            tpre[q][1] = ok ? tab_e[LR_TROWS * LR_RCAP + x] : 0.0;
+        }
+    }
     // wave-uniform by construction; said explicitly so that the rank guards below are scalar branches
     const int r = __builtin_amdgcn_readfirstlane(mt.r);
     const int ns_tiles = __builtin_amdgcn_readfirstlane(mt.ns_tiles), n_tiles = __builtin_amdgcn_readfirstlane(mt.n_tiles);
     // TABG: the tables stay in global memory (L1 / L2: 13 KB per evaluation, shared by its 250 workgroups) and the LDS
     // they would take goes to a third workgroup per CU (ranks 25 ... 31); needs a zero column, i.e. r < LR_RCAP
-    const int h = T >> 1, nt = (T + 1) >> 1;
-    const int gs = seg0 + c;
-    const bool sval = gs < M;
-    const int64_t r0 = sval ? off[gs] : 0;
     const LrGeom G = lr_geom(r, 4 * NK, NW, TABG);
     const double* Ul = TABG ? tab_e : lds + G.o_u;
     const double* Udl = TABG ? tab_e + LR_TROWS * LR_RCAP : lds + G.o_ud;
@@ -324,11 +346,13 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     if constexpr (!TABG) {
         double* Uw = lds + G.o_u;
         double* Udw = lds + G.o_ud;
-        for (int x = threadIdx.x; x < 4 * NK * LR_RCAP; x += 64 * NW) {  // (LR_RCAP = 32 columns per table row: shifts)
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) {  // (LR_RCAP = 32 columns per table row: shifts)
+            const int x = threadIdx.x + q * 64 * NW;
             const int tau = x >> 5, cc = x & 31;
-            if (cc < LDU) {  // columns >= r of the table are zero already
-                Uw[tau * LDU + cc] = tab_e[x];
-                Udw[tau * LDU + cc] = tab_e[LR_TROWS * LR_RCAP + x];
+            if (x < 4 * NK * LR_RCAP && cc < LDU) {  // columns >= r of the table are zero already
+                Uw[tau * LDU + cc] = tpre[q][0];
+                Udw[tau * LDU + cc] = tpre[q][1];
             }
         }
         if (LDU > LR_RCAP && threadIdx.x < 4 * NK) {  // full rank: the zero column lies beyond the table's
@@ -341,14 +365,14 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     // sweeps of phase 2, which need the room for the matrix rows)
     double ap[NK], am[NK], bp[NK], bm[NK];
     double dsum = 0.0;
-    auto weights = [&]() {
+    auto weights = [&](const double* p1, const double* p2) {
         dsum = 0.0;
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             const int tau = 4 * kk + g;
             const bool in1 = sval && tau < nt, in2 = sval && tau < h;
-            const double w1 = in1 ? w[(r0 + tau) * L + l] : 0.0;
-            const double w2 = in2 ? w[(r0 + T - 1 - tau) * L + l] : 0.0;
+            const double w1 = p1 ? p1[kk] : (in1 ? w[(r0 + tau) * L + l] : 0.0);
+            const double w2 = p2 ? p2[kk] : (in2 ? w[(r0 + T - 1 - tau) * L + l] : 0.0);
             const double d1 = lr_rcp(fma(eps, w1, 1.0)), d2 = lr_rcp(fma(eps, w2, 1.0));
             const double t1 = w1 * d1, t2 = w2 * d2;
             const double q1 = t1 * d1, q2 = t2 * d2;
@@ -360,7 +384,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
             dsum += (in1 ? d1 : 0.0) + (in2 ? d2 : 0.0);
         }
     };
-    weights();
+    weights(wpre1, wpre2);
     __syncthreads();
     stamp(0);
     // ---- phase 1: M = I + U' diag(wt) U, 16 pairs x 16 segments per tile; two tiles of one kind at a time (two
@@ -569,7 +593,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     stamp(2);
     // ---- phase 3: < M^-1, U' diag(wt d) U > and < M^-1, Ud' diag(wt) U + U' diag(wt) Ud > ----
     double ts[4] = {0.0, 0.0, 0.0, 0.0}, cs[4] = {0.0, 0.0, 0.0, 0.0};
-    weights();
+    weights(nullptr, nullptr);
     dsum += __shfl_xor(dsum, 16, 64);
     dsum += __shfl_xor(dsum, 32, 64);
     for (int q = wid; q < n_tiles; q += NW) {
