@@ -12,6 +12,7 @@ for _ in range(2):
 sid = sess.segs.set_id
 L = dims[3]
 eng.hstep_begin(sid, 50)
+os.environ["VLGP_HSTEP_LOWRANK"] = "1"  # (no size rule: this is what calibrates it)
 def timeit(lat, logp, dense):
     if dense: os.environ["VLGP_HSTEP_DENSE"] = "1"
     else: os.environ.pop("VLGP_HSTEP_DENSE", None)
@@ -27,8 +28,8 @@ def timeit(lat, logp, dense):
     eng.profile(False)
     os.environ.pop("VLGP_HSTEP_DENSE", None)
     return 1e6 * wall, 1e3 * ms / max(n, 1), eng.last_hstep_path, ll, dll
-for om in (1e-3, 2e-3, 4e-3, 6e-3, 8e-3, 1e-2, 1.3e-2, 1.6e-2):
-    for n_eval in (1, 5, 15):
+for om in [float(x) for x in os.environ.get("OMS", "1e-3,2e-3,4e-3,6e-3,8e-3,1e-2,1.3e-2,1.6e-2").split(",")]:
+    for n_eval in [int(x) for x in os.environ.get("NE", "1,5,15").split(",")]:
         lat = np.arange(n_eval, dtype=np.int32) % L
         logp = np.log(np.array([[1.0, om, 1e-4] for i in range(n_eval)]))
         w1, k1, p1, ll1, dll1 = timeit(lat, logp, False)

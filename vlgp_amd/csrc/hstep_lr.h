@@ -269,7 +269,23 @@ struct LrGeom {
     int LDU, NPS;
     int o_u, o_ud, o_mp, o_xb, o_red, o_codes, total;
 };
-__host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_global = false) {
+// doubles per wave of phase 2's exchange buffer for register class rc: one slot of GB BS entries per segment a wave
+// holds (block-triangle layout of lr_group: GB = 4 blocks a side up to class 16, 5 above)
+// class 32 keeps the lane-per-row sweeps: a 7 x 7 block per lane (98 registers) on top of the rest of the kernel
+// spills inside the sweep loop -- measured 284 us against 151 us for a round of five evaluations at rank 29
+__host__ __device__ constexpr bool lr_block_inverse(int rc) {
+#ifdef LR_ROWWISE
+    return false;
+#else
+    return rc <= 28;
+#endif
+}
+__host__ __device__ constexpr int lr_xs_per_wave(int rc) {
+    if (!lr_block_inverse(rc)) return 64;
+    const int gb = rc <= 16 ? 4 : 5, bs = (rc + gb - 1) / gb, lps = gb * (gb + 1) / 2, spw = 64 / lps;
+    return (spw * gb * bs + 1) & ~1;
+}
+__host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_global, int rc) {
     LrGeom G;
     G.LDU = tab_global ? LR_RCAP : ((r + 1) | 1);  // column r: zeros (padding pairs point at it)
     G.NPS = (r * (r + 1) / 2 + 2) | 1;     // packed lower triangle + a zero slot (padding pairs) + a trash slot
@@ -277,9 +293,15 @@ __host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_globa
     G.o_ud = tab_global ? 0 : ntp * G.LDU;
     G.o_mp = tab_global ? 0 : ((2 * ntp * G.LDU + 1) & ~1);
     G.o_xb = (G.o_mp + 16 * G.NPS + 1) & ~1;
-    G.o_red = G.o_xb + nw * 7 * 36;   // exchange buffers of phase 2: up to six segments (+ one idle slot) of <= 36 entries per wave
-    G.o_codes = G.o_red + nw * 32 + 2;        // pair codes of the evaluation (LR_NPAIR unsigned shorts)
-    G.total = G.o_codes + LR_NPAIR / 4;
+    // exchange buffers of phase 2; the partial sums of the final reduction (nw x 32 doubles) take the same place later.
+    // (Every double counts here: at ranks 23 ... 27 the packed matrices leave ~5 KB for everything else if three
+    // workgroups are to share a CU.)
+    G.o_red = G.o_xb;
+    const int xw = nw * lr_xs_per_wave(rc), rw = nw * 32 + 2;
+    G.o_codes = G.o_xb + (xw > rw ? xw : rw);  // pair codes of the evaluation (LR_NPAIR unsigned shorts)
+    int ncode = r * (r + 1) / 2 + 32;  // same-parity + cross pairs = r (r + 1) / 2, each list padded to a tile of 16
+    if (ncode > LR_NPAIR) ncode = LR_NPAIR;
+    G.total = G.o_codes + (ncode + 3) / 4;
     return G;
 }
 
@@ -333,11 +355,11 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     const int ns_tiles = __builtin_amdgcn_readfirstlane(mt.ns_tiles), n_tiles = __builtin_amdgcn_readfirstlane(mt.n_tiles);
     // TABG: the tables stay in global memory (L1 / L2: 13 KB per evaluation, shared by its 250 workgroups) and the LDS
     // they would take goes to a third workgroup per CU (ranks 25 ... 31); needs a zero column, i.e. r < LR_RCAP
-    const LrGeom G = lr_geom(r, 4 * NK, NW, TABG);
+    const LrGeom G = lr_geom(r, 4 * NK, NW, TABG, RC);
     const double* Ul = TABG ? tab_e : lds + G.o_u;
     const double* Udl = TABG ? tab_e + LR_TROWS * LR_RCAP : lds + G.o_ud;
     double* Mp = lds + G.o_mp;
-    double* xb = lds + G.o_xb + wid * 7 * 36;
+    double* xb = lds + G.o_xb + wid * lr_xs_per_wave(RC);
     double* red = lds + G.o_red;
     unsigned short* codes = reinterpret_cast<unsigned short*>(lds + G.o_codes);
     for (int x = threadIdx.x; x < 16 * n_tiles; x += 64 * NW) codes[x] = pairs_e[x];  // (the tile loops read them from LDS)
@@ -437,7 +459,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     phase1(ns_tiles, n_tiles, am);
     __syncthreads();
     stamp(1);
-#ifndef LR_ROWWISE
+    if constexpr (lr_block_inverse(RC)) {
     // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps on the LOWER BLOCK TRIANGLE, six segments side by side.  The
     // matrix is cut into 4 x 4 blocks of BS x BS entries (BS = RC / 4); lane <-> one of the ten blocks (I >= J) of one
     // segment, its BS^2 entries in registers (diagonal blocks hold both triangles).  Sweep k (block K = k / BS, local
@@ -461,7 +483,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
             int iv = BS * I, jv = BS * J;  // opaque per pass: the packed indices are not worth registers across the sweeps
             asm volatile("" : "+v"(iv), "+v"(jv));
             double* Ms = Mp + seg * NPS;
-            double* xs = xb + (act ? sg : SPW) * (GB * BS);
+            double* xs = xb + (act ? sg : 0) * (GB * BS);  // (idle lanes write nothing and read a neighbour's slot)
             double blk[BS][BS];
 #pragma unroll
             for (int a_ = 0; a_ < BS; ++a_)
@@ -480,7 +502,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                     const int K = k / BS, kl = k % BS;
                     const bool wc = J == K;            // this block holds column k for its rows (local column kl)
                     const bool wr = I == K && J < K;   // this block holds row k for its columns (local row kl)
-                    if (wc || wr) {
+                    if ((wc || wr) && act) {
                         double* dst = xs + (wc ? BS * I : BS * J);
 #pragma unroll
                         for (int a_ = 0; a_ < BS; ++a_) dst[a_] = wc ? blk[a_][kl] : blk[kl][a_];
@@ -521,7 +543,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
             }
         }
     }
-#else
+    } else {
     // ---- phase 2: M^-1 by symmetric Gauss-Jordan sweeps, lane <-> row, SPP segments side by side.  Sweep k: every
     // lane hands its entry of column k (= row k, the matrix stays symmetric) to the others through `xs`; the lane that
     // holds row k hands over 1 / pivot instead.  Rows beyond the rank idle.  A sweep is one dependent chain (column
@@ -588,7 +610,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                 if (j < r) Ms[(rowok && j <= rowv) ? base + j : NPZ + 1] = j == rowv ? -a[j] : -2.0 * a[j];
         }
     }
-#endif
+    }
     __syncthreads();
     stamp(2);
     // ---- phase 3: < M^-1, U' diag(wt d) U > and < M^-1, Ud' diag(wt) U + U' diag(wt) Ud > ----
