@@ -98,6 +98,40 @@ def pmc_traffic(kernel_key):
     return (hit or {}).get("hbm_bytes_per_launch")
 
 
+_STATS_CACHE = {}
+
+
+def rocprof_avg_ms(kernel_key):
+    """Average duration (ms) of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this command
+    (profiles/r*/*kernel_stats*.csv), same name matching as pmc_traffic; (None, None) when the kernel is not on file.
+    The live HIP-event figure brackets the launch on its stream -- with the second E-step lane or the M-step lane busy it
+    also contains the wait for the other lane's workgroups to drain -- while rocprofv3 reports the kernel's own span."""
+    import csv, glob
+
+    if not _STATS_CACHE:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*kernel_stats*.csv")))
+        newest = {}
+        for fpath in files:  # later rounds / later tags override
+            rnd = os.path.basename(os.path.dirname(fpath))
+            newest[rnd] = fpath
+        if newest:
+            fpath = newest[sorted(newest)[-1]]
+            try:
+                with open(fpath) as f:
+                    for row in csv.DictReader(f):
+                        name = row["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+                        _STATS_CACHE[name] = (float(row["AverageNs"]) * 1e-6, int(row["Calls"]), os.path.relpath(fpath, ROOT))
+            except Exception:
+                pass
+        _STATS_CACHE.setdefault("_", (None, 0, None))
+    hit = _STATS_CACHE.get(kernel_key)
+    if hit is None and kernel_key.endswith("*"):
+        cands = [k for k in sorted(_STATS_CACHE) if k.startswith(kernel_key[:-1])]
+        if cands:
+            hit = _STATS_CACHE[max(cands, key=lambda k: _STATS_CACHE[k][1])]
+    return (hit[0], hit[2]) if hit else (None, None)
+
+
 def host_info():
     model = "unknown"
     try:
@@ -406,6 +440,10 @@ def main():
     # north_star also asks for the HBM side of the factorisation kernels: measured bytes (PMC passes on
     # file, keyed by the exact kernel name) over the live launch time, against the 8 TB/s peak
     for kd in kernels.values():
+        ra, rsrc = rocprof_avg_ms(kd.get("pmc_key", ""))
+        if ra:
+            kd["avg_ms_rocprofv3"] = ra
+            kd["avg_ms_rocprofv3_source"] = rsrc
         tb = pmc_traffic(kd.get("pmc_key", ""))
         if tb:
             kd["hbm_bytes_per_launch_pmc"] = tb
@@ -421,6 +459,8 @@ def main():
                     "unit": kd["unit"], "frac": kd["frac"], "traffic": kd.get("hbm_bytes_per_launch_pmc"),
                     "hbm_gbs": kd.get("hbm_gbs"), "hbm_frac": kd.get("hbm_frac"),
                     "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"],
+                    "avg_launch_ms_rocprofv3": kd.get("avg_ms_rocprofv3"),
+                    "avg_launch_ms_rocprofv3_source": kd.get("avg_ms_rocprofv3_source"),
                     "units_per_launch": kd["units_per_launch"],
                     "algorithmic_flops_per_launch": kd.get("flops_per_launch_survey_count", kd["flops_per_launch_executed"]),
                     "executed_flops_per_launch": kd["flops_per_launch_executed"],
