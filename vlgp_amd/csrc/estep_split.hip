@@ -1494,11 +1494,15 @@ __global__ void __launch_bounds__(256, 4) elong_mean(SplitArgs A) {
 // the stream the launch helpers below enqueue on: the handle's main stream, or the second E-step lane (the unit set
 // split in two halves that run their sweeps side by side, launch_estep_split)
 static thread_local hipStream_t t_lane = nullptr;
+// (a helper reached without a lane would launch on the legacy null stream without a word)
+#define NEED_LANE(ctx) \
+    do { if (!t_lane) return vlgp_fail(ctx, VLGP_ERR_STATE, "split E-step launch helper called outside launch_estep_split"); } while (0)
 
 template <int LT, int CS, int RPL>
 int run_passes_cs(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
     constexpr int RPB = (256 / CS) * RPL;
     const dim3 grid((unsigned)((A.rows + RPB - 1) / RPB)), blk(256);
+    NEED_LANE(ctx);
     hipStream_t st = t_lane;
     if (A.xb) {
         if (kind == SP_RES) hipLaunchKernelGGL((esplit_pass<LT, SP_RES, true, CS, RPL>), grid, blk, 0, st, A, cols);
@@ -1513,6 +1517,7 @@ int run_passes_cs(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* col
 
 template <int LT>
 int run_passes(vlgp_ctx* ctx, const SplitArgs& A, int kind, const double* cols) {
+    NEED_LANE(ctx);
     if (kind == SP_YA) {
         const dim3 grid((unsigned)((A.rows + 255) / 256)), blk(256);
         if (A.xb) hipLaunchKernelGGL((esplit_pass<LT, SP_YA, true, 1, 1>), grid, blk, 0, t_lane, A, cols);
@@ -1552,6 +1557,7 @@ int run_ya(vlgp_ctx* ctx, const SplitArgs& A, int LT, const double* cols, const 
     if (A.N > 128 || old_form) return run_pass(ctx, A, LT, SP_YA, cols);
     const int rows_per_wave = 64;
     const dim3 grid((unsigned)((A.rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave))), blk(256);
+    NEED_LANE(ctx);
     hipStream_t st = t_lane;
 #define ESPLIT_YA(LTV, NJV) \
     hipLaunchKernelGGL((esplit_ya<LTV, NJV>), grid, blk, 0, st, A.N, A.L, A.rows, A.ld, A.y, ycoef, A.ya, rows_per_wave)
@@ -1571,6 +1577,7 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     const dim3 grid(A.shg ? (unsigned)(((A.M + 3) / 4) * A.n_lat) : (unsigned)((tasks + 3) / 4)), blk(256);
     static const int lds_pad = getenv("VLGP_LDS_PAD") ? atoi(getenv("VLGP_LDS_PAD")) : 0;  // occupancy experiments
     const size_t lds = (size_t)(4 * (A.pkl + A.lds_g + 128 + (mean ? 192 : 0)) + (A.shg ? A.shg_cap : 0)) * 8 + (size_t)lds_pad;
+    NEED_LANE(ctx);
     hipStream_t st = t_lane;
 #define ESPLIT_LAUNCH(RA, MEANV)                                                                                      \
     do {                                                                                                              \
@@ -1593,6 +1600,7 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
 int run_latent_long(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const unsigned tasks = (unsigned)(A.M * A.L);
     if (tasks == 0) return VLGP_OK;
+    NEED_LANE(ctx);
     if (mean) hipLaunchKernelGGL(elong_mean, dim3(tasks), dim3(256), (size_t)(LPK + 384) * 8, t_lane, A);
     else hipLaunchKernelGGL(elong_factor, dim3(tasks), dim3(256), (size_t)(LPK + LRED) * 8, t_lane, A);
     HIPCHK(ctx, hipGetLastError());
