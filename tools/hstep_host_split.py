@@ -13,9 +13,9 @@ for _ in range(8):
 eng = sess.eng
 orig = eng.hstep_objective
 acc = [0.0, 0]
-def timed(*a):
+def timed(*a, **kw):
     t = time.perf_counter()
-    r = orig(*a)
+    r = orig(*a, **kw)
     acc[0] += time.perf_counter() - t
     acc[1] += 1
     return r

@@ -259,8 +259,9 @@ class Engine:
         self._ck(self.lib.vlgp_mstep_end(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
-    def hstep_objective(self, set_id, window, dt, latents, logp):
-        """Batched (ll, dll) for evaluations (latents[e], logp[e, :3])."""
+    def hstep_objective(self, set_id, window, dt, latents, logp, copy=True):
+        """Batched (ll, dll) for evaluations (latents[e], logp[e, :3]).  copy=False hands out views of the call's
+        persistent result buffers (valid until the next call)."""
         n = len(latents)
         if n > 16:  # a call takes at most 16 evaluations (more than 16 latents in lock-step): in slices
             logp = np.reshape(logp, (n, 3))
@@ -273,9 +274,11 @@ class Engine:
             hb = self._hbuf = (cap, arrs, (iptr(arrs[0]), dptr(arrs[1]), dptr(arrs[2]), dptr(arrs[3])))
         (lat, lp, ll, dll), ptrs = hb[1], hb[2]
         lat[:n] = latents
-        lp[:n] = np.reshape(logp, (n, 3))
+        lp[:n] = logp if getattr(logp, "shape", None) == (n, 3) else np.reshape(logp, (n, 3))
         self._ck(self.lib.vlgp_hstep_objective(self.h, set_id, int(window), float(dt), n, *ptrs))
-        return ll[:n].copy(), dll[:n].copy()
+        if copy:
+            return ll[:n].copy(), dll[:n].copy()
+        return ll[:n], dll[:n]
 
     def project_latent(self, set_id, proj, shift):
         """mu = y @ proj - shift on the device for every row of the set; returns the column sums of y."""

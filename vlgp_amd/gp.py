@@ -109,12 +109,16 @@ class _Lbfgsb:
 
     MAXCOR, FTOL, GTOL, MAXLS, MAXITER, MAXFUN = 10, 2.2204460492503131e-09, 1e-5, 20, 15000, 15000
 
-    def __init__(self, setulb, x0, log_bounds):
+    def __init__(self, setulb, x0, log_bounds, xbuf=None):
         self.setulb = setulb
         lo, hi = log_bounds[:, 0].copy(), log_bounds[:, 1].copy()
         n = x0.size
         m = self.MAXCOR
-        self.x = np.clip(np.array(x0, dtype=np.float64), lo, hi)
+        if xbuf is None:
+            self.x = np.clip(np.array(x0, dtype=np.float64), lo, hi)
+        else:  # the caller's row of a shared (runs, n) array: the batch of pending points needs no gathering
+            self.x = xbuf
+            np.clip(np.asarray(x0, dtype=np.float64), lo, hi, out=self.x)
         self.lo, self.hi = lo, hi
         self.nbd = np.full(n, 2, dtype=np.int32)  # both bounds finite
         self.f = 0.0
@@ -134,14 +138,16 @@ class _Lbfgsb:
         self._head = (self.MAXCOR, self.x, self.lo, self.hi, self.nbd)
         self._tail = (self.g, self.factr, self.GTOL, self.wa, self.iwa, self.task, self.lsave, self.isave, self.dsave,
                       self.MAXLS, self.ln_task)
+        self._args = self._head + (self.f,) + self._tail  # rebuilt by feed(): f is the only argument passed by value
 
     def advance(self):
         """Run until the routine asks for (f, g) at self.x or terminates.
         Returns True when an evaluation is wanted."""
         task = self.task
+        setulb, args = self.setulb, self._args
         while not self.done:
-            self.setulb(*self._head, self.f, *self._tail)
-            t0 = task[0]
+            setulb(*args)
+            t0 = int(task[0])
             if t0 == 3:
                 return True
             if t0 == 1:  # new iterate accepted
@@ -158,6 +164,7 @@ class _Lbfgsb:
         self.f = float(f)
         self.g[:] = g  # in place: setulb reads the array bound in _tail
         self.nfev += 1
+        self._args = self._head + (self.f,) + self._tail
 
 
 def _setulb_or_none():
@@ -184,17 +191,16 @@ def lockstep_minimize(batch_fn, x0s, log_bounds):
     setulb = _setulb_or_none()
     if setulb is None:
         return _lockstep_threads(batch_fn, x0s, log_bounds)
-    runs = [_Lbfgsb(setulb, x0, log_bounds) for x0 in x0s]
-    X = np.empty((len(runs), runs[0].x.size))
+    n_runs = len(x0s)
+    X = np.empty((n_runs, np.asarray(x0s[0]).size))  # row k IS run k's iterate (setulb updates it in place)
+    runs = [_Lbfgsb(setulb, x0, log_bounds, xbuf=X[k]) for k, x0 in enumerate(x0s)]
+    active = list(range(n_runs))
     while True:
-        want = [k for k, r in enumerate(runs) if not r.done and r.advance()]
-        if not want:
+        active = [k for k in active if runs[k].advance()]
+        if not active:
             break
-        n = len(want)
-        for i, k in enumerate(want):
-            X[i] = runs[k].x
-        f, G = batch_fn(want, X[:n])
-        for i, k in enumerate(want):
+        f, G = batch_fn(active, X if len(active) == n_runs else X[active])
+        for i, k in enumerate(active):
             runs[k].feed(f[i], G[i])
     return [r.x.copy() for r in runs]
 
@@ -246,8 +252,10 @@ def optimize(trials, params, config):
                               (gp_noise / 2, gp_noise * 2)]))
 
     def batch(latents, logps):  # scipy minimises: negate ll and its gradient
-        ll, dll = eng.hstep_objective(sid, window, dt, latents, logps)
-        return -ll, -dll
+        ll, dll = eng.hstep_objective(sid, window, dt, latents, logps, copy=False)
+        np.negative(ll, out=ll)  # (the engine's own result buffers: consumed before the next call)
+        np.negative(dll, out=dll)
+        return ll, dll
 
     x0s = [np.log(np.array([sigma[l] ** 2, omega[l], gp_noise])) for l in range(L)]
     eng.hstep_begin(sid, window)
