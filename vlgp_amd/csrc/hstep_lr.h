@@ -495,13 +495,18 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                     blk[a_][b_] = hi >= r ? (i == j ? 1.0 : 0.0) : v;  // unit diagonal beyond the rank
                 }
             auto sweeps = [&]() {
+                // (the block index K is a RUN-TIME loop: only the BS sweeps of one block are unrolled.  Unrolled over all
+                // GB BS sweeps the kernel is ~90 KB of straight-line code that every wave walks through once, against a
+                // 64 KB instruction cache shared by two CUs.)
+#pragma nounroll
+                for (int K = 0; K < GB; ++K) {
+                const bool wc = J == K;            // this block holds column k for its rows (local column kl)
+                const bool wr = I == K && J < K;   // this block holds row k for its columns (local row kl)
 #pragma unroll
-                for (int k = 0; k < GB * BS; ++k) {
+                for (int kl = 0; kl < BS; ++kl) {
+                    const int k = K * BS + kl;
                     if (k >= r) return;
                     constexpr int dummy = 0;
-                    const int K = k / BS, kl = k % BS;
-                    const bool wc = J == K;            // this block holds column k for its rows (local column kl)
-                    const bool wr = I == K && J < K;   // this block holds row k for its columns (local row kl)
                     if ((wc || wr) && act) {
                         double* dst = xs + (wc ? BS * I : BS * J);
 #pragma unroll
@@ -527,6 +532,7 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
                     }
                     tri_wave_order();
                     (void)dummy;
+                }
                 }
             };
             sweeps();
