@@ -501,6 +501,35 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
     assert abs(got[1][0, 1] - want[1][1]) <= STAGE * max(abs(want[1][1]), 1e-3 * abs(want[0]))
 
 
+@pytest.mark.parametrize("dt", [0.5, 2.0, 0.02])
+def test_hstep_objective_other_bin_widths_vs_oracle(V, dt, monkeypatch):
+    """params["dt"] != 1 (vlgp/gp.py:113: the kernel matrix is built on t = arange(T) * dt): the low-rank round's tables and
+    the host's rank thresholds take the bin width; omega scaled so that omega dt^2 spans the usual range, plus one rough
+    evaluation that sends the round to the dense kernel.  (ll, dll) against gp.obj_func's restatement on every path."""
+    rng = np.random.default_rng(int(dt * 100))
+    M, T, L = 40, 50, 2
+    units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": 2.0 * rng.random((T, L)),
+              "v": np.zeros((T, L))} for _ in range(M)]
+    t = np.arange(T) * dt
+    cases = [("lowrank", np.log(np.array([[1.0, 3e-3 / dt ** 2, 1e-4], [0.6, 1.2e-2 / dt ** 2, 1e-4]]))),
+             ("dense", np.log(np.array([[1.0, 3e-3 / dt ** 2, 1e-4], [0.6, 6e-2 / dt ** 2, 1e-4]])))]
+    monkeypatch.setenv("VLGP_HSTEP_LOWRANK", "1")
+    with V.Engine(2, L, 1, 50) as eng:
+        eng.upload(0, units)
+        for path, logp in cases:
+            ll, dll = eng.hstep_objective(0, T, dt, np.arange(L), logp)
+            assert eng.last_hstep_path == path
+            monkeypatch.setenv("VLGP_HSTEP_GENERIC", "1")
+            llg, dllg = eng.hstep_objective(0, T, dt, np.arange(L), logp)
+            monkeypatch.delenv("VLGP_HSTEP_GENERIC")
+            for l in range(L):
+                want = O.gp_objective(logp[l], t, np.stack([u["mu"][:, l] for u in units], 1),
+                                      np.stack([u["w"][:, l] for u in units], 1))
+                for got_ll, got_dll in ((ll, dll), (llg, dllg)):
+                    assert abs(got_ll[l] - want[0]) <= STAGE * abs(want[0]), (path, l)
+                    assert abs(got_dll[l, 1] - want[1][1]) <= STAGE * max(abs(want[1][1]), 1e-3 * abs(want[0])), (path, l)
+
+
 @pytest.mark.parametrize("T", [4, 7, 12, 20, 25, 40, 56, 64, 65, 80, 100, 127, 128, 129, 150, 200])
 def test_hstep_objective_other_windows_vs_oracle(V, T, monkeypatch):
     """Windows other than 50: up to 64 bins the low-rank round (any window from 4 bins; the K block compiled for 50 /
