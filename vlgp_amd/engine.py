@@ -91,6 +91,20 @@ class Engine:
     def _ck(self, rc):
         check(rc, self.h)
 
+    def check(self, rc):
+        """Raise VlgpError with the handle's message for a non-zero status returned outside this class."""
+        check(rc, self.h)
+
+    @property
+    def handle_address(self):
+        """The vlgp_ctx* as an integer (for native callers of the C ABI: vlgp_amd._lockstep)."""
+        return int(self.h.value)
+
+    @property
+    def hstep_objective_address(self):
+        """Address of vlgp_hstep_objective in the loaded library."""
+        return int(C.cast(self.lib.vlgp_hstep_objective, C.c_void_p).value)
+
     def synchronize(self, main_only=False):
         """Wait for the device: everything, or (main_only) the main stream without a pending M-step lane."""
         self._ck(self.lib.vlgp_synchronize_main(self.h) if main_only else self.lib.vlgp_synchronize(self.h))

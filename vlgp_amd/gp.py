@@ -10,6 +10,7 @@ that each round of evaluations is ONE kernel launch over all latents.
 """
 import logging
 import math
+import os
 import threading
 
 import numpy as np
@@ -181,6 +182,31 @@ def _setulb_or_none():
         return None
 
 
+def _lockstep_ext():
+    """vlgp_amd._lockstep (csrc/lockstep_ext.c), or None when it is not built."""
+    try:
+        from . import _lockstep
+
+        return _lockstep
+    except Exception:  # pragma: no cover
+        return None
+
+
+def lockstep_minimize_native(objective_address, handle_address, set_id, window, dt, latents, x0s, log_bounds):
+    """lockstep_minimize with the loop around SciPy's setulb and the objective call in C (vlgp_amd._lockstep): same
+    calls to the same routine with the same arguments, hence the same iterates; the objective is vlgp_hstep_objective
+    called through its address.  Returns (xs, status); None when SciPy's routine or the module is not available."""
+    setulb, ext = _setulb_or_none(), _lockstep_ext()
+    if setulb is None or ext is None:
+        return None
+    n_runs = len(x0s)
+    X = np.empty((n_runs, 3))
+    runs = [_Lbfgsb(setulb, x0, log_bounds, xbuf=X[k]) for k, x0 in enumerate(x0s)]
+    status = ext.run(setulb, [(r._head, r._tail, int(l)) for r, l in zip(runs, latents)], int(objective_address),
+                     int(handle_address), int(set_id), int(window), float(dt), _Lbfgsb.MAXITER, _Lbfgsb.MAXFUN)
+    return [r.x.copy() for r in runs], int(status)
+
+
 def lockstep_minimize(batch_fn, x0s, log_bounds):
     """Minimise len(x0s) independent objectives with L-BFGS-B, evaluating all
     pending points of a round with ONE call ``batch_fn(keys, X) -> (f, G)``
@@ -260,7 +286,15 @@ def optimize(trials, params, config):
     x0s = [np.log(np.array([sigma[l] ** 2, omega[l], gp_noise])) for l in range(L)]
     eng.hstep_begin(sid, window)
     try:
-        xs = lockstep_minimize(batch, x0s, bounds)
+        xs = None
+        if not os.environ.get("VLGP_LOCKSTEP_PYTHON"):
+            res = lockstep_minimize_native(eng.hstep_objective_address, eng.handle_address, sid, window, dt, range(L),
+                                           x0s, bounds)
+            if res is not None:
+                xs, status = res
+                eng.check(status)
+        if xs is None:
+            xs = lockstep_minimize(batch, x0s, bounds)
     finally:
         eng.hstep_end()
     for l in range(L):
