@@ -28,6 +28,7 @@ typedef int (*objective_fn)(void* ctx, int set, int window, double dt, int n_eva
 
 typedef struct {
     PyObject *head, *tail;  /* borrowed from the list (which outlives the call) */
+    PyObject* args;         /* owned: (m, x, l, u, nbd, f, g, ..., ln_task), built once; only slot 5 (f) is replaced */
     Py_buffer x, g, task;
     int have_x, have_g, have_task;
     int latent, done, nit, nfev;
@@ -39,6 +40,7 @@ static void release_runs(Run* r, int n) {
         if (r[i].have_x) PyBuffer_Release(&r[i].x);
         if (r[i].have_g) PyBuffer_Release(&r[i].g);
         if (r[i].have_task) PyBuffer_Release(&r[i].task);
+        Py_XDECREF(r[i].args);
     }
 }
 
@@ -48,17 +50,26 @@ static int advance(PyObject* setulb, Run* r, long maxiter, long maxfun) {
     while (!r->done) {
         PyObject* fobj = PyFloat_FromDouble(r->f);
         if (!fobj) return -1;
-        PyObject* mid = PyTuple_Pack(1, fobj);
-        Py_DECREF(fobj);
-        if (!mid) return -1;
-        PyObject* a1 = PySequence_Concat(r->head, mid);
-        Py_DECREF(mid);
-        if (!a1) return -1;
-        PyObject* args = PySequence_Concat(a1, r->tail);
-        Py_DECREF(a1);
-        if (!args) return -1;
-        PyObject* res = PyObject_CallObject(setulb, args);
-        Py_DECREF(args);
+        if (!r->args) {
+            r->args = PyTuple_New(17);
+            if (!r->args) { Py_DECREF(fobj); return -1; }
+            for (int q = 0; q < 5; ++q) {
+                PyObject* o = PyTuple_GET_ITEM(r->head, q);
+                Py_INCREF(o);
+                PyTuple_SET_ITEM(r->args, q, o);
+            }
+            for (int q = 0; q < 11; ++q) {
+                PyObject* o = PyTuple_GET_ITEM(r->tail, q);
+                Py_INCREF(o);
+                PyTuple_SET_ITEM(r->args, 6 + q, o);
+            }
+            PyTuple_SET_ITEM(r->args, 5, fobj);
+        } else {  /* the tuple is ours alone (the callee keeps no reference to it): swap the one by-value argument */
+            PyObject* old = PyTuple_GET_ITEM(r->args, 5);
+            PyTuple_SET_ITEM(r->args, 5, fobj);
+            Py_DECREF(old);
+        }
+        PyObject* res = PyObject_CallObject(setulb, r->args);
         if (!res) return -1;
         Py_DECREF(res);
         const int t0 = task[0];
