@@ -586,6 +586,33 @@ def test_hstep_optimize_golden(V, golden):
         dev.engine.close()
 
 
+def test_hstep_native_and_python_drivers_agree_bit_for_bit(V, golden, monkeypatch):
+    """gp.optimize through vlgp_amd._lockstep (the loop around SciPy's setulb and the objective call in C) and through the
+    Python loop (VLGP_LOCKSTEP_PYTHON=1): same routine, same arguments, same device objective -> identical omega, sigma."""
+    from vlgp_amd import gp as G
+
+    if G._lockstep_ext() is None:
+        pytest.skip("vlgp_amd/_lockstep.so is not built")
+    g = golden("hstep")
+    M, T, L = g["mu"].shape
+    out = []
+    for python_loop in (False, True):
+        if python_loop:
+            monkeypatch.setenv("VLGP_LOCKSTEP_PYTHON", "1")
+        units = [{"y": np.zeros((T, 2)), "mu": g["mu"][m].copy(), "w": g["w"][m].copy(),
+                  "v": np.zeros((T, L))} for m in range(M)]
+        params = {"ydim": 2, "zdim": L, "xdim": 1, "rank": 50, "a": np.zeros((L, 2)), "b": np.zeros((1, 2)),
+                  "noise": np.ones(2), "likelihood": np.array(["poisson"] * 2), "sigma": g["sigma0"].copy(),
+                  "omega": g["omega0"].copy(), "gp_noise": 1e-4, "dt": 1, "cholesky": {}}
+        dev = _resident(V, units, params, set_prior=False)
+        try:
+            V.hstep(dev, params, V.get_config())
+            out.append((params["omega"].copy(), params["sigma"].copy()))
+        finally:
+            dev.engine.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 # ------------------------------------------------------------------ EM loop
 def _c1(g):
     y = g["y"].astype(float)
