@@ -851,7 +851,13 @@ static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
         g.tiles = (N + 511) / 512;
     }
     int64_t G = (rows + 63) / 64;
-    const int64_t cap = 2LL * ctx->n_cu;
+    // ONE workgroup per CU (round 4; two until then).  Alone the accumulation is 3 % slower that way (2.22 against
+    // 2.15 ms per M-step at C3), but the M-step runs BESIDE the H-step's rounds, which are the critical path of the phase:
+    // two resident workgroups (14 waves, 256 of a SIMD's 512 registers) leave a CU room for one workgroup of the low-rank
+    // round instead of three.  C3: H-step 4.3 -> 4.0 ms, 133-134 -> 137-141 EM it/s on the same boxes; 0.75 or 0.5 per CU
+    // make the M-step itself the longer lane (125-131).  VLGP_MSTEP_WG_PER_CU overrides.
+    static const double wg_per_cu = getenv("VLGP_MSTEP_WG_PER_CU") ? atof(getenv("VLGP_MSTEP_WG_PER_CU")) : 1.0;
+    const int64_t cap = (int64_t)((wg_per_cu > 0 ? wg_per_cu : 1.0) * ctx->n_cu);
     if (G > cap) G = cap;
     if (G < 1) G = 1;
     g.rows_per_wg = (int)((rows + G - 1) / G);
