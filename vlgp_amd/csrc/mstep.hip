@@ -855,7 +855,8 @@ static Geometry plan(vlgp_ctx* ctx, int64_t rows) {
     // 2.15 ms per M-step at C3), but the M-step runs BESIDE the H-step's rounds, which are the critical path of the phase:
     // two resident workgroups (14 waves, 256 of a SIMD's 512 registers) leave a CU room for one workgroup of the low-rank
     // round instead of three.  C3: H-step 4.3 -> 4.0 ms, 133-134 -> 137-141 EM it/s on the same boxes; 0.75 or 0.5 per CU
-    // make the M-step itself the longer lane (125-131).  VLGP_MSTEP_WG_PER_CU overrides.
+    // make the M-step itself the longer lane (125-131), and so do smaller workgroups (320 / 256 threads instead of 448:
+    // 119 / 127 against 132-133 on the same box).  VLGP_MSTEP_WG_PER_CU overrides.
     static const double wg_per_cu = getenv("VLGP_MSTEP_WG_PER_CU") ? atof(getenv("VLGP_MSTEP_WG_PER_CU")) : 1.0;
     const int64_t cap = (int64_t)((wg_per_cu > 0 ? wg_per_cu : 1.0) * ctx->n_cu);
     if (G > cap) G = cap;
