@@ -621,10 +621,34 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     stamp(2);
     // ---- phase 3: < M^-1, U' diag(wt d) U > and < M^-1, Ud' diag(wt) U + U' diag(wt) Ud > ----
     double ts[4] = {0.0, 0.0, 0.0, 0.0}, cs[4] = {0.0, 0.0, 0.0, 0.0};
-    weights(nullptr, nullptr);
-    dsum += __shfl_xor(dsum, 16, 64);
-    dsum += __shfl_xor(dsum, 32, 64);
-    for (int q = wid; q < n_tiles; q += NW) {
+    // One kind of tiles at a time -- same-parity pairs with (w+, w+ d), then mixed pairs with (w-, w- d) -- so that only
+    // ONE pair of weight arrays (2 NK doubles) is live beside the accumulators: the four arrays at once were the
+    // register peak of the kernel.  Same tiles in the same order per wave as one loop over all of them.
+    double wa[NK], wb[NK];
+    auto weights_kind = [&](int kind) {
+        double ds = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int tau = 4 * kk + g;
+            const bool in1 = sval && tau < nt, in2 = sval && tau < h;
+            const double w1 = in1 ? w[(r0 + tau) * L + l] : 0.0;
+            const double w2 = in2 ? w[(r0 + T - 1 - tau) * L + l] : 0.0;
+            const double d1 = lr_rcp(fma(eps, w1, 1.0)), d2 = lr_rcp(fma(eps, w2, 1.0));
+            const double t1 = w1 * d1, t2 = w2 * d2;
+            const double q1 = t1 * d1, q2 = t2 * d2;
+            const double fa = in2 ? 0.5 : 1.0;  // the middle row of an odd window is its own mirror image
+            if (kind == 0) {
+                wa[kk] = fa * (t1 + t2);
+                wb[kk] = fa * (q1 + q2);
+                ds += (in1 ? d1 : 0.0) + (in2 ? d2 : 0.0);
+            } else {
+                wa[kk] = in2 ? 0.5 * (t1 - t2) : 0.0;
+                wb[kk] = in2 ? 0.5 * (q1 - q2) : 0.0;
+            }
+        }
+        if (kind == 0) dsum = ds;
+    };
+    auto tile3 = [&](int q) {
         const unsigned code = codes[q * 16 + c];
         const bool valid = code != 0xffffu;
         const int i = valid ? (int)(code >> 8) : r, j = valid ? (int)(code & 255u) : r;
@@ -633,19 +657,15 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
         const double* di = Udl + g * LDU + i;
         const double* dj = Udl + g * LDU + j;
         hm_d4 accB = hm_d4{0.0, 0.0, 0.0, 0.0}, accD = hm_d4{0.0, 0.0, 0.0, 0.0};
-        auto tile = [&](const double(&aw)[NK], const double(&bw)[NK]) {
 #pragma unroll
-            for (int kk = 0; kk < NK; ++kk) {
-                const int o = 4 * kk * LDU;
-                const double vi = ui[o], vj = uj[o];
-                const double pb = vi * vj;
-                const double pd = fma(di[o], vj, vi * dj[o]);
-                accB = __builtin_amdgcn_mfma_f64_16x16x4f64(bw[kk], pb, accB, 0, 0, 0);
-                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], pd, accD, 0, 0, 0);
-            }
-        };
-        if (q >= ns_tiles) tile(am, bm);
-        else tile(ap, bp);
+        for (int kk = 0; kk < NK; ++kk) {
+            const int o = 4 * kk * LDU;
+            const double vi = ui[o], vj = uj[o];
+            const double pb = vi * vj;
+            const double pd = fma(di[o], vj, vi * dj[o]);
+            accB = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[kk], pb, accB, 0, 0, 0);
+            accD = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kk], pd, accD, 0, 0, 0);
+        }
         const int idx = valid ? i * (i + 1) / 2 + j : NPZ;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -653,7 +673,13 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
             ts[p] = fma(m, accB[p], ts[p]);
             cs[p] = fma(m, accD[p], cs[p]);
         }
-    }
+    };
+    weights_kind(0);
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    for (int q = wid; q < ns_tiles; q += NW) tile3(q);
+    weights_kind(1);
+    for (int q = ns_tiles + ((wid - ns_tiles % NW) + NW) % NW; q < n_tiles; q += NW) tile3(q);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const double tsum = lr_row_sum_to15(ts[p]), csum = lr_row_sum_to15(cs[p]);
