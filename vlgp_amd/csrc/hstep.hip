@@ -1133,12 +1133,12 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // us per round over n = n_eval x M segment-evaluations, 4000 of them = one "generation"):
                 //   dense      41 + 28 (n / 4000 - 1): one wave per segment, 4096 resident waves, ~25 us wave lifetime
                 //   low-rank   13 (tables launch) + base + marg (n / 4000 - 1), by rank class 16 / 24 / 28 / 32:
-                //              base 30 / 34 / 44 / 51 (one workgroup's latency), marg 12.6 / 11.8 / 15 / 22.6
+                //              base 26 / 35 / 42 / 51 (one workgroup's latency), marg 8.7 / 12 / 15.5 / 22.6
                 //              (re-measured with the block-triangle inverse and the early loads; class 32 keeps the
                 //              lane-per-row inverse and only beats the dense round from about ten evaluations)
                 // A few hundred segments (C1, C2, the shard a rank holds at 8 GPUs) never fill the chip: the dense round's
                 // single launch wins there.  VLGP_HSTEP_LOWRANK=1 takes the low-rank round regardless (tests).
-                static const double base[4] = {30.0, 34.0, 44.0, 51.0}, marg[4] = {12.6, 11.8, 15.0, 22.6};
+                static const double base[4] = {26.0, 35.0, 42.0, 51.0}, marg[4] = {8.7, 12.0, 15.5, 22.6};
                 const int ci = rmax <= 16 ? 0 : (rmax <= 24 ? 1 : (rmax <= 28 ? 2 : 3));
                 const double gens = (double)n_eval * M / 4000.0;
                 const double extra = gens > 1.0 ? gens - 1.0 : 0.0;
