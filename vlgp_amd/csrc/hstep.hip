@@ -908,8 +908,11 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
 // The round in the low-rank form (hstep_lr.h): blocks [0, n_eval) are the K blocks as above, every other block takes
 // sixteen segments of one evaluation.  The tables of the evaluations come from hstep_lr_tables, launched in front.
 // T: compiled window of the K block (50: windows <= 50, 64: <= 64); RC: register class of the ranks in this round.
+// (four waves per SIMD up to class 24: since phase 3 takes one kind of tiles at a time the class fits 128 registers
+// without scratch; ranks up to 20 then have four workgroups per CU -- their LDS allows it -- and two instead of one fit
+// beside a workgroup of the M-step lane.  Same box: 139.0 against 137.7 EM it/s.)
 template <int T, int NW, int RC, bool TABG = false>
-__global__ void __launch_bounds__(64 * NW, RC <= 16 ? 4 : 3) hstep_round_lr(HRoundArgs R) {
+__global__ void __launch_bounds__(64 * NW, RC <= 24 ? 4 : 3) hstep_round_lr(HRoundArgs R) {
     constexpr bool ONESET = T == 50;
     constexpr int NK = T == 50 ? 7 : 8;
     using KG = HRoundK<T, NW, ONESET>;
