@@ -48,6 +48,9 @@ struct SplitArgs {
     int64_t ld;          // = rows
     double *ra, *ya;     // (L, ld) as well
     double* xg;        // (M L, pkg): packed X = chol(I + G'WG)^-1 per (unit, latent)
+    unsigned long long* clk;  // debug: per-phase cycle counters of the first wave of the lane-per-task launches, or null
+    int prio, warm;    // lane-per-task launches: s_setprio level of their waves; warm the scalar cache with G first
+    double* xl;        // lane-per-task launches (estep_lane.h): X entry-major, 64 LANE_EMAX doubles per (group of 64 units, latent)
     int pkg;           // stride of xg
     int pkl;           // doubles of LDS per wave for the packed X of this launch's rank class
     int* failg;        // (M L): 1 = the factor of this (unit, latent) failed
@@ -1046,6 +1049,8 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
     tri_wave_sync();
 }
 
+#include "estep_lane.h"
+
 // MAXRA: largest register-array size compiled in (16: every latent of the launch has rank <= 16)
 // LASTSW (mean only): the last sweep of the call
 // (second launch bound = waves per SIMD: the rank <= 16 launches are bound by the number of resident waves --
@@ -1596,6 +1601,25 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     return VLGP_OK;
 }
 
+// one wave per (latent, group of 64 units): estep_lane.h
+int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
+    const int groups = (A.M + 63) / 64;
+    if (groups == 0 || A.n_lat == 0) return VLGP_OK;
+    const int TP = A.shg_T | 1;
+    const bool last = mean && A.last;
+    const size_t lds = (size_t)((last ? 3 : 1) * 64 * TP + 64) * 8;
+    const dim3 grid((unsigned)(groups * A.n_lat)), blk(64);
+    NEED_LANE(ctx);
+    hipStream_t st = t_lane;
+    auto fn = !mean ? esplit_lane<0> : (last ? esplit_lane<2> : esplit_lane<1>);
+    if (lds > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    hipLaunchKernelGGL(fn, grid, blk, lds, st, A);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
 // long units: one workgroup per (unit, latent)
 int run_latent_long(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const unsigned tasks = (unsigned)(A.M * A.L);
@@ -1610,6 +1634,7 @@ int run_latent_long(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
 // One launch per rank class: the latents of rank <= 16 run the lean instantiation (staged G, small LDS footprint),
 // the others the mixed one -- a single latent above 16 slows its own waves only.
 struct LatentClasses {
+    int n_ln = 0, ln[16];  // rank <= LANE_RMAX and one prior for the whole set: lane-per-task launches (estep_lane.h)
     int n_lo = 0, lo[16];
     int n_hi = 0, hi[16];
     int maxra_hi = 16;
@@ -1630,6 +1655,22 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
             A.pkl = 0;
         }
         CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
+    }
+    if (C.n_ln) {
+        A.n_lat = C.n_ln;
+        for (int i = 0; i < C.n_ln; ++i) {
+            A.lat[i] = C.ln[i];
+            A.shg_rk[i] = C.single->rl[C.ln[i]];
+            A.shg_gl[i] = C.single->d_compact + C.single->goff[C.ln[i]];
+        }
+        A.shg = 1;
+        A.shg_T = C.single_T;
+        static const int prio = getenv("VLGP_LANE_PRIO") ? atoi(getenv("VLGP_LANE_PRIO")) : 3;
+        A.prio = prio;
+        A.clk = ctx->d_clk;
+        static const int warm = getenv("VLGP_LANE_WARM") ? atoi(getenv("VLGP_LANE_WARM")) : 1;
+        A.warm = warm;
+        CHK(run_latent_lane(ctx, A, mean));
     }
     if (C.n_lo) {
         A.n_lat = C.n_lo;
@@ -1710,7 +1751,14 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     const int pkg = lng ? LPK : tri_packed_size(maxra);
     // scratch of the set: ra | ya | xg | failg(int) ; records + wconst in ctx->d_ecols
     const int64_t nRL = us.rows * L;
-    const int64_t need = 5 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8;
+    // lane-per-task launches (estep_lane.h): one prior for the whole set, T <= 64; VLGP_ESTEP_LANEPT=0 keeps the
+    // wave-per-task kernels (per call: tests toggle it)
+    const char* lpt = getenv("VLGP_ESTEP_LANEPT");
+    const bool use_lane = !lng && need_prior && us.Tmin == us.Tmax && (lpt && lpt[0] == '1') &&
+                          !getenv("VLGP_ESTEP_NO_SHARED_G");
+    const int64_t n_groups = ((int64_t)us.M + 63) / 64;
+    const int64_t xl_len = use_lane ? n_groups * L * 64 * LANE_EMAX : 0;
+    const int64_t need = 5 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8 + xl_len;
     if (us.scratch_len < need) {
         if (us.d_scratch) HIPCHK(ctx, hipFree(us.d_scratch));
         us.d_scratch = nullptr;
@@ -1741,13 +1789,20 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         HIPCHK(ctx, hipGetLastError());
     }
     A.failg = reinterpret_cast<int*>(A.xg + (int64_t)us.M * L * pkg);
+    A.xl = reinterpret_cast<double*>(A.failg) + ((int64_t)us.M * L + 1) / 2 + 1;
     A.fail = E.fail;
     A.wconst = wconst;
     A.dmu_bound = E.dmu_bound;
     A.ntot = N; A.np = N - ctx->n_gauss;
     LatentClasses C;
+    if (need_prior && us.Tmin == us.Tmax) {
+        C.single_T = us.Tmax;
+        for (auto& kv : ctx->priors)
+            if (kv.second.T == us.Tmax) C.single = &kv.second;
+    }
     for (int l = 0; l < L; ++l) {
-        if (rlat[l] <= 16) C.lo[C.n_lo++] = l;
+        if (use_lane && C.single && rlat[l] <= LANE_RMAX) C.ln[C.n_ln++] = l;
+        else if (rlat[l] <= 16) C.lo[C.n_lo++] = l;
         else C.hi[C.n_hi++] = l;
     }
     C.maxra_hi = maxra;
@@ -1755,11 +1810,6 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     if (C.lds_g_lo < 256) C.lds_g_lo = 256;
     A.lds_g = 256; A.pkl = pkg; A.n_lat = 0;
     A.shg = 0; A.shg_cap = 0; A.shg_T = 0;
-    if (need_prior && us.Tmin == us.Tmax) {
-        C.single_T = us.Tmax;
-        for (auto& kv : ctx->priors)
-            if (kv.second.T == us.Tmax) C.single = &kv.second;
-    }
     A.do_v = 0; A.last = 0;
     *handled = lng ? 2 : 1;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
@@ -1793,8 +1843,10 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     Half H[VLGP_E_LANES];
     {
         for (int h = 0; h < n_lanes; ++h) {
-            // cuts at multiples of four units: the shared-G launches take four units per workgroup
-            int m0 = (int)(((int64_t)us.M * h / n_lanes + 3) & ~3LL), m1 = (int)(((int64_t)us.M * (h + 1) / n_lanes + 3) & ~3LL);
+            // cuts at multiples of four units: the shared-G launches take four units per workgroup (64: a wave of the
+            // lane-per-task launches)
+            const int64_t cm = C.n_ln ? 63 : 3;
+            int m0 = (int)(((int64_t)us.M * h / n_lanes + cm) & ~cm), m1 = (int)(((int64_t)us.M * (h + 1) / n_lanes + cm) & ~cm);
             if (m0 > us.M) m0 = us.M;
             if (m1 > us.M || h == n_lanes - 1) m1 = us.M;
             const int64_t row_lo = us.off[m0], row_hi = us.off[m1];
@@ -1808,6 +1860,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             hf.lat.off = A.off + m0;
             hf.lat.unit_prior = A.unit_prior ? A.unit_prior + m0 : nullptr;
             hf.lat.xg = A.xg + (int64_t)m0 * L * pkg;
+            hf.lat.xl = A.xl + (int64_t)(m0 / 64) * L * 64 * LANE_EMAX;
             hf.lat.failg = A.failg + (int64_t)m0 * L;
             // row passes: every row-indexed pointer shifted to the half's first row
             hf.pass = A;
