@@ -11,7 +11,8 @@ sess = FitSession(trials, dims[3], verbose=False, a=a0.copy(), b=b0.copy(), max_
 for _ in range(3):
     sess.em_iteration()
 L = dims[3]
-names = ["F staging", "F build", "F chol+inv", "F variance+stores", "M staging", "M G's", "M solve", "M expand+update"]
+names = {"1": ["staging", "build", "reduction", "chol+inv", "hand-back", "variance", "stores", "-"],
+         "2": ["staging", "G's", "reduction", "solve", "hand-back", "expansion", "update", "-"]}[os.environ.get("VLGP_LANE_CLOCK", "1")]
 for om in [float(x) for x in os.environ.get("OMS", "5e-3").split(",")]:
     sess.params["omega"] = np.full(L, om)
     E.make_cholesky(sess.segs, sess.params, sess.config)

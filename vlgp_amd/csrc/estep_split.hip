@@ -47,9 +47,13 @@ struct SplitArgs {
     double* dmu;         // the unit-set array itself, (rows, L)
     int64_t ld;          // = rows
     double *ra, *ya;     // (L, ld) as well
+    double *sv, *dl;     // (L, ld): s = ra + w mu (written by the residual pass for the lane-per-task mean launch), and that
+                         // launch's raw step target G (I + H)^-1 G's: the curvature pass that follows applies
+                         // mu += clip(dl - mu) for the latents in `dmask` (estep_lane.h)
+    unsigned dmask;
     double* xg;        // (M L, pkg): packed X = chol(I + G'WG)^-1 per (unit, latent)
     unsigned long long* clk;  // debug: per-phase cycle counters of the first wave of the lane-per-task launches, or null
-    int prio, warm;    // lane-per-task launches: s_setprio level of their waves; warm the scalar cache with G first
+    int prio, clk_kind;    // lane-per-task launches: s_setprio level of their waves; warm the scalar cache with G first
     double* xl;        // lane-per-task launches (estep_lane.h): X entry-major, 64 LANE_EMAX doubles per (group of 64 units, latent)
     int pkg;           // stride of xg
     int pkl;           // doubles of LDS per wave for the packed X of this launch's rank class
@@ -70,7 +74,7 @@ struct SplitArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// channel records, Poisson channels first: a[LT] | a^2[LT] | b | c (1/noise or 1) | id (integer bits) | pad
+// channel records, Poisson channels first: a[LT] | a^2 / 2 [LT] | b | c (1/noise or 1) | id (integer bits) | pad
 template <int LT>
 constexpr int rec_len() { return (2 * LT + 3 + 1) & ~1; }
 
@@ -94,7 +98,7 @@ esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double*
         for (int l = 0; l < LT; ++l) {
             const double av = l < L ? a[l * N + n] : 0.0;
             rec[l] = av;
-            rec[LT + l] = av * av;
+            rec[LT + l] = 0.5 * av * av;  // half squares: the rate's exponent is one chain b + mu.a + v.(a^2 / 2)
         }
         rec[2 * LT] = b[n];
         rec[2 * LT + 1] = gauss[n] ? 1.0 / noise[n] : 1.0;
@@ -198,9 +202,9 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
     const int lane = threadIdx.x & 63;
     const int part = CS == 1 ? 0 : wid % CS;
     const int64_t row0 = (int64_t)blockIdx.x * RPB + (wid / CS) * (64 * RPL) + lane;
-    __shared__ double etab[64];  // 2^(j/64) for fast_exp_tab
+    __shared__ double etab[256];  // 2^(j/256) for fast_exp_tab256
     if constexpr (KIND != SP_YA) {
-        fast_exp_tab_init(etab, threadIdx.x);
+        fast_exp_tab256_init(etab, threadIdx.x);
         __syncthreads();
     }
     const int N = A.N, L = A.L;
@@ -225,12 +229,31 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
     }
     // the residual pass subtracts from ya at the end: fetched here, by the wave that writes (a load after the channel
     // loop is one more trip to memory in the life of a short wave)
-    double yav[RPL][LT];
+    double yav[RPL][LT], wv[RPL][LT];
     if constexpr (KIND == SP_RES) {
 #pragma unroll
         for (int q = 0; q < RPL; ++q)
 #pragma unroll
-            for (int l = 0; l < LT; ++l) yav[q][l] = (part == 0 && l < L) ? A.ya[(int64_t)l * A.ld + rr[q]] : 0.0;
+            for (int l = 0; l < LT; ++l) {
+                yav[q][l] = (part == 0 && l < L) ? A.ya[(int64_t)l * A.ld + rr[q]] : 0.0;
+                wv[q][l] = (part == 0 && l < L && A.sv) ? A.w[(int64_t)l * A.ld + rr[q]] : 0.0;
+            }
+    }
+    if constexpr (KIND == SP_W) {
+        // the step of the lane-per-task mean launch, applied here: mu += clip(dl - mu) (core.py:91, 96); every wave of
+        // the row group advances its copy, the wave that writes w stores it (after the barrier below: the others
+        // have read the old value by then)
+        if (A.dmask) {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int l = 0; l < LT; ++l)
+                    if (l < L && ((A.dmask >> l) & 1u)) {
+                        double st = A.dl[(int64_t)l * A.ld + rr[q]] - mr[q][l];
+                        st = fmin(fmax(st, -A.dmu_bound), A.dmu_bound);
+                        mr[q][l] += st;
+                    }
+        }
     }
     auto load_rec = [&](int i, double (&rv)[REC]) {
         const double2* rp = reinterpret_cast<const double2*>(cols + (int64_t)i * REC);
@@ -270,13 +293,11 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 double eta = HASXB ? xbrow[q][(int)__double_as_longlong(rv[2 * LT + 2])] : rv[2 * LT];
-                double lin = 0.0;
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
-                    eta = fma(mr[q][l], rv[l], eta);
-                    lin = fma(vr[q][l], rv[LT + l], lin);
-                }
-                const double rate = fast_exp_tab(clamp10(fma(0.5, lin, eta)), etab);
+                for (int l = 0; l < LT; ++l) eta = fma(mr[q][l], rv[l], eta);
+#pragma unroll
+                for (int l = 0; l < LT; ++l) eta = fma(vr[q][l], rv[LT + l], eta);
+                const double rate = fast_exp_tab256(clamp10(eta), etab);
 #pragma unroll
                 for (int l = 0; l < LT; ++l) acc[q][l] = fma(rate, rv[KIND == SP_RES ? l : LT + l], acc[q][l]);
             }
@@ -333,8 +354,14 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
             for (int l = 0; l < LT; ++l) {
                 if (l < L) {
                     if constexpr (KIND == SP_YA) A.ya[(int64_t)l * A.ld + row] = acc[q][l];
-                    else if constexpr (KIND == SP_RES) A.ra[(int64_t)l * A.ld + row] = yav[q][l] - acc[q][l];
-                    else A.w[(int64_t)l * A.ld + row] = acc[q][l] + A.wconst[l];
+                    else if constexpr (KIND == SP_RES) {
+                        const double rav = yav[q][l] - acc[q][l];
+                        A.ra[(int64_t)l * A.ld + row] = rav;
+                        if (A.sv) A.sv[(int64_t)l * A.ld + row] = fma(wv[q][l], mr[q][l], rav);
+                    } else {
+                        A.w[(int64_t)l * A.ld + row] = fma(2.0, acc[q][l], A.wconst[l]);  // (the records hold a^2 / 2)
+                        if ((A.dmask >> l) & 1u) A.mu[(int64_t)l * A.ld + row] = mr[q][l];
+                    }
                 }
             }
         }
@@ -1601,14 +1628,13 @@ int run_latent_class(vlgp_ctx* ctx, const SplitArgs& A, int maxra, bool mean) {
     return VLGP_OK;
 }
 
-// one wave per (latent, group of 64 units): estep_lane.h
+// one workgroup (four waves) per (latent, group of 64 units): estep_lane.h
 int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const int groups = (A.M + 63) / 64;
     if (groups == 0 || A.n_lat == 0) return VLGP_OK;
-    const int TP = A.shg_T | 1;
     const bool last = mean && A.last;
-    const size_t lds = (size_t)((last ? 3 : 1) * 64 * TP + 64) * 8;
-    const dim3 grid((unsigned)(groups * A.n_lat)), blk(64);
+    const size_t lds = lane_lds_doubles(A.shg_T, mean, last) * 8;
+    const dim3 grid((unsigned)(groups * A.n_lat)), blk(256);
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
     auto fn = !mean ? esplit_lane<0> : (last ? esplit_lane<2> : esplit_lane<1>);
@@ -1665,11 +1691,11 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         }
         A.shg = 1;
         A.shg_T = C.single_T;
-        static const int prio = getenv("VLGP_LANE_PRIO") ? atoi(getenv("VLGP_LANE_PRIO")) : 3;
+        static const int prio = getenv("VLGP_LANE_PRIO") ? atoi(getenv("VLGP_LANE_PRIO")) : 0;  // (measured: 3 is 5 % slower)
+        static const int clk_kind = getenv("VLGP_LANE_CLOCK") ? atoi(getenv("VLGP_LANE_CLOCK")) : 0;
         A.prio = prio;
         A.clk = ctx->d_clk;
-        static const int warm = getenv("VLGP_LANE_WARM") ? atoi(getenv("VLGP_LANE_WARM")) : 1;
-        A.warm = warm;
+        A.clk_kind = clk_kind;
         CHK(run_latent_lane(ctx, A, mean));
     }
     if (C.n_lo) {
@@ -1754,11 +1780,11 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     // lane-per-task launches (estep_lane.h): one prior for the whole set, T <= 64; VLGP_ESTEP_LANEPT=0 keeps the
     // wave-per-task kernels (per call: tests toggle it)
     const char* lpt = getenv("VLGP_ESTEP_LANEPT");
-    const bool use_lane = !lng && need_prior && us.Tmin == us.Tmax && (lpt && lpt[0] == '1') &&
+    const bool use_lane = !lng && need_prior && us.Tmin == us.Tmax && !(lpt && lpt[0] == '0') &&
                           !getenv("VLGP_ESTEP_NO_SHARED_G");
     const int64_t n_groups = ((int64_t)us.M + 63) / 64;
     const int64_t xl_len = use_lane ? n_groups * L * 64 * LANE_EMAX : 0;
-    const int64_t need = 5 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8 + xl_len;
+    const int64_t need = 5 * nRL + (int64_t)us.M * L * pkg + ((int64_t)us.M * L + 1) / 2 + 8 + xl_len + (use_lane ? 2 * nRL : 0);
     if (us.scratch_len < need) {
         if (us.d_scratch) HIPCHK(ctx, hipFree(us.d_scratch));
         us.d_scratch = nullptr;
@@ -1790,6 +1816,9 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     }
     A.failg = reinterpret_cast<int*>(A.xg + (int64_t)us.M * L * pkg);
     A.xl = reinterpret_cast<double*>(A.failg) + ((int64_t)us.M * L + 1) / 2 + 1;
+    A.sv = use_lane ? A.xl + xl_len : nullptr;
+    A.dl = use_lane ? A.sv + nRL : nullptr;
+    A.dmask = 0;
     A.fail = E.fail;
     A.wconst = wconst;
     A.dmu_bound = E.dmu_bound;
@@ -1869,6 +1898,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             hf.pass.xb = A.xb ? A.xb + row_lo * N : nullptr;
             hf.pass.mu = A.mu + row_lo; hf.pass.v = A.v + row_lo; hf.pass.w = A.w + row_lo;
             hf.pass.ra = A.ra + row_lo; hf.pass.ya = A.ya + row_lo;
+            if (A.sv) { hf.pass.sv = A.sv + row_lo; hf.pass.dl = A.dl + row_lo; }
         }
     }
     // (measured: three or four lanes are SLOWER than one -- E-step 5.7 ms against 3.5 / 3.0 for one / two at C3 -- and
@@ -1898,7 +1928,11 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
                     if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_MEAN, tasks, hf.st);
                 }
                 if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS, hf.st);
+                hf.pass.dmask = 0;  // the mean launch of the lane-per-task latents left its step for this pass to apply
+                if (with_mean)
+                    for (int i = 0; i < C.n_ln; ++i) hf.pass.dmask |= 1u << C.ln[i];
                 if (rc == VLGP_OK) rc = run_pass(ctx, hf.pass, LT, SP_W, cols);
+                hf.pass.dmask = 0;
                 if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, share, hf.st);
                 do_factor = with_mean && (E.vb || !last);
                 do_v = E.vb != 0;
