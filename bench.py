@@ -35,7 +35,20 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 # C3s8 (C3s4, C3s2) = the shard of C3 one rank holds at 8 (4, 2) GPUs (25 of the 200 trials): its time per EM iteration on one MI355X is the
 # compute a rank has left at N = 8, i.e. an upper bound on the strong-scaling speed-up before any exchange
 WORKLOADS = {"C1": (10, 200, 20, 3), "C2": (50, 500, 50, 3), "C3": (200, 1000, 100, 5), "C3s8": (25, 1000, 100, 5),
-             "C3s2": (100, 1000, 100, 5), "C3s4": (50, 1000, 100, 5)}  # the shards of C3 at 2 and 4 GPUs
+             "C3s2": (100, 1000, 100, 5), "C3s4": (50, 1000, 100, 5),  # the shards of C3 at 2 and 4 GPUs
+             # BASELINE.json configs[4] on ONE GPU: 500 ragged trials (500 ... 2000 bins, multiples of the window),
+             # 150 Poisson + 50 Gaussian channels, ten latents (SURVEY 8(d) recipe; n_bins here = the longest trial)
+             "C5": (500, 2000, 200, 10)}
+C5_GAUSS = 50
+
+
+def workload_extras(name, n_trials):
+    """(trial lengths or None, per-channel likelihood list or None) of a workload."""
+    if name != "C5":
+        return None, None
+    lengths = (50 * np.random.default_rng(0).integers(10, 41, n_trials)).tolist()
+    n = WORKLOADS[name][2]
+    return lengths, ["poisson"] * (n - C5_GAUSS) + ["gaussian"] * C5_GAUSS
 
 
 def build_inputs(name):
@@ -46,9 +59,13 @@ def build_inputs(name):
     from vlgp_amd.preprocess import get_config, get_params, initialize
 
     n_trials, n_bins, N, L = WORKLOADS[name]
-    trials = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    lengths, lik = workload_extras(name, n_trials)
+    if lengths is None:
+        trials = synth.make_trials(n_trials, n_bins, N, L, seed=0)
+    else:
+        trials = synth.make_trials(n_trials, n_bins, N, L, seed=0, n_gauss=C5_GAUSS, lengths=lengths)
     cfg = get_config()
-    params = get_params(trials, L, omega_bound=cfg["omega_bound"])
+    params = get_params(trials, L, omega_bound=cfg["omega_bound"], **({"lik": lik} if lik else {}))
     np.random.seed(0)
     initialize(trials, params, cfg)
     for tr in trials:
@@ -154,12 +171,14 @@ def _oracle_em_iteration(name, budget_trials, threads):
     with threadpool_limits(limits=threads):
         trials, a0, b0, (n_trials, n_bins, N, L) = build_inputs(name)
         trials = trials[:budget_trials]
+        _, lik = workload_extras(name, n_trials)
         for tr in trials:
-            tr["x"] = np.ones((n_bins, 1, N))
-            tr["w"] = np.zeros((n_bins, L))
-            tr["v"] = np.zeros((n_bins, L))
+            nb = tr["y"].shape[0]
+            tr["x"] = np.ones((nb, 1, N))
+            tr["w"] = np.zeros((nb, L))
+            tr["v"] = np.zeros((nb, L))
         cfg = O.make_config(max_iter=2, min_iter=2)
-        params = O.make_params(trials, L, a=a0.copy(), b=b0.copy())
+        params = O.make_params(trials, L, a=a0.copy(), b=b0.copy(), **({"lik": lik} if lik else {}))
         params["da"], params["db"] = np.zeros_like(a0), np.zeros_like(b0)
         O.fill_trials(trials)
         O.make_cholesky(trials, params)
@@ -237,12 +256,13 @@ def main():
     trials, a0, b0, (n_trials, n_bins, N, L) = build_inputs(args.workload)
     mine = comm.shard(trials)
     total_iters = args.warmup + args.steps
+    _, lik = workload_extras(args.workload, n_trials)
     sess = FitSession(mine, L, device=device, comm=comm if world > 1 else None, verbose=False,
-                      a=a0.copy(), b=b0.copy(), max_iter=total_iters, min_iter=total_iters)
+                      a=a0.copy(), b=b0.copy(), max_iter=total_iters, min_iter=total_iters, **({"lik": lik} if lik else {}))
     eng = sess.eng
     cfg = sess.config
     n_seg_local = len(sess.segs)
-    n_seg = n_trials * (n_bins // cfg["window"])
+    n_seg = sum(int(tr["y"].shape[0]) // cfg["window"] for tr in trials)
 
     for _ in range(args.warmup):
         sess.em_iteration()
@@ -476,9 +496,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %d trials x %d bins x %d Poisson channels, %d latents, window %d -> %d segments; "
-                               "Eniter=Mniter=25, rank 50, VB, Hstep on" % (args.workload, n_trials, n_bins, N, L,
-                                                                             cfg["window"], n_seg),
+        "config": {"workload": ("%s: %d trials x %d bins x %d Poisson channels, %d latents, window %d -> %d segments; "
+                                "Eniter=Mniter=25, rank 50, VB, Hstep on" % (args.workload, n_trials, n_bins, N, L,
+                                                                              cfg["window"], n_seg)) if lik is None else
+                               ("%s: %d ragged trials of 500 ... %d bins (%d bins in all) x %d channels (%d Poisson + %d "
+                                "Gaussian), %d latents, window %d -> %d segments; Eniter=Mniter=25, rank 50, VB, Hstep on"
+                                % (args.workload, n_trials, n_bins, sum(int(tr["y"].shape[0]) for tr in trials), N,
+                                   N - C5_GAUSS, C5_GAUSS, L, cfg["window"], n_seg)),
                    "parallelism": "trials sharded over %d rank(s)%s" % (
                        world, "" if world == 1 else "; all-reduce of the M-step statistics and norms over " + transport +
                        ", H-step round sums added on the host (shared memory)"),

@@ -285,6 +285,10 @@ int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
 #define VLGP_PATH_HSTEP_GENERIC 4  /* generic kernels (any window; the reference's omega retry) */
 #define VLGP_PATH_HSTEP_OLD 5      /* round-1 kernels behind their debug switches */
 int vlgp_debug_last_hstep_path(vlgp_ctx* ctx, int* path);
+/* The H-step's debug switches (environment VLGP_HSTEP_DENSE / _GENERIC / _LOWRANK / _GENERIC_SEG / _LR_TOL,
+ * VLGP_DEBUG_OCC) are read when the handle is created; this reads them again (tests that switch kernels on a live
+ * handle).  Nothing in production needs it. */
+int vlgp_debug_reload_switches(vlgp_ctx* ctx);
 /* Counters of the H-step objective calls since the handle was created: out[0] evaluations that took the low-rank round,
  * out[1] the sum of their predicted ranks (even + odd block), out[2] evaluations that took the dense round,
  * out[3] low-rank rounds re-run densely because a rank exceeded the prediction. */

@@ -5,7 +5,7 @@ C4 (C3 over 2/4/8 GPUs) needs the multi-GPU node: tests/test_gpu_multirank.py ru
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import relerr_elem, relerr
 from oracle import vlgp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -107,6 +107,11 @@ def test_c3_full_size_vem_against_reference_golden(V, golden):
             assert relerr(p[k], g[k]) < TRAJ, k
         for k in ("mu", "v", "w"):
             assert relerr(np.stack([segs[i][k] for i in pick]), g["seg_" + k]) < TRAJ, k
+        # element by element as well (parity item 3): every entry of the picked segments' mu, v to
+        # 1e-6 of its OWN size (floor: a tenth of the array's r.m.s.), not only of the largest entry
+        for k in ("mu", "v"):
+            assert relerr_elem(np.stack([segs[i][k] for i in pick]), g["seg_" + k]) < TRAJ, k
+        assert relerr_elem(traj[0][4], g["seg_mu_it1"]) < TRAJ
     finally:
         sess.close()
 

@@ -57,6 +57,31 @@ def test_fit_returns_the_references_dicts(V):
     assert res["config"]["runtime"]["it"] == 2 and len(res["config"]["runtime"]["em_elapsed"]) == 2
 
 
+def test_initial_cholesky_without_a_window(V):
+    """window=None: vlgp/api.py:60 deep-copies params after make_cholesky(trials), so params["initial"]["cholesky"]
+    holds the full-length factors of the INITIAL omega, sigma, keyed by trial length.  Same keys, and the arrays are
+    what the oracle's restatement of math.ichol_gauss (pinned to the reference's own ichol.npz) builds from
+    params["initial"]["omega"] / ["sigma"]."""
+    from oracle import vlgp_oracle as O
+    from vlgp_amd import synth
+
+    trials = [{"ID": t["ID"], "y": t["y"].copy()} for t in synth.make_trials(3, 120, 8, 2, seed=4)]
+    trials[1]["y"] = trials[1]["y"][:90].copy()  # two distinct lengths
+    np.random.seed(2)
+    # (Hstep=False: the reference's own H-step cannot run without a window -- gp.optimize builds np.arange(window))
+    res = V.fit(trials, 2, max_iter=2, min_iter=2, window=None, Hstep=False, verbose=False)
+    init = res["params"]["initial"]
+    assert sorted(int(k) for k in init["cholesky"].keys()) == [90, 120]
+    assert sorted(int(k) for k in res["params"]["cholesky"].keys()) == [90, 120]
+    want = O.build_prior([90, 120], init["omega"], init["sigma"], init["rank"])
+    for T in (90, 120):
+        G = init["cholesky"][T]
+        assert G.shape == (2, T, init["rank"])
+        assert relerr(G, want[T]) < 1e-12, T
+    # the copy is detached from the live params, as a deepcopy is
+    assert init["cholesky"] is not res["params"]["cholesky"]
+
+
 @pytest.mark.parametrize("ext", ["npy", "npz"])
 def test_reference_written_result_file_is_usable(V, ext):
     """util.save of the reference wrote tests/golden/ref_result.{npy,npz}; vlgp_amd.load reads it and

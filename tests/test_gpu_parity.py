@@ -17,6 +17,7 @@ from oracle import vlgp_oracle as O
 pytestmark = pytest.mark.gpu
 
 STAGE = 1e-9
+DLL_TOL = 1e-9  # (ll, dll) rel <= 1e-9
 TRAJ = 1e-6
 
 
@@ -391,16 +392,35 @@ def _resident(V, units, params, set_prior=True):
     return V.DeviceTrials(units, eng, 0)
 
 
-def test_hstep_objective_golden(V, golden):
+@pytest.mark.parametrize("lowrank", [False, True])
+def test_hstep_objective_golden(V, golden, lowrank, monkeypatch):
+    """(ll, dll) captured from the real reference (gp.py:12-43, 126-147) against BOTH round kernels: eight segments are
+    below the size rule's threshold, so the default takes the dense matrix-pipe round; VLGP_HSTEP_LOWRANK=1 holds the
+    low-rank round -- the kernel the headline runs -- to the same fixture directly (parity item 1)."""
     g = golden("hstep")
     M, T, L = g["mu"].shape
     units = [{"y": np.zeros((T, 2)), "mu": g["mu"][m].copy(), "w": g["w"][m].copy(),
               "v": np.zeros((T, L))} for m in range(M)]
+    if lowrank:
+        monkeypatch.setenv("VLGP_HSTEP_LOWRANK", "1")
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)
-        lat = np.repeat(np.arange(L), len(g["logp"]))
-        logp = np.tile(g["logp"], (L, 1))
-        ll, dll = eng.hstep_objective(0, T, 1.0, lat, logp)
+        if lowrank:
+            # one round per fixture point (a point above rank 32 -- omega = 0.05 -- sends its whole round to the dense
+            # kernel: in one call with the others it would take them along)
+            n_pt = len(g["logp"])
+            ll = np.empty((L, n_pt))
+            dll = np.empty((L, n_pt, 3))
+            for i in range(n_pt):
+                li, di = eng.hstep_objective(0, T, 1.0, np.arange(L), np.tile(g["logp"][i], (L, 1)))
+                ll[:, i], dll[:, i] = li, di
+                assert eng.last_hstep_path == ("lowrank" if np.exp(g["logp"][i, 1]) < 2e-2 else "dense"), i
+            ll, dll = ll.reshape(-1), dll.reshape(-1, 3)
+        else:
+            lat = np.repeat(np.arange(L), len(g["logp"]))
+            logp = np.tile(g["logp"], (L, 1))
+            ll, dll = eng.hstep_objective(0, T, 1.0, lat, logp)
+            assert eng.last_hstep_path == "dense"
     ll = ll.reshape(L, -1)
     dll = dll.reshape(L, -1, 3)
     for l in range(L):
@@ -430,13 +450,16 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
         eng.hstep_end()
         assert eng.last_hstep_path == "lowrank"
         monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
+        eng.reload_switches()  # (the switches are cached when the handle is created)
         dense = eng.hstep_objective(0, T, 1.0, lat, logp)
         assert eng.last_hstep_path == "dense"
         monkeypatch.delenv("VLGP_HSTEP_DENSE")
         monkeypatch.setenv("VLGP_HSTEP_GENERIC", "1")
+        eng.reload_switches()
         generic = eng.hstep_objective(0, T, 1.0, lat, logp)
         assert eng.last_hstep_path == "generic"
         monkeypatch.delenv("VLGP_HSTEP_GENERIC")
+        eng.reload_switches()
         for other in (first, again):
             assert np.array_equal(other[0], plain[0]) and np.array_equal(other[1], plain[1])
         # three different algorithms (Woodbury form at the numerical rank, blocked elimination of the 50 x 50 matrices,
@@ -475,13 +498,16 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
         again = eng.hstep_objective(0, T, 1.0, lat, logp)
         assert np.array_equal(low[0], again[0]) and np.array_equal(low[1], again[1])  # repeatable bit for bit
         monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
+        eng.reload_switches()
         dense = eng.hstep_objective(0, T, 1.0, lat, logp)
         assert eng.last_hstep_path == "dense"
         assert np.array_equal(dense[0], eng.hstep_objective(0, T, 1.0, lat, logp)[0])
         monkeypatch.delenv("VLGP_HSTEP_DENSE")
         monkeypatch.setenv("VLGP_HSTEP_GENERIC", "1")
+        eng.reload_switches()
         generic = eng.hstep_objective(0, T, 1.0, lat, logp)
         monkeypatch.delenv("VLGP_HSTEP_GENERIC")
+        eng.reload_switches()
         # an evaluation above the rank the low-rank round takes sends the whole round to the dense kernel
         rough = logp.copy()
         rough[2, 1] = np.log(4e-2)
@@ -520,8 +546,10 @@ def test_hstep_objective_other_bin_widths_vs_oracle(V, dt, monkeypatch):
             ll, dll = eng.hstep_objective(0, T, dt, np.arange(L), logp)
             assert eng.last_hstep_path == path
             monkeypatch.setenv("VLGP_HSTEP_GENERIC", "1")
+            eng.reload_switches()
             llg, dllg = eng.hstep_objective(0, T, dt, np.arange(L), logp)
             monkeypatch.delenv("VLGP_HSTEP_GENERIC")
+            eng.reload_switches()
             for l in range(L):
                 want = O.gp_objective(logp[l], t, np.stack([u["mu"][:, l] for u in units], 1),
                                       np.stack([u["w"][:, l] for u in units], 1))
@@ -552,14 +580,16 @@ def test_hstep_objective_other_windows_vs_oracle(V, T, monkeypatch):
         want_ll, want_dll = O.gp_objective(logp[l], t, np.stack([u["mu"][:, l] for u in units], 1),
                                            np.stack([u["w"][:, l] for u in units], 1))
         assert abs(ll[l] - want_ll) <= STAGE * abs(want_ll), (T, l)
-        assert abs(dll[l, 1] - want_dll[1]) <= 1e-7 * max(abs(want_dll[1]), 1e-3 * abs(want_ll)), (T, l)
+        # windows above 64 bins (hstep_prep_big / hstep_seg_big): measured 3.2e-9 at window 128, 1e-9 holds up to 64 --
+        # cond(K) grows with the window and the oracle's LAPACK path carries it as well
+        assert abs(dll[l, 1] - want_dll[1]) <= (DLL_TOL if T <= 64 else 1e-8) * max(abs(want_dll[1]), 1e-3 * abs(want_ll)), (T, l)
     if 64 < T <= 128:
         monkeypatch.setenv("VLGP_HSTEP_GENERIC_SEG", "1")
         with V.Engine(2, L, 1, 50) as eng:
             eng.upload(0, units)
             ll2, dll2 = eng.hstep_objective(0, T, 1.0, np.arange(L), logp)
         assert np.abs(ll2 - ll).max() <= STAGE * np.abs(ll).max()
-        assert np.abs(dll2[:, 1] - dll[:, 1]).max() <= 1e-7 * np.abs(ll).max()
+        assert np.abs(dll2[:, 1] - dll[:, 1]).max() <= 1e-8 * np.abs(ll).max()
 
 
 def test_hstep_optimize_golden(V, golden):

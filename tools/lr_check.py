@@ -23,9 +23,11 @@ def run(T, M, L, omegas, wscale, seed=0, oracle=True):
             logp[:, 1] += np.linspace(0, 0.3, L)
             os.environ.pop("VLGP_HSTEP_DENSE", None)
             os.environ["VLGP_HSTEP_LOWRANK"] = "1"  # whatever the size rule says
+            eng.reload_switches()  # (cached at vlgp_create)
             ll1, dll1 = eng.hstep_objective(0, T, 1.0, lat, logp)
             p1 = eng.last_hstep_path
             os.environ["VLGP_HSTEP_DENSE"] = "1"
+            eng.reload_switches()
             ll2, dll2 = eng.hstep_objective(0, T, 1.0, lat, logp)
             p2 = eng.last_hstep_path
             os.environ.pop("VLGP_HSTEP_DENSE", None)

@@ -17,6 +17,7 @@ logp = np.log(np.array([[1.0, om, 1e-4] for om in oms]))
 for dense in (False, True):
     if dense: os.environ["VLGP_HSTEP_DENSE"] = "1"
     else: os.environ.pop("VLGP_HSTEP_DENSE", None)
+    eng.reload_switches()  # (cached at vlgp_create)
     for _ in range(5):
         eng.hstep_objective(sid, 50, 1.0, lat, logp)
     eng.synchronize()

@@ -13,9 +13,11 @@ sid = sess.segs.set_id
 L = dims[3]
 eng.hstep_begin(sid, 50)
 os.environ["VLGP_HSTEP_LOWRANK"] = "1"  # (no size rule: this is what calibrates it)
+eng.reload_switches()
 def timeit(lat, logp, dense):
     if dense: os.environ["VLGP_HSTEP_DENSE"] = "1"
     else: os.environ.pop("VLGP_HSTEP_DENSE", None)
+    eng.reload_switches()  # (cached at vlgp_create)
     for _ in range(5):
         eng.hstep_objective(sid, 50, 1.0, lat, logp)
     eng.synchronize()

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "vlgp_debug_npx": (C.c_int, [_h, C.c_int, C.c_int64, _dp, _dp, _dp]),
     "vlgp_debug_last_estep_path": (C.c_int, [_h, _ip]),
     "vlgp_debug_last_hstep_path": (C.c_int, [_h, _ip]),
+    "vlgp_debug_reload_switches": (C.c_int, [_h]),
     "vlgp_debug_hstep_stats": (C.c_int, [_h, _dp]),
 }
 EXPORTS = tuple(_SIGNATURES)

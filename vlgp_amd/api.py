@@ -142,12 +142,14 @@ class FitSession:
             else:
                 self.segs = self.dev_trials
             # params["initial"] = deepcopy(params) (api.py:60): every key, the segment-length factors included.  The
-            # resident factor is downloaded for it only when a window is set (one (L, window, rank) array); without
-            # a window it would be every full-length factor, which stays on the device until someone asks
+            # resident factor is downloaded for it when a window is set (one (L, window, rank) array); without a
+            # window it is every full-length factor: those are rebuilt on the host when somebody reads them
             snapshot = {k: v for k, v in params.items() if k != "cholesky"}
             chol = params["cholesky"]
             if isinstance(chol, E._LazyPrior):
-                chol = chol.materialize() if window else dict()
+                # no window: the full-length factors of the initial omega, factored on first access (engine._InitialPrior)
+                chol = chol.materialize() if window else E._InitialPrior(chol._lengths, params["omega"], params["sigma"],
+                                                                         params["rank"])
             snapshot["cholesky"] = chol
             params["initial"] = copy.deepcopy(snapshot)
             E._push_params(eng, params)

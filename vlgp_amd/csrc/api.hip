@@ -479,6 +479,7 @@ extern "C" int vlgp_create(int device, int N, int L, int P, int R, const uint8_t
     vlgp_ctx* ctx = new (std::nothrow) vlgp_ctx();
     if (!ctx) return vlgp_fail(nullptr, VLGP_ERR_HIP, "out of host memory");
     ctx->dev = device; ctx->N = N; ctx->L = L; ctx->P = P; ctx->R = R;
+    vlgp_read_switches(ctx);
 #define CREATE_CHK(call)                                                                  \
     do {                                                                                  \
         hipError_t e2 = (call);                                                           \
@@ -1039,8 +1040,21 @@ extern "C" int vlgp_set_overlaps(vlgp_ctx* ctx, int set, int n_stages, const int
         if (stage_start[s + 1] < stage_start[s]) return vlgp_fail(ctx, VLGP_ERR_ARG, "stages must be ordered");
     for (int k = 0; k < n_links; ++k) {
         const int a = links[3 * k], b = links[3 * k + 1], o = links[3 * k + 2];
-        if (a < 0 || a >= us->M || b < 0 || b >= us->M || o < 1 || o >= us->Tmax)
+        if (a < 0 || a >= us->M || b < 0 || b >= us->M || a == b || o < 1 || o >= us->Tmax)
             return vlgp_fail(ctx, VLGP_ERR_ARG, "bad overlap link %d", k);
+    }
+    if (n_links > 0) {
+        // link_start[s] .. link_start[s + 1] index `links` for stage s: they go to the copy kernels unchecked afterwards
+        if (link_start[0] != 0 || link_start[n_stages] != n_links)
+            return vlgp_fail(ctx, VLGP_ERR_ARG, "link_start must run from 0 to n_links");
+        for (int s = 0; s < n_stages; ++s) {
+            if (link_start[s + 1] < link_start[s]) return vlgp_fail(ctx, VLGP_ERR_ARG, "link_start must be non-decreasing");
+            for (int k = link_start[s]; k < link_start[s + 1]; ++k) {
+                const int b = links[3 * k + 1];  // the second unit of a link lies in the stage the link is filed under
+                if (b < stage_start[s] || b >= stage_start[s + 1])
+                    return vlgp_fail(ctx, VLGP_ERR_ARG, "overlap link %d is filed under stage %d but its second unit is not in it", k, s);
+            }
+        }
     }
     us->stage_start.assign(stage_start, stage_start + n_stages + 1);
     us->link_start.assign(n_links > 0 ? link_start : stage_start, (n_links > 0 ? link_start : stage_start) + n_stages + 1);
@@ -1268,6 +1282,22 @@ extern "C" int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path) {
     NEED_CTX(ctx);
     if (!path) return vlgp_fail(ctx, VLGP_ERR_ARG, "null path");
     *path = ctx->last_estep_path;
+    return VLGP_OK;
+}
+
+void vlgp_read_switches(vlgp_ctx* ctx) {
+    HstepSwitches& w = ctx->hsw;
+    w.dense = getenv("VLGP_HSTEP_DENSE") != nullptr;
+    w.generic = getenv("VLGP_HSTEP_GENERIC") != nullptr;
+    w.lowrank = getenv("VLGP_HSTEP_LOWRANK") != nullptr;
+    w.generic_seg = getenv("VLGP_HSTEP_GENERIC_SEG") != nullptr;
+    w.debug_occ = getenv("VLGP_DEBUG_OCC") != nullptr;
+    w.lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-12;
+}
+
+extern "C" int vlgp_debug_reload_switches(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    vlgp_read_switches(ctx);
     return VLGP_OK;
 }
 

@@ -56,6 +56,15 @@ struct UnitSet {
     bool share_mu = true;           // false once the segments' mu was rebound (constrain_loading "svd")
 };
 
+// Debug / test switches of the H-step dispatch (environment VLGP_HSTEP_*, VLGP_DEBUG_OCC), read ONCE when the handle is
+// created and again on vlgp_debug_reload_switches: the objective call itself -- ~40 times per EM iteration, on the
+// optimiser's critical path -- reads this struct, not the environment.
+struct HstepSwitches {
+    bool dense = false, generic = false, lowrank = false, generic_seg = false, debug_occ = false;
+    double lr_tol = 1e-12;
+};
+void vlgp_read_switches(struct vlgp_ctx* ctx);
+
 struct ProfSlot {
     int64_t launches = 0;
     double ms = 0.0;
@@ -122,6 +131,8 @@ struct vlgp_ctx {
     // low-rank H-step round (hstep_lr.h): per (window, dt, tol) the largest omega whose folded kernel blocks have rank <= r
     struct LrThr { int T; double dt, tol; std::vector<double> om; };
     std::vector<LrThr> lr_thr;
+    HstepSwitches hsw;
+    std::vector<const void*> lds_attr_done;  // kernels whose dynamic-LDS ceiling was raised on this handle's device
     int last_hstep_path = 0;      // VLGP_PATH_HSTEP_* of the most recent H-step objective call
     double hstat[4] = {0.0, 0.0, 0.0, 0.0};  // vlgp_debug_hstep_stats
 

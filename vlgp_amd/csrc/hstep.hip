@@ -1014,11 +1014,14 @@ constexpr int LR_NW = 4;  // waves per workgroup of the low-rank round (sixteen 
 template <int T, int RC, bool TABG = false>
 static int launch_round_lr(vlgp_ctx* ctx, const HRoundArgs& R, int grid, size_t lds_bytes) {
     constexpr int NW = LR_NW;
-    static size_t attr_set = 0;
-    if (lds_bytes > attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC, TABG>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512)));
-        attr_set = 160 * 1024;
+    // the dynamic-LDS ceiling is a per-DEVICE attribute of the function: remembered per handle (one handle = one device),
+    // not per process (a second engine on another device never got it)
+    const void* fn = reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC, TABG>);
+    bool have = false;
+    for (const void* f : ctx->lds_attr_done) have = have || f == fn;
+    if (!have) {
+        HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512)));
+        ctx->lds_attr_done.push_back(fn);
     }
     hipLaunchKernelGGL((hstep_round_lr<T, NW, RC, TABG>), dim3(grid), dim3(64 * NW), lds_bytes, ctx->stream, R);
     return VLGP_OK;
@@ -1048,8 +1051,9 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     // (round 4: the round-1 / round-2 kernels behind VLGP_HSTEP_UNFUSED / _PADDED / _LEAN / _TWOSET are gone; what is left
     // is the low-rank round, the dense matrix-pipe round (VLGP_HSTEP_DENSE=1 forces it), and the generic kernels
     // (VLGP_HSTEP_GENERIC=1), which also implement the reference's omega retry)
-    const bool lr_allowed = !force_dense && !getenv("VLGP_HSTEP_DENSE");
-    const bool fast = T <= 64 && T >= (lr_allowed ? 4 : 24) && !getenv("VLGP_HSTEP_GENERIC");
+    const HstepSwitches& sw = ctx->hsw;  // (the environment is read at vlgp_create / vlgp_debug_reload_switches)
+    const bool lr_allowed = !force_dense && !sw.dense;
+    const bool fast = T <= 64 && T >= (lr_allowed ? 4 : 24) && !sw.generic;
     const int TC = T <= 50 ? 50 : 64;  // compiled window
     const int64_t TT = fast ? (int64_t)TC * TC : (int64_t)T * T;
     // workspace: kinv | q | dk | scal | seg_out | red | logp | latent(int)
@@ -1116,8 +1120,8 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             const bool mfma = true;
             // the exact low-rank round (hstep_lr.h) when every evaluation's kernel matrix has numerical rank <= LR_RCAP
             // (omega below about 2e-2 on a 50-bin window); VLGP_HSTEP_DENSE=1 keeps the dense matrix-pipe round
-            const bool lr_off = getenv("VLGP_HSTEP_DENSE") != nullptr;  // read per call: the tests switch it
-            const double lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-12;
+            const bool lr_off = sw.dense;
+            const double lr_tol = sw.lr_tol;
             bool lr = !lr_off && !force_dense;
             int rcap[16], rmax = 0;
             if (lr) {
@@ -1131,7 +1135,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     if (rcap[e] > rmax) rmax = rcap[e];
                 }
             }
-            if (lr && !getenv("VLGP_HSTEP_LOWRANK")) {
+            if (lr && !sw.lowrank) {
                 // Which round is faster depends on how much there is to do (measured on MI355X, tools/lr_round_bench.py,
                 // us per round over n = n_eval x M segment-evaluations, 4000 of them = one "generation"):
                 //   dense      41 + 28 (n / 4000 - 1): one wave per segment, 4096 resident waves, ~25 us wave lifetime
@@ -1143,7 +1147,11 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // single launch wins there.  VLGP_HSTEP_LOWRANK=1 takes the low-rank round regardless (tests).
                 static const double base[4] = {26.0, 35.0, 42.0, 51.0}, marg[4] = {8.7, 12.0, 15.5, 22.6};
                 const int ci = rmax <= 16 ? 0 : (rmax <= 24 ? 1 : (rmax <= 28 ? 2 : 3));
-                const double gens = (double)n_eval * M / 4000.0;
+                // (several ranks: the rule must pick the SAME round on every rank -- a rank alone on the low-rank round
+                // would also be alone in its overflow fallback and its extra collectives, ADVICE round 4 -- so it looks
+                // at the mean shard, a rank-invariant number once the row totals have been exchanged)
+                const double m_rule = (ctx->world > 1 && us.rows_all_ranks > 0.0) ? us.rows_all_ranks / ((double)T * ctx->world) : (double)M;
+                const double gens = (double)n_eval * m_rule / 4000.0;
                 const double extra = gens > 1.0 ? gens - 1.0 : 0.0;
                 const double t_dense = 41.0 + 28.0 * extra, t_lr = 13.0 + base[ci] + marg[ci] * extra;
                 if (T >= 24 && t_lr > 0.95 * t_dense) lr = false;
@@ -1253,7 +1261,19 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 }
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 for (int i = 0; i < 3 * n_eval; ++i) hres[i] = ctx->h_hres[i];
-                if (ctx->world > 1) CHK(vlgp_hx_allreduce(ctx, hres, 2 * n_eval));
+                if (ctx->world > 1) {
+                    // the status flags travel with the sums (as counts: failed factorisations + 1024 x overflows), so that
+                    // every rank takes the same fallback
+                    for (int e = 0; e < n_eval; ++e) {
+                        const double f = hres[2 * n_eval + e];
+                        hres[2 * n_eval + e] = f == 1.0 ? 0.0 : (f == 2.0 ? 1024.0 : 1.0);
+                    }
+                    CHK(vlgp_hx_allreduce(ctx, hres, 3 * n_eval));
+                    for (int e = 0; e < n_eval; ++e) {
+                        const double c = hres[2 * n_eval + e];
+                        hres[2 * n_eval + e] = c == 0.0 ? 1.0 : (fmod(c, 1024.0) != 0.0 ? 0.0 : 2.0);
+                    }
+                }
             } else {
                 CHK(vlgp_allreduce(ctx, W + o_red, 2LL * n_eval));
                 HIPCHK(ctx, hipMemcpyAsync(hres, W + o_red, sizeof(double) * 3 * n_eval, hipMemcpyDeviceToHost, ctx->stream));
@@ -1279,7 +1299,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         }
         // K did not factor for some evaluation: fall through to the generic path,
         // which implements the reference's omega bump
-        if (getenv("VLGP_DEBUG_OCC")) fprintf(stderr, "hstep: K failed to factor in a round of %d evaluations -> generic kernels\n", n_eval);
+        if (sw.debug_occ) fprintf(stderr, "hstep: K failed to factor in a round of %d evaluations -> generic kernels\n", n_eval);
     }
     // generic path: its sums go through the main communicator; with several ranks the M-step lane's
     // collectives must not be in flight at the same time (two communicators, no common order)
@@ -1306,7 +1326,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     if (lds_prep > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hstep_prep_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
-    const bool big = T > 64 && T <= 128 && !getenv("VLGP_HSTEP_GENERIC_SEG");  // hstep_prep_big / hstep_seg_big
+    const bool big = T > 64 && T <= 128 && !sw.generic_seg;  // hstep_prep_big / hstep_seg_big
     ctx->last_hstep_path = big ? VLGP_PATH_HSTEP_BIG : VLGP_PATH_HSTEP_GENERIC;
     if (big) {
         const size_t lds_pb = (size_t)(4 * 64 * 66 + HmGeom<64>::TASK + 2 * 128) * 8;

@@ -390,6 +390,10 @@ class Engine:
         self._ck(self.lib.vlgp_debug_last_hstep_path(self.h, C.byref(p)))
         return _lib.HSTEP_PATHS[p.value]
 
+    def reload_switches(self):
+        """Read the VLGP_HSTEP_* debug switches from the environment again (they are cached at creation)."""
+        self._ck(self.lib.vlgp_debug_reload_switches(self.h))
+
     def hstep_stats(self):
         """(low-rank evaluations, sum of their predicted ranks, dense evaluations, low-rank rounds re-run densely)."""
         out = np.zeros(4)
@@ -560,6 +564,49 @@ class _LazyPrior(dict):
 
     def materialize(self):
         return {T: np.array(self[T]) for T in sorted(self._lengths)}
+
+
+class _InitialPrior(dict):
+    """params["initial"]["cholesky"] of a fit without a window (vlgp/api.py:60 deep-copies the full-length factors of
+    the INITIAL omega, sigma): the device's copies are overwritten by the first H-step and downloading every
+    full-length factor up front costs PCIe time nobody may want, so a length is factored on first access -- on the
+    host, in math.ichol_gauss's own operation order (gp.ichol_gauss_host), from the initial hyperparameters kept here."""
+
+    def __init__(self, lengths, omega, sigma, rank):
+        super().__init__()
+        self._lengths = sorted(int(t) for t in lengths)
+        self._omega, self._sigma, self._rank = np.array(omega, dtype=float), np.array(sigma, dtype=float), int(rank)
+
+    def __missing__(self, T):
+        from . import gp as _gp
+
+        if int(T) not in self._lengths:
+            raise KeyError(T)
+        G = np.stack([_gp.ichol_gauss_host(int(T), self._omega[l], self._rank) * self._sigma[l]
+                      for l in range(len(self._omega))])
+        self[int(T)] = G
+        return G
+
+    def __contains__(self, T):
+        return int(T) in self._lengths
+
+    def __iter__(self):
+        return iter(self._lengths)
+
+    def __len__(self):
+        return len(self._lengths)
+
+    def keys(self):
+        return list(self._lengths)
+
+    def items(self):
+        return [(T, self[T]) for T in self._lengths]
+
+    def values(self):
+        return [self[T] for T in self._lengths]
+
+    def __deepcopy__(self, memo):
+        return _InitialPrior(self._lengths, self._omega, self._sigma, self._rank)
 
 
 def update_w(trials, params, config=None):
