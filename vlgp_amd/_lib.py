@@ -101,11 +101,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("VLGP_LIB_PATH", LIB_PATH)  # (A/B runs of two builds on one box; never set in production)
+    if not os.path.exists(path):
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C vlgp_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "or `make -C vlgp_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res

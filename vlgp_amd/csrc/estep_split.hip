@@ -297,7 +297,7 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
                 for (int l = 0; l < LT; ++l) eta = fma(mr[q][l], rv[l], eta);
 #pragma unroll
                 for (int l = 0; l < LT; ++l) eta = fma(vr[q][l], rv[LT + l], eta);
-                const double rate = fast_exp_tab256(clamp10(eta), etab);
+                const double rate = trunc_exp_tab256(eta, etab);
 #pragma unroll
                 for (int l = 0; l < LT; ++l) acc[q][l] = fma(rate, rv[KIND == SP_RES ? l : LT + l], acc[q][l]);
             }

@@ -57,8 +57,9 @@ __device__ __forceinline__ void fast_exp_tab_init(double* tab, int tid) {
 // exp(x) for x <= 10 through the 64-entry table (in LDS): x = (64 e + j) ln2/64 + r, |r| <= ln2/128,
 // exp(x) = 2^e 2^(j/64) (1 + expm1(r)), expm1 by its degree-5 Taylor polynomial (truncation 3.4e-17).
 // Twelve double-precision operations instead of twenty-one; < 1.5 ulp.
+template <bool CLAMPED = false>
 __device__ __forceinline__ double fast_exp_tab(double x, const double* tab) {
-    x = x < -745.0 ? -745.0 : x;
+    if constexpr (!CLAMPED) x = x < -745.0 ? -745.0 : x;
     const double k = rint(x * 0x1.71547652b82fep+6);  // 64 / ln 2
     double r = fma(k, -0x1.62e42fee00000p-7, x);  // ln2_hi / 64 (low 32 bits zero: k * hi is exact)
     r = fma(k, -0x1.a39ef35793c76p-39, r);  // ln2_lo / 64
@@ -139,8 +140,9 @@ static __device__ const double vlgp_exp2_tab256[256] = {
     0x1.fa7c1819e90d8p+0, 0x1.fbdba3692d514p+0, 0x1.fd3c22b8f71f1p+0, 0x1.fe9d96b2a23d9p+0,
 };
 
+// (any workgroup size: the M-step runs 128 ... 512 threads)
 __device__ __forceinline__ void fast_exp_tab256_init(double* tab, int tid) {
-    if (tid < 256) tab[tid] = vlgp_exp2_tab256[tid];
+    for (int i = tid; i < 256; i += (int)blockDim.x) tab[i] = vlgp_exp2_tab256[i];
 }
 
 // exp(x) for x <= 10 through the 256-entry table (2 KB of LDS): x = (256 e + j) ln2/256 + r, |r| <= ln2/512,
@@ -148,8 +150,10 @@ __device__ __forceinline__ void fast_exp_tab256_init(double* tab, int tid) {
 // The integer part comes from the low word of x 256/ln2 + 1.5 2^52 (round to nearest by the addition itself: no
 // multiply / round / convert), so ten double-precision operations after the clamp instead of twelve; < 1.5 ulp.
 // A NaN stays a NaN (the index is masked, r is NaN).
+// CLAMPED: the caller's argument is already inside [-745, 10].
+template <bool CLAMPED = false>
 __device__ __forceinline__ double fast_exp_tab256(double x, const double* tab) {
-    x = x < -745.0 ? -745.0 : x;
+    if constexpr (!CLAMPED) x = x < -745.0 ? -745.0 : x;
     const double kd = fma(x, 0x1.71547652b82fep+8, 0x1.8p+52);  // 256 / ln 2
     const int ki = __double2loint(kd);
     const double k = kd - 0x1.8p+52;
@@ -160,4 +164,19 @@ __device__ __forceinline__ double fast_exp_tab256(double x, const double* tab) {
     p = fma(p, r, 0.5);
     const double q = fma(p, r * r, r);
     return ldexp(fma(t, q, t), ki >> 8);
+}
+
+// math.trunc_exp (vlgp/math.py:24-38), exp(min(x, 10)), for the row passes: both clamps as one v_min / v_max pair (two
+// instructions instead of two compares and four selects; they drop a NaN, IEEE minNum / maxNum), and one FMA at the end
+// that puts it back: x * 0 is 0 for every finite x and NaN for a NaN.  (+-inf also come out as NaN where the reference
+// returns exp(10) / 0: an infinite linear predictor needs an infinite mu, a or b, which no finite input produces -- every
+// update of the E- and M-step is clipped.)
+__device__ __forceinline__ double trunc_exp_tab256(double x, const double* tab) {
+    const double xc = fmax(fmin(x, 10.0), -745.0);
+    return fma(x, 0.0, fast_exp_tab256<true>(xc, tab));
+}
+// the same through the 64-entry table (the M-step: its LDS is room the H-step's workgroups lose)
+__device__ __forceinline__ double trunc_exp_tab64(double x, const double* tab) {
+    const double xc = fmax(fmin(x, 10.0), -745.0);
+    return fma(x, 0.0, fast_exp_tab<true>(xc, tab));
 }

@@ -88,13 +88,16 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
     double* red = smem;                       // aliases the tiles after the row loop: MS_GS x (S CT)
     const int red_d = MS_GS * S * CT;
     double* etab = smem + (NBUF * tile_d > red_d ? NBUF * tile_d : red_d);  // NEWTON: 2^(j/64) for fast_exp_tab
+    // (the 64-entry table, not the E-step passes' 256-entry one: measured on one box, same build otherwise, the extra
+    // 1.5 KB of LDS per workgroup make this kernel 3 % faster and the EM iteration 4 % SLOWER -- 143-144 against 147-150 EM
+    // it/s at C3 -- because the H-step's round workgroups lose room on every CU while the two lanes run side by side)
     if constexpr (KIND == K_NEWTON) fast_exp_tab_init(etab, tid);
 
     double al[LT], al2[LT], bl[PT], acc[NA];
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
         al[l] = (active && l < L) ? A.a[l * N + n] : 0.0;
-        al2[l] = al[l] * al[l];
+        al2[l] = 0.5 * al[l] * al[l];  // half squares: the rate's exponent is one chain x.b + mu.a + v.(a^2 / 2)
     }
 #pragma unroll
     for (int j = 0; j < PT; ++j) bl[j] = (active && j < P) ? A.b[j * N + n] : 0.0;
@@ -150,16 +153,16 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
 #pragma unroll
                     for (int j = 0; j <= i; ++j) { acc[k] = fma(xv[i], xv[j], acc[k]); ++k; }
             } else {
-                double eta = 0.0, lin = 0.0;
+                double eta = 0.0;
 #pragma unroll
                 for (int j = 0; j < PT; ++j) eta = fma(xv[j], bl[j], eta);
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
-                    eta = fma(mr[l], al[l], eta);
-                    lin = fma(vr[l], al2[l], lin);
-                }
+                for (int l = 0; l < LT; ++l) eta = fma(mr[l], al[l], eta);
                 if constexpr (KIND == K_NEWTON) {
-                    const double rate = fast_exp_tab(clamp10(fma(0.5, lin, eta)), etab);
+                    double ex = eta;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) ex = fma(vr[l], al2[l], ex);
+                    const double rate = trunc_exp_tab64(ex, etab);
                     double mt[LT], q[LT];
 #pragma unroll
                     for (int l = 0; l < LT; ++l) {
