@@ -1637,7 +1637,9 @@ int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const dim3 grid((unsigned)(groups * A.n_lat)), blk(256);
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
-    auto fn = !mean ? esplit_lane<0> : (last ? esplit_lane<2> : esplit_lane<1>);
+    const bool big = A.shg_rk[0] > LANE_RSMALL;  // (run_latent launches the two kinds separately)
+    auto fn = big ? (!mean ? esplit_lane<0, true> : (last ? esplit_lane<2, true> : esplit_lane<1, true>))
+                  : (!mean ? esplit_lane<0, false> : (last ? esplit_lane<2, false> : esplit_lane<1, false>));
     if (lds > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -1682,13 +1684,17 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         }
         CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
     }
-    if (C.n_ln) {
-        A.n_lat = C.n_ln;
+    for (int kind = 0; kind < 2 && C.n_ln; ++kind) {  // ranks above LANE_RSMALL first (the longer workgroups), then the others
+        A.n_lat = 0;
         for (int i = 0; i < C.n_ln; ++i) {
-            A.lat[i] = C.ln[i];
-            A.shg_rk[i] = C.single->rl[C.ln[i]];
-            A.shg_gl[i] = C.single->d_compact + C.single->goff[C.ln[i]];
+            const int rk = C.single->rl[C.ln[i]];
+            if ((rk > LANE_RSMALL) != (kind == 0)) continue;
+            A.lat[A.n_lat] = C.ln[i];
+            A.shg_rk[A.n_lat] = rk;
+            A.shg_gl[A.n_lat] = C.single->d_compact + C.single->goff[C.ln[i]];
+            ++A.n_lat;
         }
+        if (!A.n_lat) continue;
         A.shg = 1;
         A.shg_T = C.single_T;
         static const int prio = getenv("VLGP_LANE_PRIO") ? atoi(getenv("VLGP_LANE_PRIO")) : 0;  // (measured: 3 is 5 % slower)
@@ -1860,7 +1866,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     // half's issue-bound passes.  No dependency crosses the halves between the fork and the join; results are
     // bit-identical to the single lane (same arithmetic per unit).  VLGP_ESTEP_LANES=1 keeps one lane.
     const int lanes_env = getenv("VLGP_ESTEP_LANES") ? atoi(getenv("VLGP_ESTEP_LANES")) : 0;  // (per call: tests toggle it)
-    int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 6 * ctx->n_cu && n_it >= 2 ? 2 : 1);  // 2000 units: 2.11 -> 1.77 ms, 1000 units: no change
+    int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 3 * ctx->n_cu && n_it >= 2 ? 2 : 1);  // 2000 units: 2.11 -> 1.77 ms; 1000 units: no change with the wave-per-task launches, 1.60 -> 1.54 ms (and the H-step that follows 2.60 -> 2.41 ms) with the lane-per-task ones
     while (n_lanes > 1 && us.M < 8 * n_lanes) --n_lanes;
     for (int h = 1; h < n_lanes; ++h) {
         if (ctx->elane[h - 1]) continue;

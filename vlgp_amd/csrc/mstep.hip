@@ -24,7 +24,9 @@
 // rows of (mu | v) staged in LDS per step: 20 KB at five latents.  (Round 4: 512 / 800 rows make the M-step ALONE faster --
 // 2.23 -> 2.17 / 2.14 ms, fewer barriers -- and the EM iteration slower, 139 -> 135 / 132 EM it/s on the same box: the LDS
 // they take is room the H-step's round workgroups lose on every CU while the two lanes run side by side.)
+#ifndef M_TILE
 #define M_TILE 256
+#endif
 
 enum { K_PREP = 0, K_NEWTON = 1, K_NOISE1 = 2, K_NOISE2 = 3 };
 
