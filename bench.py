@@ -100,7 +100,7 @@ def pmc_traffic(kernel_key):
     else profiles/r1: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, plus WRITE_SIZE; separate
     passes).  None when no measurement is on file for that exact kernel name."""
     if not _PMC_CACHE:
-        for rnd in ("r1", "r2", "r3", "r4"):  # later rounds override
+        for rnd in ("r1", "r2", "r3", "r4", "r5"):  # later rounds override
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
                     _PMC_CACHE.update(json.load(f))
@@ -389,16 +389,18 @@ def main():
             kernels["esplit_latent<factor>"] = entry(
                 n_f, ms_f, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_f / n_f,
                 flops_per_launch_executed=fl, sampled="one launch per E-step call",
-                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_latent<%d, false*" % ra_typ,
-                note="one wave per (unit, latent): I + G'WG (MFMA), factor + inverse, variance; bound by vector "
-                     "instruction issue (PMC: ~900 VALU instructions + 13 MFMA per wave, ~85 % of the issue slots)")
+                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_lane<0, false*",
+                note="factor + variance launches of one lane (half of the units): esplit_lane<0, *> (one LANE per (unit, "
+                     "latent), ranks <= 16: a few hundred long workgroups, bound by one workgroup's latency) plus the "
+                     "wave-per-task esplit_latent<*, false> launch of the latents above rank 16; the event pair also "
+                     "brackets the other lane's row passes running beside it")
         n_u, ms_u, u_u = prof["estep_mean"]
         if n_u:
             fl = float(np.mean([8.0 * T * r for r in rk_mean])) * u_u / n_u
             kernels["esplit_latent<mean>"] = entry(
                 n_u, ms_u, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_u / n_u,
                 flops_per_launch_executed=fl, sampled="one launch per E-step call",
-                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_latent<%d, true*" % ra_typ)
+                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_lane<1, false*")
     n_m, ms_m, u_m = prof["mstep"]
     if n_m:
         fl = work["mstep_flops_per_row"] * u_m / n_m
@@ -444,9 +446,12 @@ def main():
             bytes_per_launch_algorithmic=work["hstep_bytes_per_seg_eval"] * u_l / n_l,
             pmc_key="hstep_round_lr<*", per_step_ms=ms_l / k_steps,
             avg_ms_overlapped=(prof_live["hstep_lr"][1] / prof_live["hstep_lr"][0]) if prof_live["hstep_lr"][0] else None,
-            note="exact low-rank (Woodbury) round, hstep_lr.h: `achieved` / `frac` price the launch at SURVEY 8(d)'s "
-                 "count M (T^3 + 4 T^2) (the work of the reference's algorithm, which this kernel replaces); "
-                 "`achieved_executed` / `frac_executed` at the flops the low-rank form issues at the mean rank")
+            frac_dense_equivalent=fl / (ms_l / n_l * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            frac_basis="`achieved` / `frac` (= frac_dense_equivalent): the launch priced at SURVEY 8(d)'s count "
+                       "M (T^3 + 4 T^2) per evaluation, the work of the reference's dense algorithm, which this kernel "
+                       "does NOT execute; `achieved_executed` / `frac_executed`: the flops the low-rank form issues at the "
+                       "mean rank -- that one is the utilisation of the fp64 pipes",
+            note="exact low-rank (Woodbury) round, hstep_lr.h")
         n_t, ms_t, u_t = prof["hstep_tab"]
         if n_t:
             kernels["hstep_lr_tables"] = {"launches": n_t, "avg_ms": ms_t / n_t, "total_ms": ms_t,
@@ -485,6 +490,9 @@ def main():
                     "algorithmic_flops_per_launch": kd.get("flops_per_launch_survey_count", kd["flops_per_launch_executed"]),
                     "executed_flops_per_launch": kd["flops_per_launch_executed"],
                     "frac_executed": kd.get("frac_executed"),
+                    "frac_dense_equivalent": kd.get("frac_dense_equivalent"),
+                    "frac_basis": kd.get("frac_basis"),
+                    "not_live": ["traffic", "hbm_gbs", "hbm_frac", "avg_launch_ms_rocprofv3"],
                     "avg_launch_ms_overlapped_in_timed_region": kd.get("avg_ms_overlapped"),
                     "timing": kernel_timing,
                     "traffic_source": "replayed from the committed rocprofv3 --pmc passes of this command "

@@ -29,8 +29,7 @@
 // architectural registers).
 #pragma once
 
-constexpr int LANE_RMAX = 16;
-constexpr int LANE_RSMALL = 12;  // ranks up to here: two workgroups per CU (<= 256 registers without spilling)
+constexpr int LANE_RMAX = 14;
 constexpr int LANE_EMAX = LANE_RMAX * (LANE_RMAX + 1) / 2;  // doubles of X per task in the hand-over buffer
 constexpr int LANE_NW = 4;    // waves per workgroup
 constexpr int LANE_CH = 32;   // entries of H per reduction round: 3 x 32 x 64 doubles = 48 KB of LDS
@@ -577,12 +576,13 @@ inline size_t lane_lds_doubles(int T, bool mean, bool last) {
 }
 
 // KIND 0: factor (+ variance), 1: mean, 2: mean of the last sweep.  One workgroup per (latent, group of 64 units).
-// BIG: ranks LANE_RSMALL + 1 .. LANE_RMAX, one workgroup per CU: 91 .. 136 doubles of H per lane plus the loop's
-// operands do not fit 256 registers (at two workgroups per CU the compiler spilled 53 registers to scratch at rank 14
-// and the rank-14 E-step cost 2.57 ms against 2.06 ms at rank 11); with the whole register file of a SIMD to itself a
-// wave keeps the overflow in the accumulation registers.  The two kinds are separate launches (run_latent).
-template <int KIND, bool BIG>
-__global__ void __launch_bounds__(256, BIG ? 1 : 2) esplit_lane(SplitArgs A) {
+// Two workgroups per CU (313 workgroups at C3 on 256 CUs); rank 14 then spills ~50 registers.  Ranks 15, 16 stay on the
+// wave-per-task kernels.  (Measured alternatives: ranks 13 .. 16 as their own launch compiled for one workgroup per CU,
+// the overflow in the accumulation registers -- the second launch is a second dependent step of every sweep: E-step 2.1 ->
+// 3.4 ms as soon as one latent reaches rank 13, tools/estep_per_step.py; ranks 15, 16 in this kernel: 1.5 KB of scratch
+// per lane, and a memory fault at launch on the second stream.)
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) esplit_lane(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int li = blockIdx.x % A.n_lat, g = blockIdx.x / A.n_lat;
     const int r = A.shg_rk[li];
@@ -598,22 +598,18 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) esplit_lane(SplitArgs A) {
 #ifdef LANE_ONLY  // (debug builds: one instantiation, to read its ISA)
     LANE_CASE(LANE_ONLY);
 #else
-    if constexpr (BIG) {
-        if (r <= 13) LANE_CASE(13);
-        else if (r == 14) LANE_CASE(14);
-        else if (r == 15) LANE_CASE(15);
-        else LANE_CASE(16);
+    if (r <= 8) {
+        if (r <= 4) LANE_CASE(4);
+        else if (r <= 6) LANE_CASE(6);
+        else LANE_CASE(8);
+    } else if (r <= 12) {
+        if (r == 9) LANE_CASE(9);
+        else if (r == 10) LANE_CASE(10);
+        else if (r == 11) LANE_CASE(11);
+        else LANE_CASE(12);
     } else {
-        if (r <= 8) {
-            if (r <= 4) LANE_CASE(4);
-            else if (r <= 6) LANE_CASE(6);
-            else LANE_CASE(8);
-        } else {
-            if (r == 9) LANE_CASE(9);
-            else if (r == 10) LANE_CASE(10);
-            else if (r == 11) LANE_CASE(11);
-            else LANE_CASE(12);
-        }
+        if (r == 13) LANE_CASE(13);
+        else LANE_CASE(14);
     }
 #endif
 #undef LANE_CASE

@@ -22,6 +22,8 @@
 //                       the whole launch to the slow instantiation.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "estep_args.h"
@@ -1637,9 +1639,7 @@ int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const dim3 grid((unsigned)(groups * A.n_lat)), blk(256);
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
-    const bool big = A.shg_rk[0] > LANE_RSMALL;  // (run_latent launches the two kinds separately)
-    auto fn = big ? (!mean ? esplit_lane<0, true> : (last ? esplit_lane<2, true> : esplit_lane<1, true>))
-                  : (!mean ? esplit_lane<0, false> : (last ? esplit_lane<2, false> : esplit_lane<1, false>));
+    auto fn = !mean ? esplit_lane<0> : (last ? esplit_lane<2> : esplit_lane<1>);
     if (lds > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -1684,17 +1684,17 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         }
         CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
     }
-    for (int kind = 0; kind < 2 && C.n_ln; ++kind) {  // ranks above LANE_RSMALL first (the longer workgroups), then the others
-        A.n_lat = 0;
+    if (C.n_ln) {
+        // ONE launch for all of them, the highest ranks first in the grid (their workgroups live longest)
+        int ord[16];
+        for (int i = 0; i < C.n_ln; ++i) ord[i] = C.ln[i];
+        std::stable_sort(ord, ord + C.n_ln, [&](int x, int y) { return C.single->rl[x] > C.single->rl[y]; });
+        A.n_lat = C.n_ln;
         for (int i = 0; i < C.n_ln; ++i) {
-            const int rk = C.single->rl[C.ln[i]];
-            if ((rk > LANE_RSMALL) != (kind == 0)) continue;
-            A.lat[A.n_lat] = C.ln[i];
-            A.shg_rk[A.n_lat] = rk;
-            A.shg_gl[A.n_lat] = C.single->d_compact + C.single->goff[C.ln[i]];
-            ++A.n_lat;
+            A.lat[i] = ord[i];
+            A.shg_rk[i] = C.single->rl[ord[i]];
+            A.shg_gl[i] = C.single->d_compact + C.single->goff[ord[i]];
         }
-        if (!A.n_lat) continue;
         A.shg = 1;
         A.shg_T = C.single_T;
         static const int prio = getenv("VLGP_LANE_PRIO") ? atoi(getenv("VLGP_LANE_PRIO")) : 0;  // (measured: 3 is 5 % slower)
