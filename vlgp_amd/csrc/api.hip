@@ -558,7 +558,7 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     free_priors(ctx);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(ctx->d_gauss); fr(ctx->d_a); fr(ctx->d_b); fr(ctx->d_noise); fr(ctx->d_da); fr(ctx->d_db);
-    fr(ctx->d_ecols); fr(ctx->d_fail); fr(ctx->d_fail_m); fr(ctx->d_work_m); fr(ctx->d_clk); fr(ctx->d_work);
+    fr(ctx->d_hwlm); fr(ctx->d_ecols); fr(ctx->d_fail); fr(ctx->d_fail_m); fr(ctx->d_work_m); fr(ctx->d_clk); fr(ctx->d_work);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_m_start) (void)hipEventDestroy(ctx->ev_m_start);
     if (ctx->ev_m_done) (void)hipEventDestroy(ctx->ev_m_done);
@@ -1149,6 +1149,7 @@ extern "C" int vlgp_hstep_end(vlgp_ctx* ctx) {
     NEED_CTX(ctx);
     ctx->hmom_bracket = false;
     ctx->hmom_us = nullptr;
+    ctx->hwlm_valid = false;
     return VLGP_OK;
 }
 

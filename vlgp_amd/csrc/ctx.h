@@ -128,6 +128,9 @@ struct vlgp_ctx {
     const UnitSet* hmom_us = nullptr;
     int hmom_T = 0;
     bool hmom_bracket = false;    // inside vlgp_hstep_begin/end: d_hmom stays valid across objective calls
+    double* d_hwlm = nullptr;     // inside the bracket: w of the set latent-major, (L, rows), for the round kernels
+    int64_t hwlm_len = 0;
+    bool hwlm_valid = false;
     // low-rank H-step round (hstep_lr.h): per (window, dt, tol) the largest omega whose folded kernel blocks have rank <= r
     struct LrThr { int T; double dt, tol; std::vector<double> om; };
     std::vector<LrThr> lr_thr;

@@ -585,6 +585,8 @@ struct HFastArgs {
     const int64_t* off;
     const double* mu;
     const double* w;
+    const double* wlm;   // w latent-major, (L, wld), or null: inside a vlgp_hstep_begin bracket the round kernels read a
+    int64_t wld;         // segment's 50 weights as 400 contiguous bytes instead of 8 of every 8 L (2.8x over-fetch, PMC)
     int latent[16];      // by value: no host->device copies on the round's critical path
     double logp[48];
     double* kinv;   // (n_eval, T, T)
@@ -830,6 +832,14 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
     }
 }
 
+// (rows, L) -> (L, rows) copy of w for the rounds of one vlgp_hstep_begin bracket
+__global__ void __launch_bounds__(256) hstep_w_latent_major(int L, int64_t rows, const double* __restrict__ w, double* __restrict__ wlm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // latent-major index
+    if (i >= rows * L) return;
+    const int64_t l = i / rows, row = i - l * rows;
+    wlm[i] = w[row * L + l];
+}
+
 // The round on the matrix pipe (hstep_mfma.h): one wave per segment, NW waves per block.  Blocks [0, n_eval) are
 // the K blocks (all NW waves share the trace phase).
 // ONESET (T = 50 only): the one-register-set task routine hstep_task_mfma50 (buffer row = lane); else the two-set routine.
@@ -861,7 +871,8 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
             const int64_t r0row = A.off[seg];
             const double sigmasq = exp(A.logp[3 * e + 0]), omega = exp(A.logp[3 * e + 1]), eps = exp(A.logp[3 * e + 2]);
             if constexpr (ONESET) {
-                const double w = lane < A.Tr ? A.w[(r0row + lane) * A.L + l] : 0.0;  // rows >= Tr: identity padding
+                const double w = lane < A.Tr ? (A.wlm ? A.wlm[(int64_t)l * A.wld + r0row + lane] : A.w[(r0row + lane) * A.L + l])
+                                             : 0.0;  // rows >= Tr: identity padding
                 const double d = lane * A.dt, d2 = d * d;
                 const double kk = sigmasq * exp(-omega * d2);
                 if (lane < HmGeom50::SVN) buf[HmGeom50::O_SV + lane] = sqrt(w);
@@ -869,7 +880,8 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
                 if (lane >= 1 && lane <= 17) kvs[17 - lane] = kk;
                 if (lane < HmGeom50::DKN) dks[lane] = -kk * d2 * omega;
             } else {
-                const double w = lane < A.Tr ? A.w[(r0row + lane) * A.L + l] : 0.0;  // rows >= Tr: identity padding
+                const double w = lane < A.Tr ? (A.wlm ? A.wlm[(int64_t)l * A.wld + r0row + lane] : A.w[(r0row + lane) * A.L + l])
+                                             : 0.0;  // rows >= Tr: identity padding
                 const double d = lane * A.dt, d2 = d * d;
                 const double kk = sigmasq * exp(-omega * d2);
                 buf[G::O_SV + lane] = sqrt(w);
@@ -931,8 +943,10 @@ __global__ void __launch_bounds__(64 * NW, RC <= 24 ? 4 : 3) hstep_round_lr(HRou
         out_slot = (int64_t)e * R.nb + bx;
         double tr = 0.0, cs = 0.0;
         const double eps = exp(A.logp[3 * e + 2]);
+        // (w indexed as w[row * L + l]: the latent-major copy enters as its latent's column with L = 1, l = 0)
         lr_group<RC, NK, NW, TABG>(R.lr.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP, R.lr.meta[e], R.lr.pairs + (int64_t)e * LR_NPAIR,
-                             A.w, A.off, A.L, A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs,
+                             A.wlm ? A.wlm + (int64_t)A.latent[e] * A.wld : A.w, A.off, A.wlm ? 1 : A.L,
+                             A.wlm ? 0 : A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs,
                              b == 0 ? R.clk : nullptr);
         if (lane == 0) {
             part[wid][0] = wid == 0 ? tr : 0.0;
@@ -1082,6 +1096,24 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         for (int i = 0; i < n_eval; ++i) F.latent[i] = latent[i];
         for (int i = 0; i < 3 * n_eval; ++i) F.logp[i] = logp[i];
         F.kinv = W + o_kinv; F.kcol = W + o_q; F.scal = W + o_scal; F.out = W + o_out;
+        F.wlm = nullptr; F.wld = 0;
+        static const bool no_wlm = getenv("VLGP_HSTEP_NO_WLM") != nullptr;
+        if (ctx->hmom_bracket && !no_wlm) {  // mu, w are fixed inside the bracket: one transposed copy of w serves every round
+            if (!ctx->hwlm_valid || ctx->hmom_us != &us) {
+                const int64_t n = us.rows * L;
+                if (ctx->hwlm_len < n) {
+                    if (ctx->d_hwlm) HIPCHK(ctx, hipFree(ctx->d_hwlm));
+                    ctx->d_hwlm = nullptr; ctx->hwlm_len = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->d_hwlm, sizeof(double) * (size_t)n));
+                    ctx->hwlm_len = n;
+                }
+                hipLaunchKernelGGL(hstep_w_latent_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L,
+                                   us.rows, us.w, ctx->d_hwlm);
+                HIPCHK(ctx, hipGetLastError());
+                ctx->hwlm_valid = true;
+            }
+            F.wlm = ctx->d_hwlm; F.wld = us.rows;
+        }
         double* hres = hp + 4 * n_eval + 8;
         {
             if (!ctx->d_hsync) {
