@@ -389,7 +389,7 @@ def main():
             kernels["esplit_latent<factor>"] = entry(
                 n_f, ms_f, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_f / n_f,
                 flops_per_launch_executed=fl, sampled="one launch per E-step call",
-                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_lane<0, false*",
+                per_step_ms=ms_f / n_f * (sweeps + 1), pmc_key="esplit_lane<0*",
                 note="factor + variance launches of one lane (half of the units): esplit_lane<0, *> (one LANE per (unit, "
                      "latent), ranks <= 16: a few hundred long workgroups, bound by one workgroup's latency) plus the "
                      "wave-per-task esplit_latent<*, false> launch of the latents above rank 16; the event pair also "
@@ -400,7 +400,7 @@ def main():
             kernels["esplit_latent<mean>"] = entry(
                 n_u, ms_u, fl, "TFLOP/s", "fp64", FP64_PEAK_TFLOPS, units_per_launch=u_u / n_u,
                 flops_per_launch_executed=fl, sampled="one launch per E-step call",
-                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_lane<1, false*")
+                per_step_ms=ms_u / n_u * sweeps, pmc_key="esplit_lane<1*")
     n_m, ms_m, u_m = prof["mstep"]
     if n_m:
         fl = work["mstep_flops_per_row"] * u_m / n_m

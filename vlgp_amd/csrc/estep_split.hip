@@ -84,14 +84,15 @@ __global__ void __launch_bounds__(256)
 esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double* b, const double* noise, const int* gauss,
                    double* cols, double* wconst, double* ycoef) {
     __shared__ int order[1024];
-    __shared__ int s_np;
+    __shared__ int gs[1024];
+    for (int n = threadIdx.x; n < N; n += 256) gs[n] = gauss[n];  // (one trip to memory: thread 0's loop below used to make N)
+    __syncthreads();
     if (threadIdx.x == 0) {
         int k = 0;
         for (int n = 0; n < N; ++n)
-            if (!gauss[n]) order[k++] = n;
-        s_np = k;
+            if (!gs[n]) order[k++] = n;
         for (int n = 0; n < N; ++n)
-            if (gauss[n]) order[k++] = n;
+            if (gs[n]) order[k++] = n;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < N; i += 256) {
@@ -112,7 +113,7 @@ esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double*
     if ((int)threadIdx.x < L) {  // w = U (a')^2 with U = 1/noise on Gaussian channels (core.py:103-104)
         double s = 0.0;
         for (int n = 0; n < N; ++n)
-            if (gauss[n]) s = fma(a[threadIdx.x * N + n] * a[threadIdx.x * N + n], 1.0 / noise[n], s);
+            if (gs[n]) s = fma(a[threadIdx.x * N + n] * a[threadIdx.x * N + n], 1.0 / noise[n], s);
         wconst[threadIdx.x] = s;
     }
 }
@@ -358,7 +359,7 @@ esplit_pass(SplitArgs A, const double* __restrict__ cols) {
                     if constexpr (KIND == SP_YA) A.ya[(int64_t)l * A.ld + row] = acc[q][l];
                     else if constexpr (KIND == SP_RES) {
                         const double rav = yav[q][l] - acc[q][l];
-                        A.ra[(int64_t)l * A.ld + row] = rav;
+                        if (A.ra) A.ra[(int64_t)l * A.ld + row] = rav;
                         if (A.sv) A.sv[(int64_t)l * A.ld + row] = fma(wv[q][l], mr[q][l], rav);
                     } else {
                         A.w[(int64_t)l * A.ld + row] = fma(2.0, acc[q][l], A.wconst[l]);  // (the records hold a^2 / 2)
@@ -1926,7 +1927,13 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
             if (it >= 0) {
                 if (with_mean) {
                     if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_PASS, hf.st);
+                    // ra itself is read by the wave-per-task mean launches and by the last sweep's dmu form only: with
+                    // every latent on the lane-per-task launch the pass writes s = ra + w mu alone (4 MB less per lane
+                    // and sweep at C3)
+                    double* const ra_keep = hf.pass.ra;
+                    if (C.n_ln && !C.n_lo && !C.n_hi && !last) hf.pass.ra = nullptr;
                     rc = run_pass(ctx, hf.pass, LT, SP_RES, cols);
+                    hf.pass.ra = ra_keep;
                     if (sample) vlgp_prof_end(ctx, VLGP_PROF_ESTEP_PASS, share, hf.st);
                     hf.lat.last = last ? 1 : 0;
                     if (sample) vlgp_prof_begin(ctx, VLGP_PROF_ESTEP_MEAN, hf.st);
