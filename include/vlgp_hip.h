@@ -284,6 +284,7 @@ int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
 #define VLGP_PATH_HSTEP_BIG 3      /* windows 65 ... 128: one workgroup per segment */
 #define VLGP_PATH_HSTEP_GENERIC 4  /* generic kernels (any window; the reference's omega retry) */
 #define VLGP_PATH_HSTEP_OLD 5      /* round-1 kernels behind their debug switches */
+#define VLGP_PATH_HSTEP_MIXED 6    /* one round, two launches: low-rank kernel up to rank 32, dense kernel for the rougher evaluations */
 int vlgp_debug_last_hstep_path(vlgp_ctx* ctx, int* path);
 /* The H-step's debug switches (environment VLGP_HSTEP_DENSE / _GENERIC / _LOWRANK / _GENERIC_SEG / _LR_TOL,
  * VLGP_DEBUG_OCC) are read when the handle is created; this reads them again (tests that switch kernels on a live

@@ -508,12 +508,25 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
         generic = eng.hstep_objective(0, T, 1.0, lat, logp)
         monkeypatch.delenv("VLGP_HSTEP_GENERIC")
         eng.reload_switches()
-        # an evaluation above the rank the low-rank round takes sends the whole round to the dense kernel
+        # an evaluation above the rank the low-rank round takes goes to the dense kernel ALONE (a mixed round: two launches,
+        # one ticket counter, one mailbox); the others keep the low-rank kernel and its bits
         rough = logp.copy()
         rough[2, 1] = np.log(4e-2)
         mixed = eng.hstep_objective(0, T, 1.0, lat, rough)
-        assert eng.last_hstep_path == "dense"
-        assert np.array_equal(mixed[0][[0, 1, 3, 4]], dense[0][[0, 1, 3, 4]])
+        assert eng.last_hstep_path == "mixed"
+        assert np.array_equal(mixed[0][[0, 1, 3, 4]], low[0][[0, 1, 3, 4]])
+        assert np.array_equal(mixed[1][[0, 1, 3, 4]], low[1][[0, 1, 3, 4]])
+        st = eng.hstep_stats()
+        monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
+        eng.reload_switches()
+        rough_dense = eng.hstep_objective(0, T, 1.0, lat, rough)
+        monkeypatch.delenv("VLGP_HSTEP_DENSE")
+        eng.reload_switches()
+        assert np.array_equal(mixed[0][2], rough_dense[0][2]) and np.array_equal(mixed[1][2], rough_dense[1][2])
+        again_mixed = eng.hstep_objective(0, T, 1.0, lat, rough)
+        st2 = eng.hstep_stats()
+        assert np.array_equal(again_mixed[0], mixed[0])
+        assert st2[0] - st[0] == 4 and st2[2] - st[2] == 5 + 1  # (the all-dense call: 5; the mixed one: 1 dense, 4 low-rank)
     for other in (dense, generic):
         assert relerr(other[0], low[0]) < 1e-10
         assert relerr(other[1][:, 1], low[1][:, 1]) < 1e-9
@@ -530,15 +543,17 @@ def test_hstep_round_kernels_agree_at_scale(V, monkeypatch):
 @pytest.mark.parametrize("dt", [0.5, 2.0, 0.02])
 def test_hstep_objective_other_bin_widths_vs_oracle(V, dt, monkeypatch):
     """params["dt"] != 1 (vlgp/gp.py:113: the kernel matrix is built on t = arange(T) * dt): the low-rank round's tables and
-    the host's rank thresholds take the bin width; omega scaled so that omega dt^2 spans the usual range, plus one rough
-    evaluation that sends the round to the dense kernel.  (ll, dll) against gp.obj_func's restatement on every path."""
+    the host's rank thresholds take the bin width; omega scaled so that omega dt^2 spans the usual range, plus a round with
+    one rough evaluation (mixed: that one on the dense kernel, the other on the low-rank one) and a round of two rough
+    ones (dense).  (ll, dll) against gp.obj_func's restatement on every path."""
     rng = np.random.default_rng(int(dt * 100))
     M, T, L = 40, 50, 2
     units = [{"y": np.zeros((T, 2)), "mu": rng.standard_normal((T, L)), "w": 2.0 * rng.random((T, L)),
               "v": np.zeros((T, L))} for _ in range(M)]
     t = np.arange(T) * dt
     cases = [("lowrank", np.log(np.array([[1.0, 3e-3 / dt ** 2, 1e-4], [0.6, 1.2e-2 / dt ** 2, 1e-4]]))),
-             ("dense", np.log(np.array([[1.0, 3e-3 / dt ** 2, 1e-4], [0.6, 6e-2 / dt ** 2, 1e-4]])))]
+             ("mixed", np.log(np.array([[1.0, 3e-3 / dt ** 2, 1e-4], [0.6, 6e-2 / dt ** 2, 1e-4]]))),
+             ("dense", np.log(np.array([[1.0, 5e-2 / dt ** 2, 1e-4], [0.6, 6e-2 / dt ** 2, 1e-4]])))]
     monkeypatch.setenv("VLGP_HSTEP_LOWRANK", "1")
     with V.Engine(2, L, 1, 50) as eng:
         eng.upload(0, units)

@@ -673,6 +673,12 @@ struct HRoundArgs {
     int k_blocks;           // this launch starts with the n_eval K blocks (the first launch of a round), else 0
     int lr_nev;             // evaluations this launch takes the segments of ...
     int lr_ev[16];          // ... and which
+    // a MIXED round is two launches, the low-rank kernel for the evaluations within rank LR_RCAP and the dense kernel for
+    // the rest: their segment blocks differ in size (16 / 4 segments), so the partial sums of evaluation e sit at
+    // out + 2 (e slot_stride + block) and there are nbe[e] of them; lr_mask: the evaluations that went through the tables
+    int slot_stride;
+    int nbe[16];
+    unsigned lr_mask;
     unsigned long long* clk;  // debug: per-phase cycle counters of the first segment block (vlgp_debug_phase_clock), or null
 };
 
@@ -788,10 +794,10 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     constexpr int NT = 64 * NW;
     for (int e = 0; e < R.n_eval; ++e) {
-        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.nb;
+        const double2* in = reinterpret_cast<const double2*>(A.out) + (int64_t)e * R.slot_stride;
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
-        for (int m = threadIdx.x; m < R.nb; m += NT) {
+        for (int m = threadIdx.x; m < R.nbe[e]; m += NT) {
             const double2 v = in[m];
             s0 += v.x;
             s1 += v.y;
@@ -809,7 +815,7 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
         }
         if (threadIdx.x == 0) {
             double okf = A.scal[4 * e + 3];
-            if (R.lr.tab != nullptr && R.lr.meta[e].overflow) okf = okf != 0.0 ? 2.0 : 0.0;
+            if (R.lr.tab != nullptr && ((R.lr_mask >> e) & 1u) && R.lr.meta[e].overflow) okf = okf != 0.0 ? 2.0 : 0.0;
             const double ll = -0.5 * R.qsum[2 * e + 0] - 0.5 * rs[0] - (double)A.M * A.scal[4 * e + 0];
             const double dll = 0.5 * (R.qsum[2 * e + 1] - rs[NT]);
             R.red[2 * e + 0] = ll;
@@ -856,11 +862,14 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
     __shared__ int s_last;
     const HFastArgs& A = R.F;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if ((int)blockIdx.x < R.n_eval) {
+    int64_t out_slot = -1;
+    if ((int)blockIdx.x < R.k_blocks) {
         hstep_round_kblock<T, NW, ONESET>(R, blockIdx.x, lds, lds + LDSN - SHR, part, lane, wid);
     } else {
-        const int b = blockIdx.x - R.n_eval;
-        const int e = b / R.nb, bx = b - e * R.nb;
+        const int b = blockIdx.x - R.k_blocks;
+        const int ei = b / R.nb, bx = b - ei * R.nb;
+        const int e = R.lr_ev[ei];  // (all of them in order, or the evaluations a mixed round leaves to this kernel)
+        out_slot = (int64_t)e * R.slot_stride + bx;
         const int seg = bx * NW + wid;
         double tr = 0.0, cs = 0.0;
         if (seg < A.M) {
@@ -906,14 +915,14 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
             part[wid][1] = cs;
         }
     }
-    hstep_round_finish<NW>(R, lds, part, &s_last, (int)blockIdx.x >= R.n_eval ? (int64_t)blockIdx.x - R.n_eval : -1);
+    hstep_round_finish<NW>(R, lds, part, &s_last, out_slot);
 }
 
 // Tables of the evaluations of a low-rank round: one block per evaluation (hstep_lr.h, lr_tables_block).
 __global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
     __shared__ double kv[64], dkv[64];
     __shared__ int s_i[4];
-    const int e = blockIdx.x;
+    const int e = R.lr_ev[blockIdx.x];  // (the evaluations of the round that take the low-rank kernel)
     lr_tables_block<128>(R.lr, e, exp(R.F.logp[3 * e + 0]), exp(R.F.logp[3 * e + 1]), kv, dkv, s_i);
 }
 
@@ -940,7 +949,7 @@ __global__ void __launch_bounds__(64 * NW, RC <= 24 ? 4 : 3) hstep_round_lr(HRou
         const int b = blockIdx.x - R.k_blocks;
         const int ei = b / R.nb, bx = b - ei * R.nb;
         const int e = R.lr_ev[ei];
-        out_slot = (int64_t)e * R.nb + bx;
+        out_slot = (int64_t)e * R.slot_stride + bx;
         double tr = 0.0, cs = 0.0;
         const double eps = exp(A.logp[3 * e + 2]);
         // (w indexed as w[row * L + l]: the latent-major copy enters as its latent's column with L = 1, l = 0)
@@ -1024,6 +1033,7 @@ static const std::vector<double>& lr_thresholds(vlgp_ctx* ctx, int T, double dt,
 }
 
 constexpr int LR_NW = 4;  // waves per workgroup of the low-rank round (sixteen segments)
+static inline int n_lr_or_all(bool lr, int n_lr, int n_eval) { return lr ? n_lr : n_eval; }
 
 template <int T, int RC, bool TABG = false>
 static int launch_round_lr(vlgp_ctx* ctx, const HRoundArgs& R, int grid, size_t lds_bytes) {
@@ -1156,17 +1166,26 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             const double lr_tol = sw.lr_tol;
             bool lr = !lr_off && !force_dense;
             int rcap[16], rmax = 0;
+            // evaluations whose kernel matrix has a numerical rank above LR_RCAP (omega above ~2e-2 at window 50: a fit's first
+            // iterations) take the dense kernel; the others of the same round keep the low-rank one (a MIXED round: two
+            // launches on the stream, one ticket counter, one mailbox -- round 5; until then one rough latent sent its whole
+            // round to the dense kernel)
+            unsigned rough = 0;
+            int n_lr = 0;
             if (lr) {
                 const std::vector<double>& om = lr_thresholds(ctx, T, dt, 0.5 * lr_tol);
-                for (int e = 0; e < n_eval && lr; ++e) {
+                for (int e = 0; e < n_eval; ++e) {
                     const double omega = exp(logp[3 * e + 1]);
                     int r = 0;
                     while (r <= LR_RCAP && !(omega <= om[r])) ++r;
-                    if (r > LR_RCAP) lr = false;
+                    if (r > LR_RCAP) { rough |= 1u << e; rcap[e] = 0; continue; }
                     rcap[e] = r < 4 ? 4 : r;
                     if (rcap[e] > rmax) rmax = rcap[e];
+                    ++n_lr;
                 }
+                if (n_lr == 0) lr = false;
             }
+            const int n_rough = lr ? n_eval - n_lr : 0;
             if (lr && !sw.lowrank) {
                 // Which round is faster depends on how much there is to do (measured on MI355X, tools/lr_round_bench.py,
                 // us per round over n = n_eval x M segment-evaluations, 4000 of them = one "generation"):
@@ -1183,17 +1202,28 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // would also be alone in its overflow fallback and its extra collectives, ADVICE round 4 -- so it looks
                 // at the mean shard, a rank-invariant number once the row totals have been exchanged)
                 const double m_rule = (ctx->world > 1 && us.rows_all_ranks > 0.0) ? us.rows_all_ranks / ((double)T * ctx->world) : (double)M;
-                const double gens = (double)n_eval * m_rule / 4000.0;
+                const double gens = (double)n_lr * m_rule / 4000.0;  // (the low-rank part of a mixed round)
                 const double extra = gens > 1.0 ? gens - 1.0 : 0.0;
                 const double t_dense = 41.0 + 28.0 * extra, t_lr = 13.0 + base[ci] + marg[ci] * extra;
                 if (T >= 24 && t_lr > 0.95 * t_dense) lr = false;
             }
-            R.n_eval = n_eval; R.nb = lr ? (M + 15) / 16 : (M + MFMA_NW - 1) / MFMA_NW;
+            const bool mixed = lr && n_rough > 0;
+            const int nb_lr = (M + 15) / 16, nb_dense = (M + MFMA_NW - 1) / MFMA_NW;
+            R.n_eval = n_eval; R.nb = lr ? nb_lr : nb_dense;
+            R.slot_stride = mixed ? nb_dense : R.nb;
+            R.lr_mask = 0;
+            for (int e = 0; e < n_eval; ++e) {
+                const bool e_lr = lr && !((rough >> e) & 1u);
+                R.nbe[e] = e_lr ? nb_lr : nb_dense;
+                if (e_lr) R.lr_mask |= 1u << e;
+                R.lr_ev[e] = e;
+            }
             R.seq = ++ctx->h_seq; R.sync = ctx->d_hsync;
             R.mom = ctx->d_hmom; R.qsum = W + o_qsum;
             R.red = W + o_red;
             R.lr.tab = nullptr; R.lr.meta = nullptr; R.lr.pairs = nullptr;
-            R.total_blocks = (unsigned)(n_eval + n_eval * R.nb); R.k_blocks = n_eval; R.lr_nev = 0; R.clk = ctx->d_clk;
+            R.total_blocks = (unsigned)(n_eval + n_lr_or_all(lr, n_lr, n_eval) * (lr ? nb_lr : nb_dense) + (mixed ? n_rough * nb_dense : 0));
+            R.k_blocks = n_eval; R.lr_nev = n_eval; R.clk = ctx->d_clk;
             if (lr) {
                 R.lr.T = T; R.lr.dt = dt; R.lr.tol = lr_tol;
                 for (int e = 0; e < n_eval; ++e) R.lr.rcap[e] = rcap[e];
@@ -1203,16 +1233,23 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // (Measured: the tables built by blocks of the round kernel itself, the segment blocks waiting on a flag,
                 // is SLOWER than this extra launch -- 57 against 26 + 12 us for one evaluation: the waiting blocks fill
                 // the chip before the table blocks finish.)
-                vlgp_prof_begin(ctx, VLGP_PROF_HSTEP_TAB);
-                hipLaunchKernelGGL(hstep_lr_tables, dim3(n_eval), dim3(128), 0, ctx->stream, R);
-                vlgp_prof_end(ctx, VLGP_PROF_HSTEP_TAB, (double)n_eval);
+                {
+                    HRoundArgs Rt = R;
+                    int k = 0;
+                    for (int e = 0; e < n_eval; ++e)
+                        if ((R.lr_mask >> e) & 1u) Rt.lr_ev[k++] = e;
+                    vlgp_prof_begin(ctx, VLGP_PROF_HSTEP_TAB);
+                    hipLaunchKernelGGL(hstep_lr_tables, dim3(n_lr), dim3(128), 0, ctx->stream, Rt);
+                    vlgp_prof_end(ctx, VLGP_PROF_HSTEP_TAB, (double)n_lr);
+                }
                 HIPCHK(ctx, hipGetLastError());
-                ctx->hstat[0] += n_eval;
+                ctx->hstat[0] += n_lr;
                 for (int e = 0; e < n_eval; ++e) ctx->hstat[1] += rcap[e];
+                ctx->hstat[2] += n_rough;
             } else if (mfma) {
                 ctx->hstat[2] += n_eval;
             }
-            ctx->last_hstep_path = lr ? VLGP_PATH_HSTEP_LOWRANK : VLGP_PATH_HSTEP_DENSE;
+            ctx->last_hstep_path = lr ? (mixed ? VLGP_PATH_HSTEP_MIXED : VLGP_PATH_HSTEP_LOWRANK) : VLGP_PATH_HSTEP_DENSE;
             // single rank: the kernel publishes to the host mailbox.  Several ranks: same, then the ranks add
             // their sums on the host (vlgp_hx_allreduce); without the exchange segment the sums go through the
             // device all-reduce and a copy instead
@@ -1235,7 +1272,8 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     HRoundArgs Rc = R;
                     Rc.lr_nev = 0;
                     int rm = rmax;
-                    for (int e = 0; e < n_eval; ++e) Rc.lr_ev[Rc.lr_nev++] = e;
+                    for (int e = 0; e < n_eval; ++e)
+                        if ((R.lr_mask >> e) & 1u) Rc.lr_ev[Rc.lr_nev++] = e;
                     // longest first: the workgroups of the highest ranks are dispatched before the cheap ones (shorter tail)
                     std::stable_sort(Rc.lr_ev, Rc.lr_ev + Rc.lr_nev, [&](int x, int y) { return rcap[x] > rcap[y]; });
                     if (Rc.lr_nev == 0) continue;
@@ -1271,6 +1309,20 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                         else CHK((launch_round_lr<64, 32>(ctx, Rc, grid, lds_bytes)));
                     }
                     first = false;
+                }
+                if (mixed) {  // the rough evaluations: the dense kernel behind it on the stream (no K blocks: the first launch had them)
+                    HRoundArgs Rd = R;
+                    Rd.nb = nb_dense;
+                    Rd.k_blocks = 0;
+                    Rd.lr_nev = 0;
+                    for (int e = 0; e < n_eval; ++e)
+                        if ((rough >> e) & 1u) Rd.lr_ev[Rd.lr_nev++] = e;
+                    if (TC == 50)
+                        hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW, true>), dim3(Rd.lr_nev * nb_dense), dim3(64 * MFMA_NW), 0,
+                                           ctx->stream, Rd);
+                    else
+                        hipLaunchKernelGGL((hstep_round_mfma<64, MFMA_NW>), dim3(Rd.lr_nev * nb_dense), dim3(64 * MFMA_NW), 0,
+                                           ctx->stream, Rd);
                 }
             } else if (TC == 50)
                 hipLaunchKernelGGL((hstep_round_mfma<50, MFMA_NW, true>), dim3(n_eval + n_eval * R.nb), dim3(64 * MFMA_NW), 0,
