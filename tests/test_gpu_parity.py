@@ -28,21 +28,15 @@ def V():
     return vlgp_amd
 
 
-@pytest.fixture(params=["default", "split", "split_fused"])
+@pytest.fixture(params=["default", "split"])
 def estep_path(request, monkeypatch):
-    """The dispatch paths of the short-unit E-step, every run: the size-based default (persistent kernels on
+    """Both dispatch paths of the short-unit E-step, every run: the size-based default (persistent kernels on
     fixture-sized sets) and the split E-step (estep_split.hip: the chip-wide launch sequence that takes over at
-    more than 512 units -- the kernels the headline number is made of) forced onto the same inputs, with the regular
-    sweeps fused into one launch where that applies (estep_fused.h: every rank <= 14, L <= 5, x = 1 -- the default)
-    and as the launch sequence throughout (VLGP_ESTEP_FUSED=0).
-    VLGP_ESTEP_SPLIT / VLGP_ESTEP_FUSED are read per call by launch_estep_split."""
-    if request.param.startswith("split"):
+    more than 512 units -- the kernels the headline number is made of) forced onto the same inputs.
+    VLGP_ESTEP_SPLIT is read per call by launch_estep_split."""
+    if request.param == "split":
         monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
         monkeypatch.setenv("VLGP_ESTEP_LSPLIT", "1")   # long units: one workgroup per (unit, latent) task
-        if request.param == "split_fused":
-            monkeypatch.setenv("VLGP_ESTEP_FUSED", "1")
-        else:
-            monkeypatch.delenv("VLGP_ESTEP_FUSED", raising=False)
     else:
         monkeypatch.delenv("VLGP_ESTEP_SPLIT", raising=False)
         monkeypatch.delenv("VLGP_ESTEP_LSPLIT", raising=False)
@@ -55,12 +49,10 @@ def _ran(V, path, *calls):
 
     for c in calls:
         got = E.TRACE.get(c)
-        if path == "split_fused":
-            assert got in ("split", "long_split", "fused"), (c, got)
-        elif path == "split":
+        if path == "split":
             assert got in ("split", "long_split"), (c, got)
         else:
-            assert got in ("fast", "generic", "long", "split", "long_split", "fused"), (c, got)
+            assert got in ("fast", "generic", "long", "split", "long_split"), (c, got)
 
 
 def _params(g, L, N, P=1, rank=50, chol=None):
@@ -207,7 +199,7 @@ def test_estep_long_unit_golden(V, golden, estep_path):
     params = _params(g, 3, 20, chol={300: g["G"]})
     V.estep(units, params, V.get_config(Eniter=5))
     from vlgp_amd import engine as E
-    assert E.TRACE["estep"] == ("long_split" if estep_path.startswith("split") else "long")
+    assert E.TRACE["estep"] == ("long_split" if estep_path == "split" else "long")
     for k in ("mu", "v", "w", "dmu"):
         assert relerr(units[0][k], g[k + "_VB_5"][0]) < STAGE, k
 
@@ -794,7 +786,7 @@ def test_headline_size_properties(V, monkeypatch):
             eng.update_v(0)
             for n in splits:
                 eng.estep(0, n)
-                assert eng.last_estep_path in ("split", "fused")  # 4000 units / 200 k rows: the split E-step by size
+                assert eng.last_estep_path == "split"  # 4000 units / 200 k rows: the split E-step by size
             out = eng.download(0)
             G = eng.get_prior(50)
         return out, G
@@ -871,11 +863,11 @@ def test_split_estep_at_dispatch_size_vs_oracle(V, case):
         eng.build_prior([T], omega, sigma)
         G = eng.get_prior(T)
         eng.update_w(0)
-        assert eng.last_estep_path in ("split", "fused")
+        assert eng.last_estep_path == "split"
         eng.update_v(0, case["vb"])
         st0 = eng.download(0, keys=("v", "w"))
         eng.estep(0, case["n_it"], vb=case["vb"])
-        assert eng.last_estep_path in ("split", "fused")
+        assert eng.last_estep_path == "split"
         got = eng.download(0)
     for l in range(L):
         assert np.array_equal(G[l], O.ichol_gauss(T, omega[l], 50) * sigma[l])

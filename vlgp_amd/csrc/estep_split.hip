@@ -1080,7 +1080,6 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
 }
 
 #include "estep_lane.h"
-#include "estep_fused.h"
 
 // MAXRA: largest register-array size compiled in (16: every latent of the launch has rank <= 16)
 // LASTSW (mean only): the last sweep of the call
@@ -1911,58 +1910,11 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     }
     // (measured: three or four lanes are SLOWER than one -- E-step 5.7 ms against 3.5 / 3.0 for one / two at C3 -- and
     // starting the second lane one or two launches late changes nothing)
-    // FUSED SWEEPS (estep_fused.h): every latent on the lane-per-task class, L <= 5, x = 1: one workgroup per group of
-    // units runs the first factor and all regular sweeps with the units' state on chip; the LAST sweep (it also
-    // produces dmu) goes through the launch sequence below.  VLGP_ESTEP_FUSED=1 (experiment, off by default).
-    int it_first = (mode & EM_FACTOR0) ? -1 : 0;
-    {
-        const char* fenv = getenv("VLGP_ESTEP_FUSED");  // (per call: tests toggle it)
-        const bool want = fenv && fenv[0] == '1';  // opt-in: measured slower than the launch sequence (estep_fused.h)
-        if (want && rc == VLGP_OK && use_lane && C.single && C.n_ln == L && !C.n_lo && !C.n_hi && L <= 5 && !A.xb &&
-            with_mean && (mode & EM_FACTOR0) && n_it >= 2) {
-            const int T = C.single_T;
-            int ug_max = 1024 / T < 128 / L ? 1024 / T : 128 / L;
-            auto rs_of = [&](int ug) { return (ug * T + 1) & ~1; };
-            while (ug_max > 1 && fused_lds_doubles(L, T, ug_max, rs_of(ug_max)) * 8 > 150 * 1024) --ug_max;
-            int ug = (us.M + ctx->n_cu - 1) / ctx->n_cu;
-            if (ug < 1) ug = 1;
-            if (ug > ug_max) ug = ug_max;
-            const size_t lds = fused_lds_doubles(L, T, ug, rs_of(ug)) * 8;
-            if (ug_max >= 1 && lds <= 150 * 1024) {
-                FusedArgs F;
-                F.A = A;
-                F.A.n_lat = L;
-                for (int l = 0; l < L; ++l) {
-                    F.A.lat[l] = l;
-                    F.A.shg_rk[l] = C.single->rl[l];
-                    F.A.shg_gl[l] = C.single->d_compact + C.single->goff[l];
-                }
-                F.A.shg = 1;
-                F.A.shg_T = T;
-                F.cols = cols;
-                F.UG = ug;
-                F.RS = rs_of(ug);
-                F.n_sweeps = n_it - 1;
-                F.do_v = E.vb ? 1 : 0;
-                static const int clk_kind = getenv("VLGP_LANE_CLOCK") ? atoi(getenv("VLGP_LANE_CLOCK")) : 0;
-                F.A.clk = ctx->d_clk;
-                F.A.clk_kind = clk_kind;
-                const dim3 grid((unsigned)((us.M + ug - 1) / ug)), blk(FUS_NT);
-                auto fn = LT == 3 ? efused_kernel<3> : efused_kernel<5>;
-                if (lds > 64 * 1024)
-                    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(fn, grid, blk, lds, ctx->stream, F);
-                HIPCHK(ctx, hipGetLastError());
-                it_first = n_it - 1;
-                *handled = 3;
-            }
-        }
-    }
     if (n_lanes > 1 && rc == VLGP_OK) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_e_fork, ctx->stream));
         for (int h = 1; h < n_lanes; ++h) HIPCHK(ctx, hipStreamWaitEvent(ctx->elane[h - 1], ctx->ev_e_fork, 0));
     }
-    for (int it = it_first; it < n_it && rc == VLGP_OK; ++it) {
+    for (int it = (mode & EM_FACTOR0) ? -1 : 0; it < n_it && rc == VLGP_OK; ++it) {
         const bool last = it == n_it - 1;
         for (int h = 0; h < n_lanes && rc == VLGP_OK; ++h) {
             Half& hf = H[h];
