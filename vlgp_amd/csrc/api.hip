@@ -1107,10 +1107,11 @@ extern "C" int vlgp_mstep_end(vlgp_ctx* ctx, int* n_failed, double* device_ms) {
     if (!ctx->m_pending) return vlgp_fail(ctx, VLGP_ERR_STATE, "no M-step in flight");
     CHK(vlgp_join_m(ctx));
     ctx->m_pending = false;
-    if (device_ms) {
+    {
         float ms = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_m_start, ctx->ev_m_done));
-        *device_ms = ms;
+        ctx->last_m_ms = ms;  // (vlgp_hstep_begin weighs it against the H-step bracket's duration)
+        if (device_ms) *device_ms = ms;
     }
     if (n_failed) HIPCHK(ctx, hipMemcpy(n_failed, ctx->d_fail_m, sizeof(int), hipMemcpyDeviceToHost));
     return VLGP_OK;
@@ -1142,11 +1143,16 @@ extern "C" int vlgp_hstep_begin(vlgp_ctx* ctx, int set, int window) {
     (void)window;
     ctx->hmom_bracket = true;
     ctx->hmom_us = nullptr;  // the first objective call inside the bracket builds the moments
+    // the rounds' waves take the high instruction priority unless the M-step lane was the longer one last time
+    ctx->h_prio = (ctx->last_m_ms > 0.0 && ctx->last_h_ms > 0.0 && ctx->last_m_ms > ctx->last_h_ms) ? 0 : 1;
+    ctx->h_t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return VLGP_OK;
 }
 
 extern "C" int vlgp_hstep_end(vlgp_ctx* ctx) {
     NEED_CTX(ctx);
+    if (ctx->hmom_bracket && ctx->h_t0 > 0.0)
+        ctx->last_h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - ctx->h_t0;
     ctx->hmom_bracket = false;
     ctx->hmom_us = nullptr;
     ctx->hwlm_valid = false;

@@ -136,6 +136,11 @@ struct vlgp_ctx {
     std::vector<LrThr> lr_thr;
     HstepSwitches hsw;
     std::vector<const void*> lds_attr_done;  // kernels whose dynamic-LDS ceiling was raised on this handle's device
+    // instruction priority of the round kernels' waves beside the M-step lane: high while the H-step bracket is the longer
+    // of the two (durations of the previous EM iteration; hstep.hip, hstep_wave_prio)
+    int h_prio = 1;
+    double last_h_ms = 0.0, last_m_ms = 0.0;  // 0 = unknown
+    double h_t0 = 0.0;
     int last_hstep_path = 0;      // VLGP_PATH_HSTEP_* of the most recent H-step objective call
     double hstat[4] = {0.0, 0.0, 0.0, 0.0};  // vlgp_debug_hstep_stats
 

@@ -680,6 +680,7 @@ struct HRoundArgs {
     int nbe[16];
     unsigned lr_mask;
     unsigned long long* clk;  // debug: per-phase cycle counters of the first segment block (vlgp_debug_phase_clock), or null
+    int prio;                 // 1: the round's waves run at high instruction priority (hstep_wave_prio)
 };
 
 // K block of a round (shared by the dense and the low-rank round kernels): wave 0 takes K -> K^-1 and log det through
@@ -838,6 +839,16 @@ __device__ __forceinline__ void hstep_round_finish(const HRoundArgs& R, double* 
     }
 }
 
+// The round kernels run beside the M-step lane's launches (ctx.h: mstream), on the same SIMDs.  When the rounds are the
+// critical path of that window (C3: ≈ 40 dependent rounds against 25 independent Newton launches with ≈ 0.6 ms of slack)
+// their waves take the instruction arbiter's highest user priority.  Same box, four runs each: 139.3 EM it/s at
+// priority 0, 140.8 / 140.4 / 141.8 at 1 / 2 / 3 (H-step 4.16 -> 3.97 ms, the M-step lane 3.34 -> 3.63 ms beside it).
+// Where the M-step lane is the longer one (C5: 28.6 against 24.5 ms) the rounds stay at the default: the host decides
+// per bracket from the durations of the previous EM iteration (vlgp_hstep_begin, ctx->h_prio).
+__device__ __forceinline__ void hstep_wave_prio(int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
+}
+
 // (rows, L) -> (L, rows) copy of w for the rounds of one vlgp_hstep_begin bracket
 __global__ void __launch_bounds__(256) hstep_w_latent_major(int L, int64_t rows, const double* __restrict__ w, double* __restrict__ wlm) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // latent-major index
@@ -852,6 +863,7 @@ __global__ void __launch_bounds__(256) hstep_w_latent_major(int L, int64_t rows,
 template <int T, int NW, bool ONESET = false>
 __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3) : 2) : 1) hstep_round_mfma(HRoundArgs R) {
     static_assert(!ONESET || T == 50, "the one-register-set routine is written for 50 = 3 x 16 + 2");
+    hstep_wave_prio(R.prio);
     using G = HmGeom<T>;
     using KG = HRoundK<T, NW, ONESET>;
     constexpr int TASKW = KG::TASKW, SHR = KG::SHR, KBLK = KG::KBLK;
@@ -922,6 +934,7 @@ __global__ void __launch_bounds__(64 * NW, NW >= 4 ? (T <= 50 ? (ONESET ? 4 : 3)
 __global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
     __shared__ double kv[64], dkv[64];
     __shared__ int s_i[4];
+    hstep_wave_prio(R.prio);
     const int e = R.lr_ev[blockIdx.x];  // (the evaluations of the round that take the low-rank kernel)
     lr_tables_block<128>(R.lr, e, exp(R.F.logp[3 * e + 0]), exp(R.F.logp[3 * e + 1]), kv, dkv, s_i);
 }
@@ -934,6 +947,7 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
 // beside a workgroup of the M-step lane.  Same box: 139.0 against 137.7 EM it/s.)
 template <int T, int NW, int RC, bool TABG = false>
 __global__ void __launch_bounds__(64 * NW, RC <= 24 ? 4 : 3) hstep_round_lr(HRoundArgs R) {
+    hstep_wave_prio(R.prio);
     constexpr bool ONESET = T == 50;
     constexpr int NK = T == 50 ? 7 : 8;
     using KG = HRoundK<T, NW, ONESET>;
@@ -1224,6 +1238,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             R.lr.tab = nullptr; R.lr.meta = nullptr; R.lr.pairs = nullptr;
             R.total_blocks = (unsigned)(n_eval + n_lr_or_all(lr, n_lr, n_eval) * (lr ? nb_lr : nb_dense) + (mixed ? n_rough * nb_dense : 0));
             R.k_blocks = n_eval; R.lr_nev = n_eval; R.clk = ctx->d_clk;
+            R.prio = ctx->h_prio;
             if (lr) {
                 R.lr.T = T; R.lr.dt = dt; R.lr.tol = lr_tol;
                 for (int e = 0; e < n_eval; ++e) R.lr.rcap[e] = rcap[e];
