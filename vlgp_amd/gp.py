@@ -182,6 +182,15 @@ def _setulb_or_none():
         return None
 
 
+_warned = set()
+
+
+def _warn_once(msg):
+    if msg not in _warned:
+        _warned.add(msg)
+        logger.warning(msg)
+
+
 def _lockstep_ext():
     """vlgp_amd._lockstep (csrc/lockstep_ext.c), or None when it is not built."""
     try:
@@ -216,6 +225,9 @@ def lockstep_minimize(batch_fn, x0s, log_bounds):
     same batching (identical results either way)."""
     setulb = _setulb_or_none()
     if setulb is None:
+        _warn_once("this SciPy does not expose the L-BFGS-B reverse-communication routine with the signature known here "
+                   "(scipy.optimize._lbfgsb.setulb, SciPy 1.15): the H-step runs one scipy.optimize.minimize per latent "
+                   "in threads (the public API, same iterates, slower)")
         return _lockstep_threads(batch_fn, x0s, log_bounds)
     n_runs = len(x0s)
     X = np.empty((n_runs, np.asarray(x0s[0]).size))  # row k IS run k's iterate (setulb updates it in place)
