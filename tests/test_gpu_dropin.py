@@ -136,3 +136,17 @@ def test_integration_md_stub_runs_as_written(V, golden):
         assert id(u["mu"]) == mu_ids[m]
         for k in ("mu", "v", "w"):
             assert relerr(u[k], g["%s_VB_25" % k][m]) < 1e-9, (k, m)
+
+
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench -- is itself under test (it toggles
+    a VLGP_HSTEP_* switch, and those are read when the handle is created: round 5 broke it once, unnoticed)."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
