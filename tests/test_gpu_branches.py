@@ -424,6 +424,10 @@ def test_ragged_window_other_modes_vs_oracle(V, kw):
     np.random.seed(4)
     np.random.choice(sum(lengths), max(sum(lengths) // 10, 50))  # initialize() draws its subsample first
     O.fit_given_init(ref, params, cfg)
+    # 1e-5 on the parameters: omega is where L-BFGS-B's own stopping rule (ftol 2.2e-9 on an objective that is flat to
+    # second order at the optimum) leaves it, and a, b, noise follow it through the next E-step; 1e-4 on the final
+    # full-length posterior: its prior factor is ichol_gauss of that omega, whose pivot order on rank-exhausted trials is
+    # discontinuous in omega.  The reference-captured trajectories hold 1e-6 (test_branches_against_reference_golden).
     for k in ("a", "b", "noise", "omega"):
         assert relerr(got["params"][k], params[k]) < 1e-5, k
     for tg, tr in zip(got["trials"], ref):

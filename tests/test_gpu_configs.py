@@ -226,6 +226,8 @@ def test_c5_full_channel_count_ragged_trials_vs_oracle(V, split, monkeypatch):
     O.fit_given_init(ref, params, cfg)
 
     gp_ = got["params"]
+    # (1e-5: the fit against the ORACLE's fit -- two L-BFGS-B runs on objectives that differ in the last bits stop within
+    # ftol = 2.2e-9 of the same flat optimum, i.e. ~1e-6 apart in omega; the real reference's trajectory holds 1e-6)
     for k in ("omega", "a", "b", "noise"):
         assert relerr(gp_[k], params[k]) < 1e-5, k
     for T, Gg in gp_["cholesky"].items():

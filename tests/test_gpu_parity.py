@@ -957,7 +957,8 @@ def test_c5_like_ragged_mixed_ten_latents(V, estep_path):
     params = O.make_params(ref_trials, L, a=a0.copy(), b=b0.copy(), lik=lik)
     O.fit_given_init(ref_trials, params, cfg)
 
-    # (1) the EM phase, through what it leaves in the parameters
+    # (1) the EM phase, through what it leaves in the parameters (1e-5: a fit against the ORACLE's fit -- both optimisers
+    # stop within L-BFGS-B's ftol of the same flat optimum, ~1e-6 apart in omega, and a, b, noise follow)
     gp_ = got["params"]
     assert relerr(gp_["omega"], params["omega"]) < 1e-5
     assert relerr(gp_["a"], params["a"]) < 1e-5
@@ -989,7 +990,7 @@ def test_c5_like_ragged_mixed_ten_latents(V, estep_path):
             if np.array_equal(gp_["cholesky"][t["y"].shape[0]], params["cholesky"][t["y"].shape[0]])]
     for tg, tr in zip(got["trials"], ref_trials):
         if tr["y"].shape[0] in same:
-            assert relerr(tg["mu"], tr["mu"]) < 1e-4
+            assert relerr(tg["mu"], tr["mu"]) < 1e-4  # (the final inference runs at the two fits' own a, b: 1e-5 apart)
 
 
 # ------------------------------------------------------------------ other windows / likelihoods through fit
@@ -1023,6 +1024,7 @@ def test_fit_other_windows_and_all_gaussian(V, window, lik_gauss):
     cfg = O.make_config(max_iter=3, min_iter=3, window=window)
     params = O.make_params(ref, L, a=a0.copy(), b=b0.copy(), lik=lik)
     O.fit_given_init(ref, params, cfg)
+    # (1e-5: against the ORACLE's fit, see test_fit_end_to_end above)
     assert relerr(got["params"]["omega"], params["omega"]) < 1e-5
     assert relerr(got["params"]["a"], params["a"]) < 1e-5
     assert relerr(got["params"]["b"], params["b"]) < 1e-5
