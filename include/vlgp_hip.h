@@ -276,6 +276,7 @@ int vlgp_debug_npx(vlgp_ctx* ctx, int kind, int64_t n, const double* a, const do
 #define VLGP_PATH_ESTEP_LONG 3     /* long units (T > 64), one workgroup per trial */
 #define VLGP_PATH_ESTEP_GENERIC 4  /* generic kernels (rank > 50 slots, L > 10, ...) */
 #define VLGP_PATH_ESTEP_LSPLIT 5   /* long units as chip-wide launches: one workgroup per (unit, latent) task */
+#define VLGP_PATH_ESTEP_SPLIT_MIXED 6 /* SPLIT whose per-latent launches carried lane-per-task and wave-per-task blocks in one grid */
 int vlgp_debug_last_estep_path(vlgp_ctx* ctx, int* path);
 /* Same for the most recent vlgp_hstep_objective call: which kernel family evaluated the per-segment terms. */
 #define VLGP_PATH_HSTEP_NONE 0

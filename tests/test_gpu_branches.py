@@ -138,7 +138,7 @@ def test_exp_clamp_at_ten_in_e_and_m_step(V, split, monkeypatch):
         monkeypatch.setenv("VLGP_ESTEP_SPLIT", "1")
     V.estep(mine, params, V.get_config())
     from vlgp_amd import engine as E
-    assert E.TRACE["estep"] == ("split" if split else "fast")
+    assert E.TRACE["estep"] in (("split", "split_mixed") if split else ("fast",))
     for u, wv in zip(mine, want):
         for k, arr in zip(("mu", "v", "w"), wv):
             # curvatures up to e^10 a^2: the reference's v = rowsum(G o (G - G H + G H M)) cancels at cond(I + H) ~ 1e5

@@ -96,7 +96,7 @@ def test_c3_full_size_vem_against_reference_golden(V, golden):
         sess.segs.pull(("mu", "v", "w"))
         segs = list(sess.segs)
         p = sess.params
-        assert paths == ["split", "split"]
+        assert all(p in ("split", "split_mixed") for p in paths) and len(paths) == 2
         assert sess.runtime["it"] == int(g["it"]) == 2
         assert relerr([t[0] for t in traj], g["norm_mu"]) < TRAJ
         assert relerr([t[1] for t in traj], g["norm_a"]) < TRAJ
@@ -267,7 +267,7 @@ def test_c5_full_size_500_ragged_trials(V):
     try:
         eng, sid = sess.eng, sess.segs.set_id
         sess.run()
-        assert eng.last_estep_path == "split"   # the E-step of the EM loop ran on the chip-wide launch sequence
+        assert eng.last_estep_path in ("split", "split_mixed")   # the E-step of the EM loop ran on the chip-wide launch sequence
         assert len(sess.segs) == sum(lengths) // T
         p = sess.params
         a, b, noise = np.array(p["a"]), np.array(p["b"]), np.array(p["noise"])
@@ -306,7 +306,7 @@ def test_c5_full_size_500_ragged_trials(V):
 
         # ---- E-step: three more sweeps on the device, 100 random segments against the oracle
         eng.estep(sid, 3)
-        assert eng.last_estep_path == "split"
+        assert eng.last_estep_path in ("split", "split_mixed")
         got = eng.download(sid)
         sh = lambda arr: arr.reshape(M, T, L)
         ones = np.ones((T, 1, N))

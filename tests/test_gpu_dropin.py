@@ -80,6 +80,14 @@ def test_initial_cholesky_without_a_window(V):
         assert relerr(G, want[T]) < 1e-12, T
     # the copy is detached from the live params, as a deepcopy is
     assert init["cholesky"] is not res["params"]["cholesky"]
+    # ... and a saved result loads where vlgp_amd is not installed: the lazy dict pickles as a plain one
+    import pickle
+    import pickletools
+
+    blob = pickle.dumps(res["params"])
+    assert b"vlgp_amd" not in blob, [op for op, arg, _ in pickletools.genops(blob) if arg and "vlgp" in str(arg)]
+    back = pickle.loads(blob)
+    assert type(back["initial"]["cholesky"]) is dict and np.array_equal(back["initial"]["cholesky"][90], init["cholesky"][90])
 
 
 @pytest.mark.parametrize("ext", ["npy", "npz"])

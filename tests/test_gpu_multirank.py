@@ -50,10 +50,24 @@ def _worker(rank, world, tmp, q, inject, workload="C1", iters=3):
     ref = os.path.join(os.environ["VLGP_TEST_SHARED"], "omega_%s.npy" % workload)
     if world == 1:
         np.save(ref, omega_fit)
-    elif os.path.exists(ref):
+    else:
+        assert os.path.exists(ref), "the unsharded run comes first and leaves its omega at %s" % ref
         sess.params["omega"] = np.load(ref)
     res = sess.finish()
     p = res["params"]
+    if world > 1:
+        # ... and the run's OWN omega through the same inference (prior build from params["omega"] + core.infer, here via
+        # api.transform): finite, and equal to the handed-over result wherever the two omegas give the same factor
+        import vlgp_amd as V
+
+        own = dict(p, omega=omega_fit, cholesky={})
+        mine2 = [{"ID": t["ID"], "y": t["y"], "mu": t["mu"].copy()} for t in mine[:4]]
+        V.transform(mine2, own, res["config"])
+        for t2, t in zip(mine2, mine):
+            assert np.all(np.isfinite(t2["mu"])) and np.all(np.isfinite(t2["v"])) and np.all(t2["v"] >= 0.0)
+            T = t["y"].shape[0]
+            if relerr(own["cholesky"][T], p["cholesky"][T]) < 1e-9:  # same pivots: same posterior
+                assert relerr(t2["mu"], t["mu"]) < 1e-3, relerr(t2["mu"], t["mu"])
     q.put((rank, p["a"], p["b"], p["noise"], omega_fit, [t["ID"] for t in mine],
            np.stack([t["mu"] for t in mine]), res["config"]["runtime"]["it"]))
 
@@ -86,19 +100,20 @@ def _run_worlds(worlds, inject, workload="C1", iters=3):
 
     ctx = mp.get_context("spawn")
     out = {}
-    shared = tempfile.mkdtemp()
-    os.environ["VLGP_TEST_SHARED"] = shared  # (inherited by the spawned workers)
-    for world in worlds:
-        q = ctx.Queue()
-        with tempfile.TemporaryDirectory() as tmp:
-            procs = [ctx.Process(target=_worker, args=(r, world, tmp, q, inject, workload, iters)) for r in range(world)]
-            for p in procs:
-                p.start()
-            res = sorted(_collect(q, procs), key=lambda r: r[0])
-            for p in procs:
-                p.join(timeout=120)
-                assert p.exitcode == 0
-        out[world] = res
+    assert worlds[0] == 1, "the unsharded run leaves the omega the sharded ones infer from"
+    with tempfile.TemporaryDirectory() as shared:
+        os.environ["VLGP_TEST_SHARED"] = shared  # (inherited by the spawned workers)
+        for world in worlds:
+            q = ctx.Queue()
+            with tempfile.TemporaryDirectory() as tmp:
+                procs = [ctx.Process(target=_worker, args=(r, world, tmp, q, inject, workload, iters)) for r in range(world)]
+                for p in procs:
+                    p.start()
+                res = sorted(_collect(q, procs), key=lambda r: r[0])
+                for p in procs:
+                    p.join(timeout=120)
+                    assert p.exitcode == 0
+            out[world] = res
     return out
 
 
@@ -188,6 +203,24 @@ def test_bench_launch_line_two_ranks_one_gpu():
     done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert done.returncode != 0 and "must come from RCCL" in done.stderr
     assert not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver runs the one-GPU bench): bench.py starts
+    the two ranks itself and rank 0 prints the one line -- never an n_gpus: 1 line for a --gpus 2 request."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(VLGP_COMM_TRANSPORT="shm", VLGP_DEVICE="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "C1", "--no-cpu-baseline"]
+    done = subprocess.run(cmd + ["--allow-shm"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["transport"] == "shm" and len(d["ms_per_step_per_rank"]) == 2
+    # the ranks it started refuse the test transport without the flag: non-zero status, no line
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert done.returncode != 0 and not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_rccl_failure_is_loud():

@@ -50,9 +50,9 @@ def _ran(V, path, *calls):
     for c in calls:
         got = E.TRACE.get(c)
         if path == "split":
-            assert got in ("split", "long_split"), (c, got)
+            assert got in ("split", "split_mixed", "long_split"), (c, got)
         else:
-            assert got in ("fast", "generic", "long", "split", "long_split"), (c, got)
+            assert got in ("fast", "generic", "long", "split", "split_mixed", "long_split"), (c, got)
 
 
 def _params(g, L, N, P=1, rank=50, chol=None):
@@ -786,7 +786,7 @@ def test_headline_size_properties(V, monkeypatch):
             eng.update_v(0)
             for n in splits:
                 eng.estep(0, n)
-                assert eng.last_estep_path == "split"  # 4000 units / 200 k rows: the split E-step by size
+                assert eng.last_estep_path in ("split", "split_mixed")  # 4000 units / 200 k rows: the split E-step by size
             out = eng.download(0)
             G = eng.get_prior(50)
         return out, G
@@ -863,11 +863,11 @@ def test_split_estep_at_dispatch_size_vs_oracle(V, case):
         eng.build_prior([T], omega, sigma)
         G = eng.get_prior(T)
         eng.update_w(0)
-        assert eng.last_estep_path == "split"
+        assert eng.last_estep_path in ("split", "split_mixed")
         eng.update_v(0, case["vb"])
         st0 = eng.download(0, keys=("v", "w"))
         eng.estep(0, case["n_it"], vb=case["vb"])
-        assert eng.last_estep_path == "split"
+        assert eng.last_estep_path in ("split", "split_mixed")
         got = eng.download(0)
     for l in range(L):
         assert np.array_equal(G[l], O.ichol_gauss(T, omega[l], 50) * sigma[l])

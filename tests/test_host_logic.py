@@ -285,3 +285,39 @@ def test_blas_thread_limit_only_lowers():
         env = dict(os.environ, OMP_NUM_THREADS=env_threads, OPENBLAS_NUM_THREADS=env_threads)
         done = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
         assert done.returncode == 0 and "ok" in done.stdout, done.stderr[-1500:]
+
+
+def test_bench_refuses_a_world_that_is_not_the_gpus_asked_for():
+    """`bench.py --gpus 8` inside a one-rank launch must not print an n_gpus: 1 line."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert done.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in done.stderr
+    assert not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_initial_prior_behaves_like_the_dict_it_stands_for():
+    """engine._InitialPrior (params["initial"]["cholesky"] of a fit without a window): get() answers for a length
+    `in` reports, a deep copy stays lazy, and a pickle is a plain {T: ndarray} dict with no vlgp_amd class in it."""
+    import copy
+    import pickle
+
+    from vlgp_amd import engine as E
+
+    d = E._InitialPrior([40, 60], [1e-2, 5e-3], [1.0, 1.0], 8)
+    assert 40 in d and 41 not in d and d.get(41) is None and d.get(41, 7) == 7
+    G = d.get(40)
+    assert G is not None and G.shape == (2, 40, 8) and np.array_equal(G, d[40])
+    want = O.build_prior([40, 60], np.array([1e-2, 5e-3]), np.ones(2), 8)
+    assert relerr(G, want[40]) < 1e-12
+    c = copy.deepcopy(d)
+    assert isinstance(c, E._InitialPrior) and np.array_equal(c[60], d[60])
+    blob = pickle.dumps({"initial": {"cholesky": d}})
+    assert b"vlgp_amd" not in blob
+    back = pickle.loads(blob)["initial"]["cholesky"]
+    assert type(back) is dict and sorted(back) == [40, 60] and np.array_equal(back[60], d[60])

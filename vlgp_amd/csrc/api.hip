@@ -493,6 +493,7 @@ extern "C" int vlgp_create(int device, int N, int L, int P, int R, const uint8_t
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.sharedMemPerBlock > 0) ctx->lds_max = (int)prop.sharedMemPerBlock;
     {   // the main stream carries the latency-critical H-step rounds: give it the highest
         // priority, the M-step lane the lowest, so that M kernels only fill what H leaves idle
         int prio_lo = 0, prio_hi = 0;

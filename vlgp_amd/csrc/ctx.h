@@ -162,6 +162,8 @@ struct vlgp_ctx {
     hipStream_t elane[VLGP_E_LANES - 1] = {};
     hipEvent_t ev_e_fork = nullptr, ev_e_join[VLGP_E_LANES - 1] = {};
     int last_estep_path = 0;      // VLGP_PATH_ESTEP_* of the most recent E-step / update_w / update_v launch
+    int last_estep_mix = 0;       // that call ran mixed lane-per-task / wave-per-task launches (esplit_mix)
+    int lds_max = 64 * 1024;      // hipDeviceAttributeMaxSharedMemoryPerBlock (gfx950: 160 KB)
 
     std::string err;
 };

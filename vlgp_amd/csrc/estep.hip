@@ -468,7 +468,7 @@ int launch_estep(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double dmu_bo
     {
         int handled = 0;
         CHK(launch_estep_split(ctx, us, A, &handled));
-        if (handled) { ctx->last_estep_path = handled == 2 ? VLGP_PATH_ESTEP_LSPLIT : VLGP_PATH_ESTEP_SPLIT; return VLGP_OK; }
+        if (handled) { ctx->last_estep_path = handled == 2 ? VLGP_PATH_ESTEP_LSPLIT : (handled == 3 ? VLGP_PATH_ESTEP_SPLIT_MIXED : VLGP_PATH_ESTEP_SPLIT); return VLGP_OK; }
     }
 
     // FAST: register-resident factorisations (estep_fast.hip); declines when it does not apply

@@ -582,9 +582,8 @@ inline size_t lane_lds_doubles(int T, bool mean, bool last) {
 // 3.4 ms as soon as one latent reaches rank 13, tools/estep_per_step.py; ranks 15, 16 in this kernel: 1.5 KB of scratch
 // per lane, and a memory fault at launch on the second stream.)
 template <int KIND>
-__global__ void __launch_bounds__(256, 2) esplit_lane(SplitArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int li = blockIdx.x % A.n_lat, g = blockIdx.x / A.n_lat;
+__device__ __forceinline__ void esplit_lane_body(const SplitArgs& A, double* smem, int bid) {
+    const int li = bid % A.n_lat, g = bid / A.n_lat;
     const int r = A.shg_rk[li];
     // (s_setprio: measured 5 % slower at level 3 than at 0 with the other lane's row passes beside)
     if (A.prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -613,4 +612,10 @@ __global__ void __launch_bounds__(256, 2) esplit_lane(SplitArgs A) {
     }
 #endif
 #undef LANE_CASE
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) esplit_lane(SplitArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    esplit_lane_body<KIND>(A, smem, blockIdx.x);
 }

@@ -385,12 +385,12 @@ struct Task {
     int gcap;      // doubles reserved for the staged G (>= 256)
 };
 
-__device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int lane) {
+__device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* lds_wave, int lane, int bid) {
     const int wid = threadIdx.x >> 6;
     if (A.shg) {
-        K.m = 4 * (blockIdx.x / A.n_lat) + wid;
+        K.m = 4 * (bid / A.n_lat) + wid;
         if (K.m >= A.M) return false;
-        const int li = blockIdx.x % A.n_lat;
+        const int li = bid % A.n_lat;
         K.l = A.lat[li];
         K.r0 = A.off[K.m];
         K.T = A.shg_T;
@@ -405,7 +405,7 @@ __device__ __forceinline__ bool task_setup(const SplitArgs& A, Task& K, double* 
         K.u = K.vec + 128;
         return true;
     } else {
-        const int task = blockIdx.x * (blockDim.x >> 6) + wid;
+        const int task = bid * (blockDim.x >> 6) + wid;
         if (task >= A.M * A.n_lat) return false;
         K.m = task / A.n_lat;
         K.l = A.lat[task - K.m * A.n_lat];
@@ -1085,14 +1085,15 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
 // LASTSW (mean only): the last sweep of the call
 // (second launch bound = waves per SIMD: the rank <= 16 launches are bound by the number of resident waves --
 // measured 17 + 103 / n us (mean) and 28 + 124 / n us (factor) with n workgroups per CU)
-template <int MAXRA, bool MEAN, bool LASTSW = false>
-__global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_latent(SplitArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+// (`bid`: the block's index among the blocks of this kind -- blockIdx.x, or its position behind the lane-per-task blocks
+// of a mixed launch, esplit_mix)
+template <int MAXRA, bool MEAN, bool LASTSW>
+__device__ __forceinline__ void esplit_latent_body(const SplitArgs& A, double* smem, int bid) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double* wave_base = smem;
     if constexpr (MAXRA == 16) {
         if (A.shg) {  // one latent per workgroup: its G (T, rs) staged once, zero-padded to the even stride
-            const int li = blockIdx.x % A.n_lat;
+            const int li = bid % A.n_lat;
             const int r = A.shg_rk[li], rs = (r + 1) & ~1;
             const double* __restrict__ Gl = A.shg_gl[li];
             for (int i = threadIdx.x; i < A.shg_T * rs; i += 256) {
@@ -1105,7 +1106,7 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_
     }
     double* lds_wave = wave_base + (int64_t)wid * (A.pkl + A.lds_g + 128 + (MEAN ? 192 : 0));
     Task K;
-    if (!task_setup(A, K, lds_wave, lane)) return;
+    if (!task_setup(A, K, lds_wave, lane, bid)) return;
     if (MAXRA == 16 && A.shg) K.Gs = smem;
     if constexpr (MEAN) {
         // singular system: zero update (core.py:92-94).  The regular rank <= 16 sweeps read the flag with their other
@@ -1136,6 +1137,25 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_
             else factor_task<32, 32, false>(A, K, lane);
         }
     }
+}
+
+template <int MAXRA, bool MEAN, bool LASTSW = false>
+__global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_latent(SplitArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    esplit_latent_body<MAXRA, MEAN, LASTSW>(A, smem, blockIdx.x);
+}
+
+// MIXED launch (round 6): the lane-per-task blocks of the latents of rank <= LANE_RMAX and the wave-per-task blocks of the
+// latents above it as ONE grid.  Within a sweep the latents are independent (vlgp/core.py:76-97), but as two launches on
+// one stream the wave-per-task launch of a single latent that has drifted to rank 15 .. 20 was a second dependent step
+// of every sweep (E-step 2.05 -> 3.1 ms at C3 for one latent at rank 18): here its blocks fill the CUs the few hundred
+// lane-per-task workgroups leave idle.  Blocks [0, n_lane) are the lane-per-task ones (they live longest: first).
+// Same arithmetic per task as the two launches, hence the same bits.  KIND as esplit_lane.
+template <int KIND, int MAXRA>
+__global__ void __launch_bounds__(256, 2) esplit_mix(SplitArgs Aln, SplitArgs Alt, int n_lane) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x < n_lane) esplit_lane_body<KIND>(Aln, smem, blockIdx.x);
+    else esplit_latent_body<MAXRA, KIND != 0, KIND == 2>(Alt, smem, (int)blockIdx.x - n_lane);
 }
 
 // =========================================================================================================
@@ -1637,6 +1657,8 @@ int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     if (groups == 0 || A.n_lat == 0) return VLGP_OK;
     const bool last = mean && A.last;
     const size_t lds = lane_lds_doubles(A.shg_T, mean, last) * 8;
+    if (lds > (size_t)ctx->lds_max)  // (162,304 bytes at T = 64 on the last sweep: 1.5 KB under gfx950's 160 KB)
+        return vlgp_fail(ctx, VLGP_ERR_ARG, "lane-per-task E-step launch needs %zu bytes of LDS, the device has %d", lds, ctx->lds_max);
     const dim3 grid((unsigned)(groups * A.n_lat)), blk(256);
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
@@ -1645,6 +1667,42 @@ int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
     hipLaunchKernelGGL(fn, grid, blk, lds, st, A);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
+// the lane-per-task blocks of `Aln` and the wave-per-task blocks of `Alt` (class maxra: 20 / 24 / 32) as one grid (esplit_mix)
+int run_latent_mix(vlgp_ctx* ctx, const SplitArgs& Aln, const SplitArgs& Alt, int maxra, bool mean) {
+    const int n_lane = ((Aln.M + 63) / 64) * Aln.n_lat;
+    const int n_lat = (Alt.M * Alt.n_lat + 3) / 4;
+    if (n_lane == 0 || n_lat == 0) return vlgp_fail(ctx, VLGP_ERR_STATE, "mixed E-step launch without both kinds of blocks");
+    const bool last = mean && Aln.last;
+    const size_t lds_lane = lane_lds_doubles(Aln.shg_T, mean, last) * 8;
+    const size_t lds_lat = (size_t)(4 * (Alt.pkl + Alt.lds_g + 128 + (mean ? 192 : 0))) * 8;
+    const size_t lds = lds_lane > lds_lat ? lds_lane : lds_lat;
+    if (lds > (size_t)ctx->lds_max)
+        return vlgp_fail(ctx, VLGP_ERR_ARG, "mixed E-step launch needs %zu bytes of LDS, the device has %d", lds, ctx->lds_max);
+    const dim3 grid((unsigned)(n_lane + n_lat)), blk(256);
+    NEED_LANE(ctx);
+    hipStream_t st = t_lane;
+    const int kind = !mean ? 0 : (last ? 2 : 1);
+#define ESPLIT_MIX(KINDV, RA)                                                                                       \
+    do {                                                                                                            \
+        auto fn = esplit_mix<KINDV, RA>;                                                                             \
+        if (lds > 64 * 1024)                                                                                        \
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL(fn, grid, blk, lds, st, Aln, Alt, n_lane);                                               \
+    } while (0)
+#define ESPLIT_MIX_RA(RA)                                                                                           \
+    do {                                                                                                            \
+        if (kind == 0) ESPLIT_MIX(0, RA); else if (kind == 1) ESPLIT_MIX(1, RA); else ESPLIT_MIX(2, RA);            \
+    } while (0)
+    if (maxra <= 20) ESPLIT_MIX_RA(20);
+    else if (maxra <= 24) ESPLIT_MIX_RA(24);
+    else ESPLIT_MIX_RA(32);
+#undef ESPLIT_MIX_RA
+#undef ESPLIT_MIX
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }
@@ -1673,17 +1731,26 @@ struct LatentClasses {
 };
 
 int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
-    if (C.n_hi) {  // the long tasks first
-        A.n_lat = C.n_hi;
-        for (int i = 0; i < C.n_hi; ++i) A.lat[i] = C.hi[i];
-        A.pkl = tri_packed_size(C.maxra_hi <= 20 ? 20 : (C.maxra_hi <= 24 ? 24 : 32));
-        A.lds_g = 256;
-        A.shg = 0;
+    // lane-per-task latents AND others: one mixed launch (esplit_mix) instead of two or three dependent ones; the latents
+    // of rank 15, 16 then ride in the class of the higher ones (VLGP_ESTEP_MIX=0: the separate launches; per call)
+    const char* mixsw = getenv("VLGP_ESTEP_MIX");
+    const bool mix = C.n_ln > 0 && (C.n_hi > 0 || C.n_lo > 0) && !(mixsw && mixsw[0] == '0');
+    SplitArgs Ahi = A;
+    const int n_hi = C.n_hi + (mix ? C.n_lo : 0);
+    const int maxra_hi = (mix && C.maxra_hi < 20) ? 20 : C.maxra_hi;
+    if (n_hi) {  // the long tasks first
+        Ahi.n_lat = n_hi;
+        for (int i = 0; i < C.n_hi; ++i) Ahi.lat[i] = C.hi[i];
+        if (mix)
+            for (int i = 0; i < C.n_lo; ++i) Ahi.lat[C.n_hi + i] = C.lo[i];
+        Ahi.pkl = tri_packed_size(maxra_hi <= 20 ? 20 : (maxra_hi <= 24 ? 24 : 32));
+        Ahi.lds_g = 256;
+        Ahi.shg = 0;
         if (!mean) {  // factor: staging tile of H, then the multiplier rows (RA x (RA + 2) doubles); X overwrites it
-            A.lds_g = C.maxra_hi * (C.maxra_hi + 2);
-            A.pkl = 0;
+            Ahi.lds_g = maxra_hi * (maxra_hi + 2);
+            Ahi.pkl = 0;
         }
-        CHK(run_latent_class(ctx, A, C.maxra_hi, mean));
+        if (!mix) CHK(run_latent_class(ctx, Ahi, maxra_hi, mean));
     }
     if (C.n_ln) {
         // ONE launch for all of them, the highest ranks first in the grid (their workgroups live longest)
@@ -1703,6 +1770,10 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         A.prio = prio;
         A.clk = ctx->d_clk;
         A.clk_kind = clk_kind;
+        if (mix) {
+            ctx->last_estep_mix = 1;
+            return run_latent_mix(ctx, A, Ahi, maxra_hi, mean);
+        }
         CHK(run_latent_lane(ctx, A, mean));
     }
     if (C.n_lo) {
@@ -1848,6 +1919,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.shg = 0; A.shg_cap = 0; A.shg_T = 0;
     A.do_v = 0; A.last = 0;
     *handled = lng ? 2 : 1;
+    ctx->last_estep_mix = 0;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
 
     const int mode = E.mode;
@@ -1868,7 +1940,8 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     // bit-identical to the single lane (same arithmetic per unit).  VLGP_ESTEP_LANES=1 keeps one lane.
     const int lanes_env = getenv("VLGP_ESTEP_LANES") ? atoi(getenv("VLGP_ESTEP_LANES")) : 0;  // (per call: tests toggle it)
     int n_lanes = (lanes_env >= 1 && lanes_env <= VLGP_E_LANES) ? lanes_env : (us.M >= 3 * ctx->n_cu && n_it >= 2 ? 2 : 1);  // 2000 units: 2.11 -> 1.77 ms; 1000 units: no change with the wave-per-task launches, 1.60 -> 1.54 ms (and the H-step that follows 2.60 -> 2.41 ms) with the lane-per-task ones
-    while (n_lanes > 1 && us.M < 8 * n_lanes) --n_lanes;
+    // (lane-per-task latents: the cuts are multiples of 64 units -- a half must not come out empty)
+    while (n_lanes > 1 && us.M < (C.n_ln ? 64 : 8) * n_lanes) --n_lanes;
     for (int h = 1; h < n_lanes; ++h) {
         if (ctx->elane[h - 1]) continue;
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->elane[h - 1], hipStreamNonBlocking));
@@ -1972,5 +2045,6 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         if (hipGetLastError() != hipSuccess) rc = vlgp_fail(ctx, VLGP_ERR_HIP, "esplit_from_lm launch failed");
     }
     vlgp_prof_end(ctx, kind, (double)us.M * (E.n_iter > 0 ? E.n_iter : 1));
+    if (ctx->last_estep_mix && !lng) *handled = 3;
     return rc;
 }

@@ -562,8 +562,14 @@ class _LazyPrior(dict):
     def __contains__(self, T):
         return int(T) in self._lengths
 
+    def get(self, T, default=None):  # (dict.get bypasses __missing__)
+        return self[T] if T in self else default
+
     def materialize(self):
         return {T: np.array(self[T]) for T in sorted(self._lengths)}
+
+    def __reduce__(self):  # a result file must load without vlgp_amd (util.save pickles the dict): a plain dict
+        return (dict, (self.materialize(),))
 
 
 class _InitialPrior(dict):
@@ -605,8 +611,14 @@ class _InitialPrior(dict):
     def values(self):
         return [self[T] for T in self._lengths]
 
+    def get(self, T, default=None):  # (dict.get bypasses __missing__)
+        return self[T] if T in self else default
+
     def __deepcopy__(self, memo):
         return _InitialPrior(self._lengths, self._omega, self._sigma, self._rank)
+
+    def __reduce__(self):  # pickled (util.save) as the plain {T: ndarray} dict the reference's load expects
+        return (dict, (dict(self.items()),))
 
 
 def update_w(trials, params, config=None):
