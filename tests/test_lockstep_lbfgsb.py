@@ -1,10 +1,18 @@
 """The H-step's lock-step L-BFGS-B driver must be scipy.optimize.minimize,
-decision for decision: same iterates, same number of evaluations."""
+decision for decision: same iterates, same number of evaluations -- whichever routine takes the steps: the own one
+(csrc/lbfgsb.c, the default since round 6), SciPy's reverse-communication routine, or scipy.optimize.minimize in threads."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 from scipy.optimize import minimize
 
 from vlgp_amd import gp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def _objective(k):
@@ -33,8 +41,8 @@ def _reference(n):
     return out, nfev
 
 
-@pytest.mark.parametrize("force_threads", [False, True])
-def test_lockstep_matches_scipy_minimize(monkeypatch, force_threads):
+@pytest.mark.parametrize("routine", ["own", "scipy", "threads"])
+def test_lockstep_matches_scipy_minimize(monkeypatch, routine):
     n = 5
     want, want_nfev = _reference(n)
     funs = [_objective(k) for k in range(n)]
@@ -51,12 +59,15 @@ def test_lockstep_matches_scipy_minimize(monkeypatch, force_threads):
             G.append(gk)
         return np.array(f), np.array(G)
 
-    if force_threads:
+    if routine == "threads":
         monkeypatch.setattr(gp, "_setulb_or_none", lambda: None)
-    elif gp._setulb_or_none() is None:
+        monkeypatch.setattr(gp, "_own_setulb_or_none", lambda: None)
+    elif routine == "scipy" and gp._setulb_or_none() is None:
         pytest.skip("this SciPy does not expose the known setulb signature")
+    elif routine == "own" and (gp._own_setulb_or_none() is None or gp.lbfgsb_blas() is None):
+        pytest.skip("needs the built extension and SciPy's OpenBLAS (bit-identity is a property of that pairing)")
     x0s = [np.array([0.2, -0.3, 0.1]) * (k + 1) / n for k in range(n)]
-    got = gp.lockstep_minimize(batch, x0s, BOUNDS)
+    got = gp.lockstep_minimize(batch, x0s, BOUNDS, routine=None if routine == "threads" else routine)
     for k in range(n):
         assert np.array_equal(got[k], want[k]), k
         assert count[k] == want_nfev[k], (k, count[k], want_nfev[k])
@@ -71,22 +82,28 @@ def test_masked_gradient_like_the_hstep():
     b = np.log(np.array([(1e-3, 1.0), (5e-4, 5e-2), (5e-5, 2e-4)]))
     x0 = np.log(np.array([1.0, 5e-2, 1e-4]))
     want = minimize(fun, x0, jac=True, bounds=b).x
-    got = gp.lockstep_minimize(lambda ks, X: (np.array([fun(x)[0] for x in X]), np.array([fun(x)[1] for x in X])),
-                               [x0], b)[0]
-    assert np.array_equal(got, want)
+    for routine in ("own", "scipy"):
+        got = gp.lockstep_minimize(lambda ks, X: (np.array([fun(x)[0] for x in X]), np.array([fun(x)[1] for x in X])),
+                                   [x0], b, routine=routine)[0]
+        assert np.array_equal(got, want), routine
 
 
-def test_native_driver_matches_scipy_minimize():
-    """vlgp_amd._lockstep (csrc/lockstep_ext.c): the loop around SciPy's setulb and the objective call in C.  Same calls
-    to the same routine, so the iterates equal scipy.optimize.minimize's bit for bit -- also with more than sixteen runs
-    (evaluations go to the objective in slices of sixteen).  The objective here is a ctypes callback with the
-    signature of vlgp_hstep_objective (it returns the UN-negated value and gradient, as the C ABI does)."""
+@pytest.mark.parametrize("driver", ["own", "scipy"])
+def test_native_driver_matches_scipy_minimize(driver):
+    """vlgp_amd._lockstep (csrc/lockstep_ext.c): the whole round loop in C with the objective called through its address
+    -- around csrc/lbfgsb.c ("own", the default) or around SciPy's setulb ("scipy").  The iterates equal
+    scipy.optimize.minimize's bit for bit -- also with more than sixteen runs (evaluations go to the objective in slices
+    of sixteen).  The objective here is a ctypes callback with the signature of vlgp_hstep_objective (it returns the
+    UN-negated value and gradient, as the C ABI does)."""
     import ctypes as C
 
     from scipy.optimize import minimize
 
-    if gp._setulb_or_none() is None or gp._lockstep_ext() is None:
-        pytest.skip("needs SciPy's setulb and the built extension")
+    if gp._lockstep_ext() is None or (driver == "scipy" and gp._setulb_or_none() is None):
+        pytest.skip("needs the built extension (and SciPy's setulb)")
+    if driver == "own" and gp.lbfgsb_blas() is None:
+        pytest.skip("bit-identity needs SciPy's OpenBLAS")
+    run = gp.lockstep_minimize_own if driver == "own" else gp.lockstep_minimize_native
     rng = np.random.default_rng(0)
     cs = [rng.normal(size=3) * 0.5 for _ in range(20)]
 
@@ -111,7 +128,7 @@ def test_native_driver_matches_scipy_minimize():
     bounds = np.array([(-2.0, 2.0)] * 3)
     for n in (5, 20):
         x0s = [np.zeros(3) for _ in range(n)]
-        xs, status = gp.lockstep_minimize_native(C.cast(cb, C.c_void_p).value, 0, 0, 50, 1.0, range(n), x0s, bounds)
+        xs, status = run(C.cast(cb, C.c_void_p).value, 0, 0, 50, 1.0, range(n), x0s, bounds)
         assert status == 0
         for k in range(n):
             ref = minimize(lambda x, k=k: fun(k, x), x0s[k], jac=True, bounds=bounds).x
@@ -122,6 +139,206 @@ def test_native_driver_matches_scipy_minimize():
         return -3
 
     cb2 = proto(failing)
-    _, status = gp.lockstep_minimize_native(C.cast(cb2, C.c_void_p).value, 0, 0, 50, 1.0, range(2),
-                                            [np.zeros(3)] * 2, bounds)
+    _, status = run(C.cast(cb2, C.c_void_p).value, 0, 0, 50, 1.0, range(2), [np.zeros(3)] * 2, bounds)
     assert status == -3
+
+
+# ---- the own routine (csrc/lbfgsb.c) against SciPy's, call for call ------------------------------------------------
+def _state(x0, m):
+    n = x0.size
+    return dict(x=np.array(x0, dtype=float), g=np.zeros(n), wa=np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m),
+                iwa=np.zeros(3 * n, np.int32), task=np.zeros(2, np.int32), ln_task=np.zeros(2, np.int32),
+                lsave=np.zeros(4, np.int32), isave=np.zeros(44, np.int32), dsave=np.zeros(29), f=0.0)
+
+
+def _step(routine, st, pr, extra=()):
+    routine(pr["m"], st["x"], pr["lo"], pr["hi"], pr["nbd"], st["f"], st["g"], pr["factr"], pr["pgtol"], st["wa"], st["iwa"],
+            st["task"], st["lsave"], st["isave"], st["dsave"], pr["maxls"], st["ln_task"], *extra)
+
+
+def _matrices(st, n, m):
+    """ws, wy, sy, ss, wt, wn, snd, z, r, d, t, xp of the workspace (everything but the 8 m scratch doubles at its end)"""
+    return st["wa"][:2 * m * n + 5 * n + 11 * m * m]
+
+
+def _problems():
+    sys.path.insert(0, GOLDEN)
+    try:
+        import gen_lbfgsb_traces as G
+    finally:
+        sys.path.pop(0)
+    for s in range(60):
+        yield "hstep%d" % s, G.hstep_like(100 + s)
+    for s in range(240):
+        yield "general%d" % s, G.general(1000 + s)
+
+
+def test_own_routine_equals_scipys_call_for_call():
+    """csrc/lbfgsb.c bound to SciPy's OpenBLAS and scipy.optimize._lbfgsb.setulb, driven side by side with the same
+    arguments: after EVERY call the iterate, the task code and the whole limited-memory state (S, Y, S'Y, S'S, the two
+    factored middle matrices, the Cauchy point, the search direction) are equal bit for bit.  300 problems: the H-step's
+    shape (three parameters, masked gradient, a start on the bound) and general boxes of 1 .. 8 variables with every bound
+    kind, 1 .. 10 corrections, kinks and inconsistent gradients (failed line searches, restarts, abnormal ends)."""
+    own, theirs, blas = gp._own_setulb_or_none(), gp._setulb_or_none(), gp.lbfgsb_blas()
+    if own is None or theirs is None or blas is None:
+        pytest.skip("needs the extension, SciPy's setulb and SciPy's OpenBLAS")
+    seen = set()
+    n_calls = 0
+    for name, (fun, x0, lo, hi, nbd, m, factr, pgtol, maxls) in _problems():
+        pr = dict(lo=lo, hi=hi, nbd=nbd, m=m, factr=factr, pgtol=pgtol, maxls=maxls)
+        a, b = _state(x0, m), _state(x0, m)
+        for _ in range(4000):
+            _step(theirs, a, pr)
+            _step(own, b, pr, (blas,))
+            n_calls += 1
+            assert np.array_equal(a["task"], b["task"]), (name, a["task"], b["task"])
+            assert np.array_equal(a["x"], b["x"]), (name, a["x"] - b["x"])
+            assert np.array_equal(_matrices(a, x0.size, m), _matrices(b, x0.size, m)), name
+            assert np.array_equal(a["iwa"], b["iwa"]), name
+            seen.add((int(a["task"][0]), int(a["task"][1])))
+            if a["task"][0] == 3:
+                f, g = fun(a["x"])
+                a["f"] = b["f"] = float(f)
+                a["g"][:] = g
+                b["g"][:] = g
+            elif a["task"][0] != 1:
+                break
+        else:
+            raise AssertionError("no termination: " + name)
+    assert {(4, 401), (4, 402), (8, 0)} <= seen and n_calls > 5000, (seen, n_calls)
+
+
+@pytest.mark.parametrize("blas", ["scipy", "own"])
+def test_own_routine_replays_recorded_scipy_traces(blas):
+    """tests/golden/lbfgsb_traces.npz (gen_lbfgsb_traces.py: the live SciPy, 64 problems, 1449 calls): the recorded
+    (f, g) sequence fed into csrc/lbfgsb.c.  Same task code after every call = the same decisions (line-search accepts,
+    BFGS updates skipped, restarts, stops); iterates equal to 1e-12 -- with the portable loops of lbfgsb.c, whose dot
+    products and triangular solves round differently from OpenBLAS's, and on a host whose OpenBLAS picks other kernels
+    than the recording one's (bit-identity on ONE host is test_own_routine_equals_scipys_call_for_call)."""
+    own = gp._own_setulb_or_none()
+    if own is None:
+        pytest.skip("needs the built extension")
+    table = None
+    if blas == "scipy":
+        table = gp._scipy_blas_addresses()
+        if table is None:
+            pytest.skip("SciPy's OpenBLAS not found")
+    z = np.load(os.path.join(GOLDEN, "lbfgsb_traces.npz"))
+    worst = 0.0
+    for i in range(int(z["n_problems"])):
+        key = lambda k: z["p%02d_%s" % (i, k)]
+        pr = dict(lo=key("lo"), hi=key("hi"), nbd=key("nbd"), m=int(key("m")), factr=float(key("factr")), pgtol=float(key("pgtol")),
+                  maxls=int(key("maxls")))
+        st = _state(key("x0"), pr["m"])
+        tasks, xs, fs, gs = key("tasks"), key("xs"), key("fs"), key("gs")
+        for c in range(len(tasks)):
+            _step(own, st, pr, (table,))
+            assert np.array_equal(st["task"], tasks[c]), (i, c, st["task"], tasks[c])
+            err = float(np.max(np.abs(st["x"] - xs[c]) / np.maximum(np.abs(xs[c]), 1.0)))
+            worst = max(worst, err)
+            assert err < 1e-12, (i, c, err)
+            st["f"] = float(fs[c])
+            st["g"][:] = gs[c]
+    assert worst < 1e-12
+
+
+def test_own_blas_table_agrees_with_openblas_to_rounding():
+    """The same problems through lbfgsb.c on its own loops and on SciPy's OpenBLAS, each following its own iterates: same
+    number of evaluations and the same minimiser to 1e-9 (relative to the box) -- what a host without SciPy's library gets."""
+    own = gp._own_setulb_or_none()
+    table = gp._scipy_blas_addresses()
+    if own is None or table is None:
+        pytest.skip("needs the extension and SciPy's OpenBLAS")
+    sys.path.insert(0, GOLDEN)
+    try:
+        import gen_lbfgsb_traces as G
+    finally:
+        sys.path.pop(0)
+    for s in range(40):
+        fun, x0, lo, hi, nbd, m, factr, pgtol, maxls = G.hstep_like(300 + s)
+        pr = dict(lo=lo, hi=hi, nbd=nbd, m=m, factr=factr, pgtol=pgtol, maxls=maxls)
+        res = []
+        for tab in (table, None):
+            st, nfev = _state(x0, m), 0
+            for _ in range(2000):
+                _step(own, st, pr, (tab,))
+                if st["task"][0] == 3:
+                    f, g = fun(st["x"])
+                    st["f"], nfev = float(f), nfev + 1
+                    st["g"][:] = g
+                elif st["task"][0] != 1:
+                    break
+            res.append((st["x"].copy(), nfev, tuple(st["task"])))
+        assert res[0][1] == res[1][1] and res[0][2] == res[1][2], (s, res)
+        assert np.max(np.abs(res[0][0] - res[1][0])) < 1e-9, (s, res)
+
+
+def test_lockstep_extension_under_address_and_undefined_sanitizers(tmp_path):
+    """csrc/lockstep_ext.c + lbfgsb.c built with -fsanitize=address,undefined and driven through every entry point (run,
+    run_own, setulb: borrowed argument tuples, in-place buffers, the 16-evaluation slices, a failing objective) in a
+    subprocess with the sanitizer runtime preloaded (VERDICT round 5, item 7 ii)."""
+    import shutil
+    import sysconfig
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan")
+    so = tmp_path / "_lockstep.so"
+    csrc = os.path.join(ROOT, "vlgp_amd", "csrc")
+    cmd = ["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-ffp-contract=off", "-fsanitize=address,undefined", "-fPIC", "-shared",
+           "-Wall", "-I" + sysconfig.get_paths()["include"], os.path.join(csrc, "lockstep_ext.c"), os.path.join(csrc, "lbfgsb.c"),
+           "-o", str(so), "-lm"]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr[-2000:]
+    script = r"""
+import importlib.util, sys, ctypes as C, numpy as np
+spec = importlib.util.spec_from_file_location("vlgp_amd._lockstep", sys.argv[1])
+mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+import vlgp_amd
+sys.modules["vlgp_amd._lockstep"] = mod; vlgp_amd._lockstep = mod
+from vlgp_amd import gp
+assert gp._lockstep_ext() is mod
+rng = np.random.default_rng(0)
+cs = [rng.normal(size=3) * 0.5 for _ in range(20)]
+def fun(k, x):
+    d = x - cs[k]
+    return float(np.sum(d ** 4) + 0.5 * np.sum(d * d) + np.sin(x[1])), 4 * d ** 3 + d + np.array([0, np.cos(x[1]), 0])
+proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                    C.POINTER(C.c_double), C.POINTER(C.c_double))
+def objective(ctx, set_id, window, dt, n, lat, logp, ll, dll):
+    for e in range(n):
+        f, g = fun(lat[e], np.array([logp[3 * e], logp[3 * e + 1], logp[3 * e + 2]]))
+        ll[e] = -f
+        for j in range(3): dll[3 * e + j] = -g[j]
+    return 0
+cb = proto(objective); bad = proto(lambda *a: -3)
+bounds = np.array([(-2.0, 2.0)] * 3)
+outs = []
+for run in (gp.lockstep_minimize_own, gp.lockstep_minimize_native):
+    for n in (1, 5, 20):
+        res = run(C.cast(cb, C.c_void_p).value, 0, 0, 50, 1.0, range(n), [np.zeros(3) for _ in range(n)], bounds)
+        assert res is not None and res[1] == 0
+        outs.append(np.array(res[0]))
+    assert run(C.cast(bad, C.c_void_p).value, 0, 0, 50, 1.0, range(2), [np.zeros(3)] * 2, bounds)[1] == -3
+for a, b in zip(outs[:3], outs[3:]): assert np.array_equal(a, b)
+# the Python loop over ext.setulb, own loops and OpenBLAS
+for tab in ("own", ""):
+    import os; os.environ["VLGP_LBFGSB_BLAS"] = tab
+    got = gp.lockstep_minimize(lambda ks, X: (np.array([fun(k, x)[0] for k, x in zip(ks, X)]), np.array([fun(k, x)[1] for k, x in zip(ks, X)])),
+                               [np.zeros(3) for _ in range(4)], bounds, routine="own")
+    assert np.max(np.abs(np.array(got) - outs[1][:4])) < 1e-9
+# argument validation
+for bad_args in ((1, 2), ([0], np.zeros((1, 2)), bounds, 0, 0, 0, 50, 1.0, 10, 10, None), ([0], np.zeros((1, 3)), bounds, 0, 0, 0, 50, 1.0, 10, 10, (1, 2))):
+    try: mod.run_own(*bad_args); raise SystemExit("accepted bad arguments")
+    except (TypeError, ValueError): pass
+print("SANITIZED-OK")
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("VLGP_LBFGSB_BLAS", None)
+    done = subprocess.run([sys.executable, "-c", script, str(so)], capture_output=True, text=True, env=env, cwd=str(tmp_path),
+                          timeout=600)
+    assert done.returncode == 0 and "SANITIZED-OK" in done.stdout, (done.stdout[-1000:], done.stderr[-3000:])
+    assert "AddressSanitizer" not in done.stderr and "runtime error" not in done.stderr, done.stderr[-3000:]

@@ -2,11 +2,15 @@
 
 ``optimize`` mirrors gp.optimize (vlgp/gp.py:65-97): one bounded L-BFGS-B run
 per latent over log(sigma^2, omega, eps) with the gradient masked to omega.
-The optimiser itself is SciPy's (it is control logic, a few dozen scalar
-decisions per latent); every objective evaluation -- the T x T factorisations
-per segment that make up all of the arithmetic -- runs on the GPU through
-``Engine.hstep_objective``.  The L latents' optimisers run in lock step so
-that each round of evaluations is ONE kernel launch over all latents.
+The optimiser is host control logic (a few dozen scalar decisions per latent):
+since round 6 an own reverse-communication L-BFGS-B in C (csrc/lbfgsb.c, inside
+``vlgp_amd._lockstep``) that takes the very steps of SciPy's -- bit for bit
+when it is bound to the OpenBLAS SciPy ships (``_scipy_blas_addresses``), to
+rounding with its own loops; SciPy's own routine remains as the fallback when
+the module is not built.  Every objective evaluation -- the T x T
+factorisations per segment that make up all of the arithmetic -- runs on the
+GPU through ``Engine.hstep_objective``.  The L latents' optimisers run in lock
+step so that each round of evaluations is ONE kernel launch over all latents.
 """
 import logging
 import math
@@ -110,7 +114,7 @@ class _Lbfgsb:
 
     MAXCOR, FTOL, GTOL, MAXLS, MAXITER, MAXFUN = 10, 2.2204460492503131e-09, 1e-5, 20, 15000, 15000
 
-    def __init__(self, setulb, x0, log_bounds, xbuf=None):
+    def __init__(self, setulb, x0, log_bounds, xbuf=None, extra=()):
         self.setulb = setulb
         lo, hi = log_bounds[:, 0].copy(), log_bounds[:, 1].copy()
         n = x0.size
@@ -138,7 +142,7 @@ class _Lbfgsb:
         # the call's arguments either side of f (the one scalar that changes): bound once, this runs ~2 x per evaluation
         self._head = (self.MAXCOR, self.x, self.lo, self.hi, self.nbd)
         self._tail = (self.g, self.factr, self.GTOL, self.wa, self.iwa, self.task, self.lsave, self.isave, self.dsave,
-                      self.MAXLS, self.ln_task)
+                      self.MAXLS, self.ln_task) + tuple(extra)  # (extra: the BLAS table of the own routine)
         self._args = self._head + (self.f,) + self._tail  # rebuilt by feed(): f is the only argument passed by value
 
     def advance(self):
@@ -201,6 +205,61 @@ def _lockstep_ext():
         return None
 
 
+_BLAS_NAMES = ("ddot", "daxpy", "dscal", "dcopy", "dnrm2", "dpotrf", "dtrtrs")
+_blas_cache = {}
+
+
+def _scipy_blas_addresses():
+    """Addresses of the seven BLAS / LAPACK routines L-BFGS-B calls, taken from the OpenBLAS that SciPy itself links
+    (``scipy.libs/libscipy_openblas*.so``, symbols ``scipy_ddot_`` ...): bound to them, csrc/lbfgsb.c reproduces
+    scipy.optimize's iterates bit for bit on this machine.  None when that library is not there (another SciPy build,
+    no SciPy): the optimiser then runs on its own portable loops -- same algorithm, same decisions up to rounding."""
+    if "v" in _blas_cache:
+        return _blas_cache["v"]
+    out = None
+    try:
+        import ctypes
+        import glob
+
+        import scipy
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(scipy.__file__)))
+        for path in sorted(glob.glob(os.path.join(root, "scipy.libs", "libscipy_openblas*.so*"))):
+            if "64_" in os.path.basename(path):
+                continue  # (the ILP64 build: 8-byte integers)
+            lib = ctypes.CDLL(path)
+            addr = tuple(ctypes.cast(getattr(lib, "scipy_%s_" % k), ctypes.c_void_p).value for k in _BLAS_NAMES)
+            if all(addr):
+                _blas_cache["lib"] = lib  # (keeps the handle alive)
+                out = addr
+                break
+    except Exception:
+        out = None
+    _blas_cache["v"] = out
+    return out
+
+
+def lbfgsb_blas():
+    """The BLAS table the own optimiser runs on: SciPy's OpenBLAS when found, else None = the loops of csrc/lbfgsb.c
+    (VLGP_LBFGSB_BLAS=own forces the latter)."""
+    if os.environ.get("VLGP_LBFGSB_BLAS", "") == "own":
+        return None
+    return _scipy_blas_addresses()
+
+
+def lockstep_minimize_own(objective_address, handle_address, set_id, window, dt, latents, x0s, log_bounds):
+    """All runs in lock step with the optimiser of csrc/lbfgsb.c and the objective (vlgp_hstep_objective) called through
+    its address: no Python object on the path of a round.  Returns (xs, status); None when the module is not built."""
+    ext = _lockstep_ext()
+    if ext is None or not hasattr(ext, "run_own"):
+        return None
+    X = np.ascontiguousarray(np.stack([np.asarray(x0, dtype=np.float64) for x0 in x0s]))
+    bnd = np.ascontiguousarray(log_bounds, dtype=np.float64)
+    status = ext.run_own([int(l) for l in latents], X, bnd, int(objective_address), int(handle_address), int(set_id),
+                         int(window), float(dt), _Lbfgsb.MAXITER, _Lbfgsb.MAXFUN, lbfgsb_blas())
+    return [X[k].copy() for k in range(len(x0s))], int(status)
+
+
 def lockstep_minimize_native(objective_address, handle_address, set_id, window, dt, latents, x0s, log_bounds):
     """lockstep_minimize with the loop around SciPy's setulb and the objective call in C (vlgp_amd._lockstep): same
     calls to the same routine with the same arguments, hence the same iterates; the objective is vlgp_hstep_objective
@@ -216,14 +275,26 @@ def lockstep_minimize_native(objective_address, handle_address, set_id, window, 
     return [r.x.copy() for r in runs], int(status)
 
 
-def lockstep_minimize(batch_fn, x0s, log_bounds):
+def _own_setulb_or_none():
+    """One reverse-communication step of csrc/lbfgsb.c with SciPy's argument list (vlgp_amd._lockstep.setulb)."""
+    ext = _lockstep_ext()
+    return getattr(ext, "setulb", None) if ext is not None else None
+
+
+def lockstep_minimize(batch_fn, x0s, log_bounds, routine=None):
     """Minimise len(x0s) independent objectives with L-BFGS-B, evaluating all
     pending points of a round with ONE call ``batch_fn(keys, X) -> (f, G)``
     (f, G are the objective values / gradients to minimise).  Returns the list
-    of final x.  Single-threaded when SciPy's reverse-communication routine is
-    available, otherwise one ``scipy.optimize.minimize`` per thread with the
-    same batching (identical results either way)."""
-    setulb = _setulb_or_none()
+    of final x.  Single-threaded on a reverse-communication routine -- the own
+    one (csrc/lbfgsb.c; ``routine="own"``), else SciPy's (``"scipy"``); without
+    either, one ``scipy.optimize.minimize`` per thread with the same batching
+    (identical results every way)."""
+    setulb, extra = None, ()
+    if routine in (None, "own"):
+        setulb = _own_setulb_or_none()
+        extra = (lbfgsb_blas(),)
+    if setulb is None and routine in (None, "scipy"):
+        setulb, extra = _setulb_or_none(), ()
     if setulb is None:
         _warn_once("this SciPy does not expose the L-BFGS-B reverse-communication routine with the signature known here "
                    "(scipy.optimize._lbfgsb.setulb, SciPy 1.15): the H-step runs one scipy.optimize.minimize per latent "
@@ -231,7 +302,7 @@ def lockstep_minimize(batch_fn, x0s, log_bounds):
         return _lockstep_threads(batch_fn, x0s, log_bounds)
     n_runs = len(x0s)
     X = np.empty((n_runs, np.asarray(x0s[0]).size))  # row k IS run k's iterate (setulb updates it in place)
-    runs = [_Lbfgsb(setulb, x0, log_bounds, xbuf=X[k]) for k, x0 in enumerate(x0s)]
+    runs = [_Lbfgsb(setulb, x0, log_bounds, xbuf=X[k], extra=extra) for k, x0 in enumerate(x0s)]
     active = list(range(n_runs))
     while True:
         active = [k for k in active if runs[k].advance()]
@@ -300,11 +371,15 @@ def optimize(trials, params, config):
     try:
         xs = None
         if not os.environ.get("VLGP_LOCKSTEP_PYTHON"):
-            res = lockstep_minimize_native(eng.hstep_objective_address, eng.handle_address, sid, window, dt, range(L),
-                                           x0s, bounds)
-            if res is not None:
-                xs, status = res
-                eng.check(status)
+            # VLGP_LBFGSB=scipy: SciPy's own routine driven from C (the round-4 / 5 path); default: the own optimiser
+            drivers = ((lockstep_minimize_native,) if os.environ.get("VLGP_LBFGSB", "") == "scipy"
+                       else (lockstep_minimize_own, lockstep_minimize_native))
+            for driver in drivers:
+                res = driver(eng.hstep_objective_address, eng.handle_address, sid, window, dt, range(L), x0s, bounds)
+                if res is not None:
+                    xs, status = res
+                    eng.check(status)
+                    break
         if xs is None:
             xs = lockstep_minimize(batch, x0s, bounds)
     finally:
