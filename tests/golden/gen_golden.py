@@ -376,6 +376,53 @@ def gen_vem_c2():
          y_checksum=np.array([float(np.concatenate([t["y"] for t in trials0]).sum())]))
 
 
+c5_small_inputs = golden_cases.c5_small_inputs
+C5S = golden_cases.C5S
+
+
+def gen_c5_small():
+    """BASELINE.json configs[4]'s COMBINATION against the real reference (VERDICT round 5, item 7 i): 24 trials of four
+    distinct lengths (100 ... 250 bins) x 40 channels (30 Poisson + 10 Gaussian), ten latents; two EM iterations with every
+    default (H-step on: vlgp/gp.py:65-97 on the 50-bin segments of ALL lengths at once, make_cholesky per distinct
+    length, vlgp/gp.py:150-162; mixed likelihood in E- and M-step, vlgp/core.py:36-37,82-83,222-235)."""
+    trials0, a0, b0, mu0, lik = c5_small_inputs()
+    c = C5S
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy()} for t, m in zip(trials0, mu0)]
+    cfg = get_config(max_iter=2, min_iter=2)
+    params = get_params(trials, c["L"], a=a0.copy(), b=b0.copy(), lik=lik, omega_bound=cfg["omega_bound"])
+    for tr in trials:
+        T = tr["y"].shape[0]
+        tr["x"] = np.ones((T, 1, c["N"]))
+        tr["w"] = np.zeros((T, c["L"]))
+        tr["v"] = np.zeros((T, c["L"]))
+    fill_params(params)
+    fill_trials(trials)
+    gp.make_cholesky(trials, params, cfg)
+    assert sorted(params["cholesky"]) == sorted(set(c["lengths"]))
+    core.update_w(trials, params, cfg)
+    core.update_v(trials, params, cfg)
+    segs = cut_trials(trials, params, cfg)
+    gp.make_cholesky(segs, params, cfg)
+    fill_trials(segs)
+    traj = {"mu": [], "a": [], "b": [], "omega": [], "noise": []}
+
+    def spy(tr_, p_, c_):
+        traj["mu"].append(sl.norm(np.concatenate([s["mu"] for s in tr_])))
+        traj["a"].append(sl.norm(p_["a"]))
+        traj["b"].append(sl.norm(p_["b"]))
+        traj["omega"].append(np.array(p_["omega"]))
+        traj["noise"].append(np.array(p_["noise"]))
+
+    cfg["callbacks"] = [spy]
+    core.vem(segs, params, cfg)
+    save("c5_small", norm_mu=np.array(traj["mu"]), norm_a=np.array(traj["a"]), norm_b=np.array(traj["b"]),
+         omega=np.array(traj["omega"]), noise_traj=np.array(traj["noise"]), a=params["a"], b=params["b"],
+         noise=params["noise"], it=cfg["runtime"]["it"], pick=np.arange(0, len(segs), 3),
+         seg_mu=np.stack([s_["mu"] for s_ in segs[::3]]),
+         seg_v=np.stack([s_["v"] for s_ in segs[::3]]), seg_w=np.stack([s_["w"] for s_ in segs[::3]]),
+         y_checksum=np.array([float(np.concatenate([t["y"] for t in trials0]).sum())]))
+
+
 def gen_vem_c3():
     """BASELINE.json configs[2] (the headline) at full size: 200 trials x 1000 bins x 100 channels, 5 latents ->
     4000 segments; two EM iterations of the real reference with every default (H-step on), from injected a, b, mu
@@ -552,7 +599,7 @@ def gen_ragged():
 
 
 ALL = ["ichol", "estep", "mstep", "mstep_singular", "ragged", "hstep", "vem", "fit", "init", "fit_h1", "branches", "result",
-       "vem_c2", "vem_c3"]
+       "c5_small", "vem_c2", "vem_c3"]
 
 if __name__ == "__main__":
     os.chdir("/tmp")  # the reference writes vlgp.log into the cwd at import

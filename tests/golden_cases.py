@@ -97,3 +97,25 @@ def ragged_window_inputs():
         return [{"ID": i, "y": t["y"].copy(), "mu": m.copy()} for i, (t, m) in enumerate(zip(trials, mu0))]
 
     return fresh, a0, b0, (lengths, N, L), dict(max_iter=2, min_iter=2, omega_bound=(1e-3, 1e-2))
+
+
+# ---- the C5 combination in small (tests/golden/c5_small.npz: gen_golden.py c5_small runs the real reference on it) ----
+C5S = dict(n_trials=24, lengths=[100, 150, 200, 250], N=40, n_gauss=10, L=10)
+
+
+def c5_small_inputs():
+    """Several distinct trial lengths, mixed Poisson / Gaussian channels, ten latents; injected a, b, mu."""
+    import numpy as np
+
+    from vlgp_amd import synth
+
+    c = C5S
+    lengths = [c["lengths"][i % len(c["lengths"])] for i in range(c["n_trials"])]
+    trials = synth.make_trials(c["n_trials"], max(lengths), c["N"], c["L"], seed=5, n_gauss=c["n_gauss"], lengths=lengths)
+    rng = np.random.default_rng(51)
+    a0 = 0.3 * rng.standard_normal((c["L"], c["N"]))
+    b0 = np.mean(np.concatenate([t["y"] for t in trials]), axis=0, keepdims=True)
+    b0[:, :c["N"] - c["n_gauss"]] = np.log(np.maximum(b0[:, :c["N"] - c["n_gauss"]], 1e-8))
+    mu0 = [0.2 * rng.standard_normal((t["y"].shape[0], c["L"])) for t in trials]
+    lik = ["poisson"] * (c["N"] - c["n_gauss"]) + ["gaussian"] * c["n_gauss"]
+    return trials, a0, b0, mu0, lik

@@ -63,6 +63,52 @@ def test_c2_full_size_vem_against_reference_golden(V, golden):
         sess.close()
 
 
+# ------------------------------------------------------------------ the C5 combination against the REAL reference
+def test_c5_small_vem_against_reference_golden(V, golden):
+    """BASELINE.json configs[4]'s combination, small enough for the real reference (gen_golden.py c5_small; VERDICT round
+    5, item 7 i): 24 trials of four distinct lengths x 40 channels (30 Poisson + 10 Gaussian), ten latents; two EM
+    iterations with every default -- the H-step on the 50-bin segments of all lengths, a prior factor per distinct length
+    (vlgp/gp.py:150-162), mixed likelihood in E- and M-step (vlgp/core.py:36-37,82-83,222-235).  1e-6."""
+    import golden_cases
+    from vlgp_amd.api import FitSession
+
+    g = golden("c5_small")
+    trials0, a0, b0, mu0, lik = golden_cases.c5_small_inputs()
+    assert float(np.concatenate([t["y"] for t in trials0]).sum()) == float(g["y_checksum"][0])  # same inputs
+    L = a0.shape[0]
+    trials = [{"ID": t["ID"], "y": t["y"], "mu": m.copy()} for t, m in zip(trials0, mu0)]
+    traj = []
+
+    def spy(tr_, p_, c_):
+        traj.append((np.linalg.norm(np.concatenate([s["mu"] for s in tr_])), np.linalg.norm(p_["a"]),
+                     np.linalg.norm(p_["b"]), np.array(p_["omega"]), np.array(p_["noise"])))
+
+    sess = FitSession(trials, L, verbose=False, a=a0.copy(), b=b0.copy(), lik=lik, max_iter=2, min_iter=2, callbacks=[spy])
+    try:
+        assert sorted(int(T) for T in sess.params["cholesky"].keys()) == [50]  # (the segments' factor; the trials' four on finish)
+        sess.run()
+        sess.segs.pull(("mu", "v", "w"))
+        segs = list(sess.segs)
+        p = sess.params
+        assert sess.runtime["it"] == int(g["it"]) == 2
+        assert relerr([t[0] for t in traj], g["norm_mu"]) < TRAJ
+        assert relerr([t[1] for t in traj], g["norm_a"]) < TRAJ
+        assert relerr([t[2] for t in traj], g["norm_b"]) < TRAJ
+        assert relerr(np.array([t[3] for t in traj]), g["omega"]) < TRAJ
+        assert relerr(np.array([t[4] for t in traj]), g["noise_traj"]) < TRAJ
+        for k in ("a", "b", "noise"):
+            assert relerr(p[k], g[k]) < TRAJ, k
+        for k in ("mu", "v", "w"):
+            assert relerr(np.stack([segs[i][k] for i in g["pick"]]), g["seg_" + k]) < TRAJ, k
+        res = sess.finish()
+        sess = None
+        assert sorted(int(T) for T in res["params"]["cholesky"].keys()) == [100, 150, 200, 250]
+        assert all(np.all(np.isfinite(t["mu"])) and t["mu"].shape == (t["y"].shape[0], L) for t in res["trials"])
+    finally:
+        if sess is not None:
+            sess.close()
+
+
 # ------------------------------------------------------------------ C3 (headline) against the REAL reference
 def test_c3_full_size_vem_against_reference_golden(V, golden):
     """BASELINE.json configs[2], the headline: 200 trials x 1000 bins x 100 channels, 5 latents -> 4000 segments.

@@ -142,6 +142,45 @@ def test_vem_trajectory_golden(golden, tag, hs):
     assert relerr(np.stack([s["v"] for s in segs]), g["seg_v_" + tag]) < tol
 
 
+def test_c5_small_vem_golden(golden):
+    """The C5 combination (four distinct trial lengths, 30 Poisson + 10 Gaussian channels, ten latents), two EM iterations
+    with the H-step on: the oracle against what the REAL reference produced (gen_golden.py c5_small)."""
+    import golden_cases
+
+    g = golden("c5_small")
+    trials0, a0, b0, mu0, lik = golden_cases.c5_small_inputs()
+    assert float(np.concatenate([t["y"] for t in trials0]).sum()) == float(g["y_checksum"][0])
+    L, N = a0.shape
+    trials = [{"ID": t["ID"], "y": t["y"].copy(), "mu": m.copy(), "x": np.ones((t["y"].shape[0], 1, N)),
+               "w": np.zeros((t["y"].shape[0], L)), "v": np.zeros((t["y"].shape[0], L))} for t, m in zip(trials0, mu0)]
+    cfg = O.make_config(max_iter=2, min_iter=2)
+    params = O.make_params(trials, L, a=a0.copy(), b=b0.copy(), lik=lik)
+    params["da"] = np.zeros_like(params["a"])
+    params["db"] = np.zeros_like(params["b"])
+    O.fill_trials(trials)
+    O.make_cholesky(trials, params)
+    O.update_w(trials, params)
+    O.update_v(trials, params, cfg)
+    segs = O.cut_trials(trials, 50)
+    O.make_cholesky(segs, params)
+    O.fill_trials(segs)
+    traj = []
+    cfg["callbacks"] = [lambda t_, p_, c_: traj.append(
+        (np.linalg.norm(np.concatenate([s["mu"] for s in t_])), np.linalg.norm(p_["a"]), np.array(p_["omega"]),
+         np.array(p_["noise"])))]
+    O.vem(segs, params, cfg)
+    tol = 1e-9
+    assert cfg["runtime"]["it"] == int(g["it"]) == 2
+    assert relerr([t[0] for t in traj], g["norm_mu"]) < tol
+    assert relerr([t[1] for t in traj], g["norm_a"]) < tol
+    assert relerr(np.array([t[2] for t in traj]), g["omega"]) < tol
+    assert relerr(np.array([t[3] for t in traj]), g["noise_traj"]) < tol
+    for k in ("a", "b", "noise"):
+        assert relerr(params[k], g[k]) < tol, k
+    for k in ("mu", "v", "w"):
+        assert relerr(np.stack([segs[i][k] for i in g["pick"]]), g["seg_" + k]) < tol, k
+
+
 def test_fit_golden(golden):
     g = golden("fit_c1")
     trials = _c1_trials(g)

@@ -581,7 +581,10 @@ inline size_t lane_lds_doubles(int T, bool mean, bool last) {
 // the overflow in the accumulation registers -- the second launch is a second dependent step of every sweep: E-step 2.1 ->
 // 3.4 ms as soon as one latent reaches rank 13, tools/estep_per_step.py; ranks 15, 16 in this kernel: 1.5 KB of scratch
 // per lane, and a memory fault at launch on the second stream.)
-template <int KIND>
+// RTOP: the largest rank compiled in (13 or LANE_RMAX = 14).  The rank-14 case spills (its 105-double triangle plus the
+// loop state exceed 256 registers) and a kernel's scratch frame is the maximum over its rank switch: launches whose
+// latents all sit at rank <= 13 -- most of a fit -- take the RTOP = 13 instantiation, which has none.
+template <int KIND, int RTOP = LANE_RMAX>
 __device__ __forceinline__ void esplit_lane_body(const SplitArgs& A, double* smem, int bid) {
     const int li = bid % A.n_lat, g = bid / A.n_lat;
     const int r = A.shg_rk[li];
@@ -607,15 +610,19 @@ __device__ __forceinline__ void esplit_lane_body(const SplitArgs& A, double* sme
         else if (r == 11) LANE_CASE(11);
         else LANE_CASE(12);
     } else {
-        if (r == 13) LANE_CASE(13);
-        else LANE_CASE(14);
+        if constexpr (RTOP >= 14) {
+            if (r == 13) LANE_CASE(13);
+            else LANE_CASE(14);
+        } else {
+            LANE_CASE(13);
+        }
     }
 #endif
 #undef LANE_CASE
 }
 
-template <int KIND>
+template <int KIND, int RTOP = LANE_RMAX>
 __global__ void __launch_bounds__(256, 2) esplit_lane(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    esplit_lane_body<KIND>(A, smem, blockIdx.x);
+    esplit_lane_body<KIND, RTOP>(A, smem, blockIdx.x);
 }

@@ -1662,7 +1662,10 @@ int run_latent_lane(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const dim3 grid((unsigned)(groups * A.n_lat)), blk(256);
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
-    auto fn = !mean ? esplit_lane<0> : (last ? esplit_lane<2> : esplit_lane<1>);
+    int rtop = 0;
+    for (int i = 0; i < A.n_lat; ++i) rtop = A.shg_rk[i] > rtop ? A.shg_rk[i] : rtop;
+    auto fn = rtop <= 13 ? (!mean ? esplit_lane<0, 13> : (last ? esplit_lane<2, 13> : esplit_lane<1, 13>))
+                         : (!mean ? esplit_lane<0> : (last ? esplit_lane<2> : esplit_lane<1>));
     if (lds > 64 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));

@@ -764,7 +764,9 @@ __device__ void mstep_solve_poisson_fixed(const SolveArgs& A, int n) {
 // 11 MB of partials at C3); FIXED is the number of latents when the register-resident solve applies, 0 otherwise.
 #define MS_OUT 32
 #define MS_SL 16
-template <int FIXED>
+// ANYG: the set has Gaussian channels (or FIXED == 0): the general solve is compiled in -- its SOLVE_MAXD-sized local arrays
+// are 2.3 KB of scratch per lane that every launch of an all-Poisson fit (C1 .. C4) used to reserve without touching it
+template <int FIXED, bool ANYG = true>
 __global__ void __launch_bounds__(512) mstep_sum_solve_kernel(const double* __restrict__ partial, int G, int64_t K,
                                                               double* __restrict__ out, unsigned* ticket, SolveArgs A) {
     __shared__ double red[MS_SL][MS_OUT];
@@ -808,13 +810,17 @@ __global__ void __launch_bounds__(512) mstep_sum_solve_kernel(const double* __re
     }
     __syncthreads();
     for (int n = threadIdx.x; n < A.N; n += 512) {
-        if constexpr (FIXED > 0) {
-            if (!A.gauss[n]) {
-                mstep_solve_poisson_fixed<FIXED>(A, n);
-                continue;
+        if constexpr (FIXED > 0 && !ANYG) {
+            mstep_solve_poisson_fixed<FIXED>(A, n);
+        } else {
+            if constexpr (FIXED > 0) {
+                if (!A.gauss[n]) {
+                    mstep_solve_poisson_fixed<FIXED>(A, n);
+                    continue;
+                }
             }
+            mstep_solve_channel(A, n);
         }
-        mstep_solve_channel(A, n);
     }
 }
 
@@ -1083,10 +1089,17 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
                 const int64_t n = (int64_t)Kn * N;
                 const dim3 sg((unsigned)((n + MS_OUT - 1) / MS_OUT));
                 const int fixed = P == 1 ? L : 0;  // register-resident solve for the usual latent counts, no regressors
-                if (fixed == 3) hipLaunchKernelGGL(mstep_sum_solve_kernel<3>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
-                else if (fixed == 5) hipLaunchKernelGGL(mstep_sum_solve_kernel<5>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
-                else if (fixed == 8) hipLaunchKernelGGL(mstep_sum_solve_kernel<8>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
-                else if (fixed == 10) hipLaunchKernelGGL(mstep_sum_solve_kernel<10>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
+                const bool anyg = ctx->n_gauss > 0;
+#define MS_SUM_SOLVE(F)                                                                                                  \
+    do {                                                                                                                  \
+        if (anyg) hipLaunchKernelGGL((mstep_sum_solve_kernel<F, true>), sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);  \
+        else hipLaunchKernelGGL((mstep_sum_solve_kernel<F, false>), sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);      \
+    } while (0)
+                if (fixed == 3) MS_SUM_SOLVE(3);
+                else if (fixed == 5) MS_SUM_SOLVE(5);
+                else if (fixed == 8) MS_SUM_SOLVE(8);
+                else if (fixed == 10) MS_SUM_SOLVE(10);
+#undef MS_SUM_SOLVE
                 else hipLaunchKernelGGL(mstep_sum_solve_kernel<0>, sg, dim3(512), 0, st, d_part, g.G, n, d_stats, d_ticket, S);
                 HIPCHK(ctx, hipGetLastError());
                 continue;
