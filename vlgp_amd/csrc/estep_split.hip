@@ -28,7 +28,6 @@
 
 #include "estep_args.h"
 #include "wave_tri.h"
-#include "hstep_mfma.h"
 #include "fast_exp.h"
 
 namespace {
@@ -67,7 +66,6 @@ struct SplitArgs {
     int np, ntot;      // Poisson channels, all channels
     int lds_g;         // doubles of LDS per wave for the G tile
     int do_v, last;
-    int fmf;           // 1: the factor of ranks 17 .. 32 runs on the blocked matrix-pipe elimination of hstep_mfma.h
     int n_lat;         // latents covered by this launch (tasks = M n_lat)
     int shg;           // 1: every unit has the same prior; a workgroup = one latent x four units, G staged ONCE per
                        //    workgroup at the start of the LDS (shg_cap doubles) instead of once per wave
@@ -617,91 +615,6 @@ __device__ __forceinline__ void factor_task(const SplitArgs& A, const Task& K, i
             for (int i = 0; i < 16; ++i)
                 if (i >= lane - 16) Xl[tri_row_off(i) + lane - 16] = i < r ? a[i] : (i == lane - 16 ? 1.0 : 0.0);
         }
-    } else if (A.fmf) {
-        // Ranks 17 .. 32 on the MATRIX PIPE (round 6).  The register elimination below (wave_chol_aug32: one pivot at a
-        // time over 32 + 32 rows, every step a chain of broadcasts) is what the class-32 factor launch spends its 172 us
-        // per half of C3 on -- the first EM iterations of a fit, where every latent sits at rank 28, 29.  The H-step's
-        // dense round inverts 4000 50 x 50 matrices in 41 us with the blocked, identity-augmented elimination of
-        // hstep_mfma.h; here the same routine takes I + G'WG, identity-padded to 32 x 32, as an explicit matrix:
-        // X = chol(I + H)^-1 leaves it panel by panel straight into the hand-over buffer (packed rows, as the mean
-        // launches read them), (I + H)^-1 = X'X comes back in place of H, and the variance is
-        // v_t = g_t'(I + H)^-1 g_t over its lower triangle.  Cost independent of the rank within the class.
-        constexpr int LDH = 34;
-        using HG = HmGeom<32>;
-        double* ht = K.tile;               // 32 x LDH: I + G'WG, then its inverse
-        double* tb = ht + 32 * LDH;        // HG::ROWS x HG::LDB panel buffer + 32 zeros
-        if (lane < 32) tb[HG::ROWS * HG::LDB + lane] = 0.0;
-        {
-            double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0;  // tiles (0, 0), (1, 0), (1, 1)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                double g0[8], g1[8], wv[8];  // G[t][col], G[t][16 + col], w[t] at t = 4 k + kq
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int t = 4 * (8 * half + kk) + kq;
-                    const bool in = t < T;
-                    const int tc = in ? t : 0;
-                    const double wt = w_s[tc];
-                    const double ga = Gl[tc * r + (col < r ? col : 0)];
-                    const double gb = Gl[tc * r + (16 + col < r ? 16 + col : 0)];
-                    wv[kk] = in ? wt : 0.0;
-                    g0[kk] = (in && col < r) ? ga : 0.0;
-                    g1[kk] = (in && 16 + col < r) ? gb : 0.0;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    if (4 * (8 * half + kk) < T) {
-                        const double w0 = wv[kk] * g0[kk], w1 = wv[kk] * g1[kk];
-                        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, g0[kk], c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, g0[kk], c1, 0, 0, 0);
-                        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, g1[kk], c2, 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int tile = 0; tile < 3; ++tile) {
-                const int bi = tile == 0 ? 0 : 1, bj = tile == 2 ? 1 : 0;
-                const int cb = 16 * bj + col;
-                const double4_t c = tile == 0 ? c0 : (tile == 1 ? c1 : c2);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = 16 * bi + kq + 4 * q;
-                    ht[row * LDH + cb] = c[q] + (row == cb ? 1.0 : 0.0);  // (columns / rows beyond the rank: G is zero there)
-                    if (tile == 1) ht[cb * LDH + row] = c[q];
-                }
-            }
-        }
-        tri_wave_sync();
-        double unused0, unused1;
-        ok = hstep_task_mfma<32, true, true, true>(tb, 0.0, lane, unused0, unused1, 32, ht, LDH, ht, LDH,
-                                                   A.xg + (int64_t)(K.m * L + l) * A.pkg, RA);
-        tri_wave_sync();
-        __builtin_amdgcn_sched_barrier(0);
-        if (A.do_v && ok && lane < T) {
-            double gt[RA];
-            load_g_row<RA>(gt, Gl, lane, r);
-            double vv = 0.0;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                if (i < r) {
-                    const double* Pi = ht + i * LDH;
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < i; q += 2) {
-                        const double2 p2 = *reinterpret_cast<const double2*>(Pi + q);
-                        s0 = fma(p2.x, gt[q], s0);
-                        if (q + 1 < i) s1 = fma(p2.y, gt[q + 1], s1);
-                    }
-                    vv = fma(gt[i], fma(Pi[i], gt[i], 2.0 * (s0 + s1)), vv);
-                }
-            }
-            v_s[lane] = vv;
-        }
-        if (lane == 0) {
-            A.failg[K.m * L + l] = ok ? 0 : 1;
-            if (!ok) atomicAdd(A.fail, 1);
-        }
-        return;
     } else {
         // H = G'WG on the matrix pipe: the lower block triangle of the 32 x 32 matrix, staged (with the mirror image of
         // the off-diagonal tile) as RA rows of stride RA + 2 in LDS
@@ -1838,8 +1751,6 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
         Ahi.shg = 0;
         if (!mean) {  // factor: staging tile of H, then the multiplier rows (RA x (RA + 2) doubles); X overwrites it
             Ahi.lds_g = maxra_hi * (maxra_hi + 2);
-            // (matrix-pipe factor: 32 x 34 for I + H and its inverse, 48 x 18 + 32 for the panels; the launch adds 128)
-            if (A.fmf) Ahi.lds_g = 32 * 34 + HmGeom<32>::ROWS * HmGeom<32>::LDB + 32 - 128;
             Ahi.pkl = 0;
         }
         if (!mix) CHK(run_latent_class(ctx, Ahi, maxra_hi, mean));
@@ -2010,10 +1921,6 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.lds_g = 256; A.pkl = pkg; A.n_lat = 0;
     A.shg = 0; A.shg_cap = 0; A.shg_T = 0;
     A.do_v = 0; A.last = 0;
-    {   // ranks 17 .. 32: factor on the blocked matrix-pipe elimination (VLGP_ESTEP_MFMA_FACTOR=0: the register elimination)
-        const char* fsw = getenv("VLGP_ESTEP_MFMA_FACTOR");
-        A.fmf = (fsw && fsw[0] == '0') ? 0 : 1;
-    }
     *handled = lng ? 2 : 1;
     ctx->last_estep_mix = 0;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));

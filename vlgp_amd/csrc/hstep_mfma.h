@@ -76,28 +76,18 @@ __device__ __forceinline__ double hm_rsqrt(double d) {
 // TP x lda, its own diagonal included): the inverse of an explicit SPD matrix, used for the Schur complement of the
 // long-window segment kernel (hstep.hip, hstep_seg_big).  In place (kl == aex) is fine: every panel's entries are read
 // before the inverse is written at the end.
-//
-// XOUT (with EXPL, E == 0; round 6: the factor of the split E-step at ranks 17 .. 32, estep_split.hip): besides the
-// inverse in `kl` the routine hands out X = L^-1 itself -- the rows col0 .. col0 + 15 of X are final when panel k has
-// been eliminated (lane i holds X[col0 + q][i] = X'[i][col0 + q]) and go to `xout` in the packed lower-triangular
-// layout of wave_tri.h, rows below `xrows` only -- and returns false when a pivot is not positive and finite.  `buf`
-// then needs ROWS x LDB + 32 doubles only (the tables are not read; the zeros sit right behind the panel buffer), and
-// no logarithm is taken.
-template <int TP, bool KMODE = false, bool EXPL = false, bool XOUT = false>
+template <int TP, bool KMODE = false, bool EXPL = false>
 __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lane, double& tr, double& cs,
                                                 int tr_k = 0, double* kl = nullptr, int ldk = 0,
-                                                const double* aex = nullptr, int lda = 0, double* xout = nullptr,
-                                                int xrows = 0) {
+                                                const double* aex = nullptr, int lda = 0) {
     static_assert(!EXPL || KMODE, "the explicit-matrix form returns the inverse (KMODE)");
     using G = HmGeom<TP>;
     constexpr int NB = G::NB, E = G::E, LDB = G::LDB, WL = G::WL, TB = 16 * NB;
-    static_assert(!XOUT || (EXPL && E == 0), "X is handed out by the explicit-matrix form of a 16 NB window");
-    const double* sv = buf + (XOUT ? 0 : G::O_SV);  // (XOUT: never dereferenced)
-    const double* kvm = buf + (XOUT ? 0 : G::O_KVM);
-    const double* dkv = buf + (XOUT ? 0 : G::O_DKV);
-    double* ntail = buf + (XOUT ? 0 : G::O_NT);
-    const double* zrow = buf + (XOUT ? G::ROWS * LDB : G::O_Z);
-    bool piv_ok = true;
+    const double* sv = buf + G::O_SV;
+    const double* kvm = buf + G::O_KVM;
+    const double* dkv = buf + G::O_DKV;
+    double* ntail = buf + G::O_NT;
+    const double* zrow = buf + G::O_Z;
     const int c = lane & 15, g = lane >> 4;
     hm_d4 N[NB][NB], M[NB][NB], P[NB][NB];
 #pragma unroll
@@ -226,7 +216,6 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                         rx[j] = fma(-rx[j - 1], lv, rx[j]);
                     }
                     const double d = tri_readlane(ra[j], j);
-                    if (XOUT) piv_ok = piv_ok && d > 0.0 && d < 1e300;  // (wave-uniform)
                     double y = __builtin_amdgcn_rsq(d);
                     if (j + 1 < W && j >= 1) {  // column j + 1 <- columns 0 .. j - 1
                         const double* row = Ld + (j + 1) * LDD;
@@ -257,7 +246,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     }
                     ra[j] *= y;
                     rx[j] *= y;
-                    if (KMODE && !XOUT) {
+                    if (KMODE) {
                         yprod *= y;
                         asm volatile("" : "+v"(yprod));  // (else the product is formed at the end from fifty kept values)
                     }
@@ -269,12 +258,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (KMODE && !XOUT) logdet -= log(yprod);  // log det chol(K) = -sum log(1 / L_jj)
-        }
-        if constexpr (XOUT) {  // rows col0 .. col0 + 15 of X = L^-1, packed: lane i holds column i
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (col0 + q < xrows && lane <= col0 + q) xout[tri_row_off(col0 + q) + lane] = rx[q];
+            if (KMODE) logdet -= log(yprod);  // log det chol(K) = -sum log(1 / L_jj)
         }
         // ---- 4. finished rows back to LDS (block rows for the operands, tail rows for the dot products) ----
         if (!last && lane >= 16 && lane < rowsA) {
@@ -396,7 +380,7 @@ __device__ __forceinline__ bool hstep_task_mfma(double* buf, double eps, int lan
         }
         tr = logdet;
         cs = 0.0;
-        return XOUT ? piv_ok : true;
+        return true;
     }
     // ---- weighted sums over A^-1: block part from P (lower blocks; off-diagonal blocks count twice) ----
     tr = 0.0;
