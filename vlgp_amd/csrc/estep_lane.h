@@ -29,7 +29,12 @@
 // architectural registers).
 #pragma once
 
-constexpr int LANE_RMAX = 14;
+// (-DLANE_RMAX_BUILD=16: the debug build of tools/lane_r16_fault.sh -- ranks 15, 16 compiled into these kernels, 1.5 KB of
+// scratch per lane -- with which the fault recorded below esplit_lane_body was reproduced and explained; never shipped)
+#ifndef LANE_RMAX_BUILD
+#define LANE_RMAX_BUILD 14
+#endif
+constexpr int LANE_RMAX = LANE_RMAX_BUILD;
 constexpr int LANE_EMAX = LANE_RMAX * (LANE_RMAX + 1) / 2;  // doubles of X per task in the hand-over buffer
 constexpr int LANE_NW = 4;    // waves per workgroup
 constexpr int LANE_CH = 32;   // entries of H per reduction round: 3 x 32 x 64 doubles = 48 KB of LDS
@@ -610,7 +615,12 @@ __device__ __forceinline__ void esplit_lane_body(const SplitArgs& A, double* sme
         else if (r == 11) LANE_CASE(11);
         else LANE_CASE(12);
     } else {
-        if constexpr (RTOP >= 14) {
+        if constexpr (RTOP >= 16) {
+            if (r == 13) LANE_CASE(13);
+            else if (r == 14) LANE_CASE(14);
+            else if (r == 15) LANE_CASE(15);
+            else LANE_CASE(16);
+        } else if constexpr (RTOP >= 14) {
             if (r == 13) LANE_CASE(13);
             else LANE_CASE(14);
         } else {
