@@ -1139,8 +1139,14 @@ __device__ __forceinline__ void esplit_latent_body(const SplitArgs& A, double* s
     }
 }
 
+#ifndef ESPLIT_LB32
+#define ESPLIT_LB32 3  /* (no accumulation registers, three waves per SIMD: class-32 E-step 8.30 -> 7.9 ms, tools/estep_lb_sweep.sh; 4 spills 88 bytes and is slower; class 24 at 4 / 5 / 6: no change) */
+#endif
+#ifndef ESPLIT_LB24
+#define ESPLIT_LB24 1
+#endif
 template <int MAXRA, bool MEAN, bool LASTSW = false>
-__global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : 1)) esplit_latent(SplitArgs A) {
+__global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : (!MEAN ? (MAXRA == 32 ? ESPLIT_LB32 : ESPLIT_LB24) : 1))) esplit_latent(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     esplit_latent_body<MAXRA, MEAN, LASTSW>(A, smem, blockIdx.x);
 }
