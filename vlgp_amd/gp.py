@@ -384,9 +384,12 @@ def optimize(trials, params, config):
             xs = lockstep_minimize(batch, x0s, bounds)
     finally:
         eng.hstep_end()
+    ob = [float(b) for b in config["omega_bound"]]
     for l in range(L):
-        sig2, om, _ = np.exp(xs[l])
-        if not np.any(np.isclose(om, config["omega_bound"])):  # gp.py:91-92
+        sig2, om, _ = (float(v) for v in np.exp(xs[l]))  # (np.exp on the vector, as the reference: its bits)
+        # gp.py:91-92: `not np.any(np.isclose(om, omega_bound))`, i.e. |om - b| <= atol + rtol |b| with NumPy's defaults
+        # (the very predicate for finite scalars; np.isclose itself costs ~25 us a call, five times per H-step)
+        if not any(abs(om - b) <= 1e-8 + 1e-5 * abs(b) for b in ob):
             omega[l] = om
         sigma[l] = math.sqrt(sig2)
     params["sigma"] = sigma
