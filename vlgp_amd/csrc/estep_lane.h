@@ -631,8 +631,14 @@ __device__ __forceinline__ void esplit_lane_body(const SplitArgs& A, double* sme
 #undef LANE_CASE
 }
 
+// (the instantiation with the rank-14 case at ONE workgroup per CU: its overflow then sits in the accumulation registers --
+// 45 / 15 / 82 of them -- instead of 148 / 64 / 408 bytes of scratch per lane at two; same box, one latent at rank 14 among
+// rank-11 ones: E-step 2.36 -> 2.19 ms, tools/variant_ab.sh)
+#ifndef LANE_LB14
+#define LANE_LB14 1
+#endif
 template <int KIND, int RTOP = LANE_RMAX>
-__global__ void __launch_bounds__(256, 2) esplit_lane(SplitArgs A) {
+__global__ void __launch_bounds__(256, (RTOP >= 14 ? LANE_LB14 : 2)) esplit_lane(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     esplit_lane_body<KIND, RTOP>(A, smem, blockIdx.x);
 }

@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void esplit_latent_body(const SplitArgs& A, double* s
 }
 
 #ifndef ESPLIT_LB32
-#define ESPLIT_LB32 3  /* (no accumulation registers, three waves per SIMD: class-32 E-step 8.30 -> 7.9 ms, tools/estep_lb_sweep.sh; 4 spills 88 bytes and is slower; class 24 at 4 / 5 / 6: no change) */
+#define ESPLIT_LB32 3  /* (no accumulation registers, three waves per SIMD: class-32 E-step 8.30 -> 7.9 ms, tools/variant_ab.sh; 4 spills 88 bytes and is slower; class 24 at 4 / 5 / 6: no change) */
 #endif
 #ifndef ESPLIT_LB24
 #define ESPLIT_LB24 1
@@ -1157,10 +1157,11 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : (!MEAN ? (M
 // of every sweep (E-step 2.05 -> 3.1 ms at C3 for one latent at rank 18): here its blocks fill the CUs the few hundred
 // lane-per-task workgroups leave idle.  Blocks [0, n_lane) are the lane-per-task ones (they live longest: first).
 // Same arithmetic per task as the two launches, hence the same bits.  KIND as esplit_lane.
-template <int KIND, int MAXRA>
+// RTOP: as esplit_lane (13: no scratch frame; 14 keeps its spills here -- the wave-per-task blocks want two workgroups per CU).
+template <int KIND, int MAXRA, int RTOP>
 __global__ void __launch_bounds__(256, 2) esplit_mix(SplitArgs Aln, SplitArgs Alt, int n_lane) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if ((int)blockIdx.x < n_lane) esplit_lane_body<KIND>(Aln, smem, blockIdx.x);
+    if ((int)blockIdx.x < n_lane) esplit_lane_body<KIND, RTOP>(Aln, smem, blockIdx.x);
     else esplit_latent_body<MAXRA, KIND != 0, KIND == 2>(Alt, smem, (int)blockIdx.x - n_lane);
 }
 
@@ -1695,9 +1696,11 @@ int run_latent_mix(vlgp_ctx* ctx, const SplitArgs& Aln, const SplitArgs& Alt, in
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
     const int kind = !mean ? 0 : (last ? 2 : 1);
+    int rtop = 0;
+    for (int i = 0; i < Aln.n_lat; ++i) rtop = Aln.shg_rk[i] > rtop ? Aln.shg_rk[i] : rtop;
 #define ESPLIT_MIX(KINDV, RA)                                                                                       \
     do {                                                                                                            \
-        auto fn = esplit_mix<KINDV, RA>;                                                                             \
+        auto fn = rtop <= 13 ? esplit_mix<KINDV, RA, 13> : esplit_mix<KINDV, RA, LANE_RMAX>;                          \
         if (lds > 64 * 1024)                                                                                        \
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                                      \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
