@@ -585,6 +585,8 @@ def main():
                    "rccl_ranks_source": "ncclCommCount of the handle's communicators"},
         "ms_per_e_step": phase_ms["e"], "ms_per_m_step": phase_ms["m"], "ms_per_h_step": phase_ms["h"],
         "ms_per_step_per_rank": per_rank_ms,
+        # every timed EM iteration's own timers (runtime lists of vlgp/core.py:307-331), rank 0
+        "phase_ms_per_step": {k: [round(1e3 * float(t), 3) for t in rt[k + "_elapsed"][timed]] for k in ("e", "m", "h", "em")},
         "value_survey_protocol": survey["value"] if survey else None, "survey_protocol": survey,
         "roofline": roofline, "kernels": kernels,
         # the H-step beyond its kernel: dependent L-BFGS-B rounds of the timed region, their kernel time at the stand-alone
