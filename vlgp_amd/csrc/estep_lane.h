@@ -638,7 +638,7 @@ __device__ __forceinline__ void esplit_lane_body(const SplitArgs& A, double* sme
 #define LANE_LB14 1
 #endif
 template <int KIND, int RTOP = LANE_RMAX>
-__global__ void __launch_bounds__(256, (RTOP >= 14 ? LANE_LB14 : 2)) esplit_lane(SplitArgs A) {
+__global__ void __launch_bounds__(256, (RTOP >= 14 || KIND == 2 ? LANE_LB14 : 2)) esplit_lane(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     esplit_lane_body<KIND, RTOP>(A, smem, blockIdx.x);
 }

@@ -1157,9 +1157,10 @@ __global__ void __launch_bounds__(256, (MAXRA == 16 && !LASTSW ? 8 : (!MEAN ? (M
 // of every sweep (E-step 2.05 -> 3.1 ms at C3 for one latent at rank 18): here its blocks fill the CUs the few hundred
 // lane-per-task workgroups leave idle.  Blocks [0, n_lane) are the lane-per-task ones (they live longest: first).
 // Same arithmetic per task as the two launches, hence the same bits.  KIND as esplit_lane.
-// RTOP: as esplit_lane (13: no scratch frame; 14 keeps its spills here -- the wave-per-task blocks want two workgroups per CU).
+// RTOP: as esplit_lane; only 13 is instantiated (no scratch frame: the host sends a rank-14 latent to the wave-per-task
+// blocks of a mixed launch).  The last-sweep launch (KIND 2, once per call) runs at one workgroup per CU for the same reason.
 template <int KIND, int MAXRA, int RTOP>
-__global__ void __launch_bounds__(256, 2) esplit_mix(SplitArgs Aln, SplitArgs Alt, int n_lane) {
+__global__ void __launch_bounds__(256, (KIND == 2 ? 1 : 2)) esplit_mix(SplitArgs Aln, SplitArgs Alt, int n_lane) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if ((int)blockIdx.x < n_lane) esplit_lane_body<KIND, RTOP>(Aln, smem, blockIdx.x);
     else esplit_latent_body<MAXRA, KIND != 0, KIND == 2>(Alt, smem, (int)blockIdx.x - n_lane);
@@ -1696,11 +1697,11 @@ int run_latent_mix(vlgp_ctx* ctx, const SplitArgs& Aln, const SplitArgs& Alt, in
     NEED_LANE(ctx);
     hipStream_t st = t_lane;
     const int kind = !mean ? 0 : (last ? 2 : 1);
-    int rtop = 0;
-    for (int i = 0; i < Aln.n_lat; ++i) rtop = Aln.shg_rk[i] > rtop ? Aln.shg_rk[i] : rtop;
+    for (int i = 0; i < Aln.n_lat; ++i)
+        if (Aln.shg_rk[i] > 13) return vlgp_fail(ctx, VLGP_ERR_STATE, "mixed E-step launch with a lane-per-task rank above 13");
 #define ESPLIT_MIX(KINDV, RA)                                                                                       \
     do {                                                                                                            \
-        auto fn = rtop <= 13 ? esplit_mix<KINDV, RA, 13> : esplit_mix<KINDV, RA, LANE_RMAX>;                          \
+        auto fn = esplit_mix<KINDV, RA, 13>;                                                                          \
         if (lds > 64 * 1024)                                                                                        \
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                                      \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
@@ -1740,13 +1741,13 @@ struct LatentClasses {
     int lds_g_lo = 256;
     int single_T = 0;  // > 0: all units have this length (one prior): the rank <= 16 launch shares G per workgroup
     const Prior* single = nullptr;
+    bool mix = false;  // lane-per-task and wave-per-task latents in one launch (esplit_mix)
 };
 
 int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
     // lane-per-task latents AND others: one mixed launch (esplit_mix) instead of two or three dependent ones; the latents
     // of rank 15, 16 then ride in the class of the higher ones (VLGP_ESTEP_MIX=0: the separate launches; per call)
-    const char* mixsw = getenv("VLGP_ESTEP_MIX");
-    const bool mix = C.n_ln > 0 && (C.n_hi > 0 || C.n_lo > 0) && !(mixsw && mixsw[0] == '0');
+    const bool mix = C.mix;
     SplitArgs Ahi = A;
     const int n_hi = C.n_hi + (mix ? C.n_lo : 0);
     const int maxra_hi = (mix && C.maxra_hi < 20) ? 20 : C.maxra_hi;
@@ -1923,6 +1924,28 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
         if (use_lane && C.single && rlat[l] <= LANE_RMAX) C.ln[C.n_ln++] = l;
         else if (rlat[l] <= 16) C.lo[C.n_lo++] = l;
         else C.hi[C.n_hi++] = l;
+    }
+    {
+        // mixed launches carry the lane-per-task code compiled for ranks <= 13 (no scratch frame: a frame alone costs
+        // every wave of the launch, and ROCr allocates it per queue at first use -- milliseconds, seen as an 8.8 ms
+        // E-step in the middle of a fit); a latent at rank 14 rides with the wave-per-task ones there
+        const char* mixsw = getenv("VLGP_ESTEP_MIX");
+        const bool mix_on = !(mixsw && mixsw[0] == '0');
+        bool others = C.n_hi > 0 || C.n_lo > 0;
+        if (mix_on && C.n_ln > 0) {
+            int keep = 0, moved = 0, mv[16];
+            for (int i = 0; i < C.n_ln; ++i) {
+                if (rlat[C.ln[i]] >= 14) mv[moved++] = C.ln[i];
+                else C.ln[keep++] = C.ln[i];
+            }
+            if (others && moved > 0 && keep > 0) {  // (all of them at 14 and nothing else: the lane-per-task launch as it is)
+                C.n_ln = keep;
+                for (int i = 0; i < moved; ++i) C.lo[C.n_lo++] = mv[i];
+            } else {  // restore
+                for (int i = 0; i < moved; ++i) C.ln[keep + i] = mv[i];
+            }
+        }
+        C.mix = mix_on && C.n_ln > 0 && (C.n_hi > 0 || C.n_lo > 0);
     }
     C.maxra_hi = maxra;
     C.lds_g_lo = (int)((gw_lo + 1) & ~1LL);  // staged G of a rank <= 16 latent (and the 16 x 16 staging tile)
