@@ -36,6 +36,35 @@ latent_map_kernel(int64_t rows, int L, const double* map, const double* shift, d
     }
 }
 
+// The same for L <= LT with the row in registers: the loop form above indexes two VLGP_MAX_L-sized local arrays, 1040 bytes of
+// scratch per lane, for a kernel that every EM iteration launches (constrain_loading, vlgp/core.py:392-416) -- a scratch
+// frame of that size is allocated by the runtime per dispatch (above its single-allocation limit), DESIGN.md section 4.1.
+template <int LT>
+__global__ void __launch_bounds__(256)
+latent_map_kernel_t(int64_t rows, int L, const double* map, const double* shift, double* mu) {
+    extern __shared__ double sm[];
+    double* m_s = sm;          // L*L
+    double* s_s = sm + L * L;  // L
+    for (int i = threadIdx.x; i < L * L; i += 256) m_s[i] = map[i];
+    for (int i = threadIdx.x; i < L; i += 256) s_s[i] = shift ? shift[i] : 0.0;
+    __syncthreads();
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+        double in[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) in[l] = l < L ? mu[t * L + l] - s_s[l] : 0.0;
+#pragma unroll
+        for (int c = 0; c < LT; ++c) {
+            if (c < L) {
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < LT; ++l)
+                    if (l < L) s = fma(in[l], m_s[l * L + c], s);  // (same order of the sum as the loop form)
+                mu[t * L + c] = s;
+            }
+        }
+    }
+}
+
 // dst row (k*window + r) <- src row (start[k] + r), `width` doubles per row
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(int M, int window, int64_t width, const int64_t* start, const double* src, double* dst) {
@@ -81,8 +110,12 @@ int launch_xb(vlgp_ctx* ctx, UnitSet& us) {
 
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift) {
     const int L = ctx->L;
-    hipLaunchKernelGGL(latent_map_kernel, dim3(grid_for(us.rows)), dim3(256), (size_t)(L * L + L) * 8, ctx->stream,
-                       us.rows, L, d_map, d_shift, us.mu);
+    const dim3 grid(grid_for(us.rows)), blk(256);
+    const size_t lds = (size_t)(L * L + L) * 8;
+    if (L <= 5) hipLaunchKernelGGL((latent_map_kernel_t<5>), grid, blk, lds, ctx->stream, us.rows, L, d_map, d_shift, us.mu);
+    else if (L <= 10) hipLaunchKernelGGL((latent_map_kernel_t<10>), grid, blk, lds, ctx->stream, us.rows, L, d_map, d_shift, us.mu);
+    else if (L <= 16) hipLaunchKernelGGL((latent_map_kernel_t<16>), grid, blk, lds, ctx->stream, us.rows, L, d_map, d_shift, us.mu);
+    else hipLaunchKernelGGL(latent_map_kernel, grid, blk, lds, ctx->stream, us.rows, L, d_map, d_shift, us.mu);
     HIPCHK(ctx, hipGetLastError());
     return VLGP_OK;
 }
