@@ -312,6 +312,54 @@ def test_estep_mid_rank_buckets_vs_oracle(V, omega, lo, hi, estep_path):
             assert relerr(u[k], r) < STAGE, k
 
 
+@pytest.mark.parametrize("omegas,mixed", [
+    ([8e-3, 8e-3, 1.7e-2, 8e-3, 8e-3], True),    # every lane-per-task latent at rank 14 beside an 18 (round 6: they all ride
+                                                 # with the wave-per-task blocks; the first version refused this launch)
+    ([5e-3, 8e-3, 1.7e-2, 6e-3, 1e-2], True),    # ranks 11, 14, 18, 12, 15: lane-per-task 11, 12 + wave-per-task 14, 15, 18
+    ([8e-3, 8e-3, 8e-3, 8e-3, 8e-3], False),     # rank 14 only: the lane-per-task kernel compiled for it, no mixing
+    ([5e-3, 5e-3, 8e-3, 5e-3, 2.2e-2], True),    # 11, 11, 14, 11, 21
+    ([5e-3, 6e-3, 7e-3, 5e-3, 4.5e-2], True),    # ranks <= 13 beside a 29
+])
+def test_estep_mixed_rank_launches_vs_oracle(V, omegas, mixed, estep_path):
+    """The split E-step's per-latent launches with lane-per-task and wave-per-task latents in ONE grid (esplit_mix,
+    estep_split.hip): every combination of rank classes the host can form, against the oracle -- and the same with the
+    separate launches (VLGP_ESTEP_MIX=0), bit for bit (same arithmetic per task)."""
+    import os
+
+    from vlgp_amd import engine as E
+
+    rng = np.random.default_rng(21)
+    units, params, gauss = _random_problem(rng, [50] * 70, 24, 5, 1, 0)
+    params["omega"] = np.array(omegas)
+    params["cholesky"] = O.build_prior([50], params["omega"], params["sigma"], 50)
+    for u in units:
+        u["w"] = O.curvature_unit(u["y"], u["x"], u["mu"], np.zeros_like(u["mu"]), params["a"], params["b"],
+                                  params["noise"], gauss)
+        u["v"] = O.variance_unit(u["w"], np.zeros_like(u["mu"]), params["cholesky"][50])[0]
+    import copy
+
+    units0 = copy.deepcopy(units)
+    want = [O.estep_unit(u["y"], u["x"], u["mu"], u["v"], u["w"], params["a"], params["b"], params["noise"],
+                         gauss, params["cholesky"][50], 4) for u in units[:12]]
+    V.estep(units, params, V.get_config(Eniter=4))
+    _ran(V, estep_path, "estep")
+    if estep_path == "split":
+        assert E.TRACE["estep"] == ("split_mixed" if mixed else "split"), (E.TRACE["estep"], omegas)
+    for u, ref in zip(units, want):
+        for k, r in zip(("mu", "v", "w", "dmu"), ref):
+            assert relerr(u[k], r) < STAGE, k
+    if estep_path == "split" and mixed:
+        os.environ["VLGP_ESTEP_MIX"] = "0"
+        try:
+            V.estep(units0, params, V.get_config(Eniter=4))
+            assert E.TRACE["estep"] == "split"
+        finally:
+            os.environ.pop("VLGP_ESTEP_MIX", None)
+        for u, u0 in zip(units, units0):
+            for k in ("mu", "v", "w", "dmu"):
+                assert np.array_equal(u[k], u0[k]), k
+
+
 def test_estep_singular_system_zeroes_update(V, estep_path):
     # a NaN curvature makes I + G'WG non-factorisable: the reference logs and
     # applies a zero update for that latent (core.py:92-94); other latents move

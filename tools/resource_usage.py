@@ -50,7 +50,7 @@ def main():
     for path in files:
         for name, vals in usage(path):
             scratch = vals[3]
-            if everything or scratch > 0 or re.search(r"esplit_lane|hstep_round|hstep_small|mstep_", name):
+            if everything or scratch > 0 or re.search(r"esplit_lane|esplit_mix|esplit_latent|latent_map|hstep_round|mstep_", name):
                 print("%-72s %s" % (name[:72], "  ".join("%*d" % (len(f), v) for (f, _), v in zip(FIELDS, vals))))
 
 

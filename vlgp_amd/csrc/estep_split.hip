@@ -1938,7 +1938,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
                 if (rlat[C.ln[i]] >= 14) mv[moved++] = C.ln[i];
                 else C.ln[keep++] = C.ln[i];
             }
-            if (others && moved > 0 && keep > 0) {  // (all of them at 14 and nothing else: the lane-per-task launch as it is)
+            if (others && moved > 0) {  // (nothing but lane-per-task latents: their launch as it is, rank 14 included)
                 C.n_ln = keep;
                 for (int i = 0; i < moved; ++i) C.lo[C.n_lo++] = mv[i];
             } else {  // restore
