@@ -56,18 +56,20 @@ def _worker(rank, world, tmp, q, inject, workload="C1", iters=3):
     res = sess.finish()
     p = res["params"]
     if world > 1:
-        # ... and the run's OWN omega through the same inference (prior build from params["omega"] + core.infer, here via
-        # api.transform): finite, and equal to the handed-over result wherever the two omegas give the same factor
+        # ... and the run's OWN omega through the prior build and an inference of its own (api.transform: factor from
+        # params["omega"] for every trial length, then core.infer from w = v = 0 -- not the state `finish` infers from, so
+        # the posterior is checked for sanity, not against the hand-over's): finite, non-negative variances, the factor
+        # of the fitted omega on every length of the shard
         import vlgp_amd as V
 
         own = dict(p, omega=omega_fit, cholesky={})
         mine2 = [{"ID": t["ID"], "y": t["y"], "mu": t["mu"].copy()} for t in mine[:4]]
         V.transform(mine2, own, res["config"])
-        for t2, t in zip(mine2, mine):
+        assert sorted(own["cholesky"]) == sorted({t["y"].shape[0] for t in mine2})
+        for t2 in mine2:
+            G = own["cholesky"][t2["y"].shape[0]]
+            assert G.shape == p["cholesky"][t2["y"].shape[0]].shape and np.all(np.isfinite(G)) and np.any(G != 0.0)
             assert np.all(np.isfinite(t2["mu"])) and np.all(np.isfinite(t2["v"])) and np.all(t2["v"] >= 0.0)
-            T = t["y"].shape[0]
-            if relerr(own["cholesky"][T], p["cholesky"][T]) < 1e-9:  # same pivots: same posterior
-                assert relerr(t2["mu"], t["mu"]) < 1e-3, relerr(t2["mu"], t["mu"])
     q.put((rank, p["a"], p["b"], p["noise"], omega_fit, [t["ID"] for t in mine],
            np.stack([t["mu"] for t in mine]), res["config"]["runtime"]["it"]))
 
