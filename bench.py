@@ -100,7 +100,7 @@ def pmc_traffic(kernel_key):
     else profiles/r1: FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, plus WRITE_SIZE; separate
     passes).  None when no measurement is on file for that exact kernel name."""
     if not _PMC_CACHE:
-        for rnd in ("r1", "r2", "r3", "r4", "r5"):  # later rounds override
+        for rnd in ("r1", "r2", "r3", "r4", "r5", "r6"):  # later rounds override
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
                     _PMC_CACHE.update(json.load(f))
