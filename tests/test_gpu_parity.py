@@ -312,18 +312,20 @@ def test_estep_mid_rank_buckets_vs_oracle(V, omega, lo, hi, estep_path):
             assert relerr(u[k], r) < STAGE, k
 
 
-@pytest.mark.parametrize("omegas,mixed", [
-    ([8e-3, 8e-3, 1.7e-2, 8e-3, 8e-3], True),    # every lane-per-task latent at rank 14 beside an 18 (round 6: they all ride
-                                                 # with the wave-per-task blocks; the first version refused this launch)
-    ([5e-3, 8e-3, 1.7e-2, 6e-3, 1e-2], True),    # ranks 11, 14, 18, 12, 15: lane-per-task 11, 12 + wave-per-task 14, 15, 18
-    ([8e-3, 8e-3, 8e-3, 8e-3, 8e-3], False),     # rank 14 only: the lane-per-task kernel compiled for it, no mixing
-    ([5e-3, 5e-3, 8e-3, 5e-3, 2.2e-2], True),    # 11, 11, 14, 11, 21
-    ([5e-3, 6e-3, 7e-3, 5e-3, 4.5e-2], True),    # ranks <= 13 beside a 29
+@pytest.mark.parametrize("omegas,mixed,rerouted", [
+    ([8e-3, 8e-3, 1.7e-2, 8e-3, 8e-3], False, True),  # every lane-per-task latent at rank 14 beside an 18: they all ride with
+                                                      # the wave-per-task blocks, nothing is left to mix (the first version
+                                                      # refused this launch: C3s2)
+    ([5e-3, 8e-3, 1.7e-2, 6e-3, 1e-2], True, True),   # ranks 11, 14, 18, 12, 15: lane-per-task 11, 12 + wave-per-task 14, 15, 18
+    ([8e-3, 8e-3, 8e-3, 8e-3, 8e-3], False, False),   # rank 14 only: the lane-per-task kernel compiled for it, no mixing
+    ([5e-3, 5e-3, 8e-3, 5e-3, 2.2e-2], True, True),   # 11, 11, 14, 11, 21
+    ([5e-3, 6e-3, 7e-3, 5e-3, 4.5e-2], True, False),  # ranks <= 13 beside a 29
 ])
-def test_estep_mixed_rank_launches_vs_oracle(V, omegas, mixed, estep_path):
+def test_estep_mixed_rank_launches_vs_oracle(V, omegas, mixed, rerouted, estep_path):
     """The split E-step's per-latent launches with lane-per-task and wave-per-task latents in ONE grid (esplit_mix,
     estep_split.hip): every combination of rank classes the host can form, against the oracle -- and the same with the
-    separate launches (VLGP_ESTEP_MIX=0), bit for bit (same arithmetic per task)."""
+    separate launches (VLGP_ESTEP_MIX=0): bit for bit where every latent keeps its kind of task (same arithmetic per task),
+    to rounding where a rank-14 latent moves from a lane to a wave per task."""
     import os
 
     from vlgp_amd import engine as E
@@ -348,7 +350,7 @@ def test_estep_mixed_rank_launches_vs_oracle(V, omegas, mixed, estep_path):
     for u, ref in zip(units, want):
         for k, r in zip(("mu", "v", "w", "dmu"), ref):
             assert relerr(u[k], r) < STAGE, k
-    if estep_path == "split" and mixed:
+    if estep_path == "split" and (mixed or rerouted):
         os.environ["VLGP_ESTEP_MIX"] = "0"
         try:
             V.estep(units0, params, V.get_config(Eniter=4))
@@ -357,7 +359,10 @@ def test_estep_mixed_rank_launches_vs_oracle(V, omegas, mixed, estep_path):
             os.environ.pop("VLGP_ESTEP_MIX", None)
         for u, u0 in zip(units, units0):
             for k in ("mu", "v", "w", "dmu"):
-                assert np.array_equal(u[k], u0[k]), k
+                if rerouted:
+                    assert relerr(u[k], u0[k]) < 1e-10, k
+                else:
+                    assert np.array_equal(u[k], u0[k]), k
 
 
 def test_estep_singular_system_zeroes_update(V, estep_path):
@@ -680,18 +685,23 @@ def test_hstep_optimize_golden(V, golden):
 
 
 def test_hstep_native_and_python_drivers_agree_bit_for_bit(V, golden, monkeypatch):
-    """gp.optimize through vlgp_amd._lockstep (the loop around SciPy's setulb and the objective call in C) and through the
-    Python loop (VLGP_LOCKSTEP_PYTHON=1): same routine, same arguments, same device objective -> identical omega, sigma."""
+    """gp.optimize on the device objective through every driver: the own optimiser in C (csrc/lbfgsb.c, the default), SciPy's
+    routine driven from C (VLGP_LBFGSB=scipy, the round-5 path), the Python loop (VLGP_LOCKSTEP_PYTHON=1) -- same steps, same
+    arguments, same device objective -> identical omega, sigma; and the own optimiser on its own loops instead of SciPy's
+    OpenBLAS (VLGP_LBFGSB_BLAS=own): the same minimiser to 1e-9."""
     from vlgp_amd import gp as G
 
     if G._lockstep_ext() is None:
         pytest.skip("vlgp_amd/_lockstep.so is not built")
     g = golden("hstep")
     M, T, L = g["mu"].shape
-    out = []
-    for python_loop in (False, True):
-        if python_loop:
-            monkeypatch.setenv("VLGP_LOCKSTEP_PYTHON", "1")
+    out = {}
+    for name, env in (("own", {}), ("scipy", {"VLGP_LBFGSB": "scipy"}), ("python", {"VLGP_LOCKSTEP_PYTHON": "1"}),
+                      ("own_loops", {"VLGP_LBFGSB_BLAS": "own"})):
+        for k in ("VLGP_LBFGSB", "VLGP_LOCKSTEP_PYTHON", "VLGP_LBFGSB_BLAS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         units = [{"y": np.zeros((T, 2)), "mu": g["mu"][m].copy(), "w": g["w"][m].copy(),
                   "v": np.zeros((T, L))} for m in range(M)]
         params = {"ydim": 2, "zdim": L, "xdim": 1, "rank": 50, "a": np.zeros((L, 2)), "b": np.zeros((1, 2)),
@@ -700,10 +710,16 @@ def test_hstep_native_and_python_drivers_agree_bit_for_bit(V, golden, monkeypatc
         dev = _resident(V, units, params, set_prior=False)
         try:
             V.hstep(dev, params, V.get_config())
-            out.append((params["omega"].copy(), params["sigma"].copy()))
+            out[name] = (params["omega"].copy(), params["sigma"].copy())
         finally:
             dev.engine.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    if G._scipy_blas_addresses() is not None:
+        for name in ("scipy", "python"):
+            assert np.array_equal(out["own"][0], out[name][0]) and np.array_equal(out["own"][1], out[name][1]), name
+    else:  # (no SciPy OpenBLAS on this host: "own" already ran on its own loops)
+        assert np.array_equal(out["scipy"][0], out["python"][0])
+    assert relerr(out["own_loops"][0], out["scipy"][0]) < 1e-9 and relerr(out["own_loops"][1], out["scipy"][1]) < 1e-9
+    assert relerr(out["own"][0], g["omega_opt"]) < 1e-6  # ... and what the real reference's optimize returned
 
 
 # ------------------------------------------------------------------ EM loop
