@@ -115,7 +115,7 @@ __device__ __forceinline__ void quad_sweeps(HArr& h, double* xs, double* xq, int
 // LDS doubles of a factor launch of class (R, NL): G staged once per workgroup (T x R, zero beyond the rank) | per wave
 // its units' w / v ([unit][t], odd stride) | per group the R doubles of the sweeps' exchange (+ R of trash)
 __host__ __device__ inline size_t quad_lds_doubles(int T, int R, int NL) {
-    return (size_t)T * R + 4 * (size_t)(64 / NL) * (T | 1) + 4 * (size_t)(64 / NL) * (2 * R + 2);
+    return (size_t)T * R + 4 * (size_t)(64 / NL) * (T | 1) + 4 * (size_t)(64 / NL) * 2 * R;
 }
 
 // factor + variance of 4 x 64 / NL units of one latent: one workgroup, the four waves independent of each other
@@ -176,9 +176,7 @@ __device__ __forceinline__ void quad_factor(const SplitArgs& A, int l, int r, co
     // 16 k instructions at R = 32 went into 2 x 528 broadcasts).  With f_i = a_ik / a_kk (f_k = 1 - 1 / a_kk for the pivot
     // row itself) ONE update a_ij -= f_i p_j covers every entry; afterwards column k <- f, a_kk <- -1 / a_kk.  All R sweeps
     // done, h = -P.  Rows beyond the rank are the identity and sweep as such (pivot 1, no update).
-    // (stride 2 R + 2 doubles: the groups of a wave read their buffers in the same instruction, 16 bytes each -- at 2 R
-    // doubles, a multiple of 256 bytes, all of them hit the same four banks: measured 550 us per launch against 140)
-    double* xs = lds + (size_t)T * R + 4 * (size_t)UPW * TP + ((size_t)wid * UPW + gu) * (2 * R + 2);
+    double* xs = lds + (size_t)T * R + 4 * (size_t)UPW * TP + ((size_t)wid * UPW + gu) * 2 * R;
     double* xq = xs + q;
     bool ok = true;
     quad_sweeps<R, NL, 0>(h, xs, xq, q, ok);
