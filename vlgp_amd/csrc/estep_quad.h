@@ -1,27 +1,24 @@
-// Split E-step, factor + variance of the latents at ranks 17 .. 32 with a GROUP OF LANES per (unit, latent) task (round 6).
+// Split E-step, factor + variance of the latents at ranks 15 .. 32 with a GROUP OF LANES per (unit, latent) task (round 6).
 //
 // Included by estep_split.hip (inside its anonymous namespace, after estep_lane.h).  Same mathematics as factor_task there
-// (reference vlgp/core.py:102-113): H = G'WG, P = (I + H)^-1, v_t = g_t'P g_t; what the mean launches need from it is
-// P c for one vector c per sweep, so P itself is handed over (A.xsym) instead of the Cholesky factor's inverse.
+// (reference vlgp/core.py:102-113): H = I + G'WG, X = chol(H)^-1, v_t = |X g_t|^2.
 //
 // Why this shape.  The wave-per-task kernel (esplit_latent<.., false>) issues ~6 k vector instructions per task at rank 29
 // -- a 64-lane machine on a 29-wide matrix, the elimination one pivot at a time over 32 + 32 rows -- and its class-32
 // launch is 144 us per half of C3.  The lane-per-task form (estep_lane.h) needs r (r + 1) / 2 doubles per lane: 105 at
-// rank 14 is the end of it.  In between: NL = 4 / 8 lanes share a task, the rows of the lower triangle dealt to them
+// rank 14 is the end of it.  In between: NL = 2 / 4 / 8 lanes share a task, the rows of the lower triangle dealt to them
 // round-robin (lane q of a group owns rows q, q + NL, ...), every index static, G wave-uniform (all units of a launch share
-// the prior factor of their latent) and staged once per workgroup.  The inverse is a symmetric Gauss-Jordan sweep per
-// pivot; the pivot's row / column reaches the lanes of its group through R doubles of LDS.
+// the prior factor of their latent).  What one lane needs from its neighbours -- the pivot column in the Cholesky sweep,
+// the finished entries of a column of X in the inversion -- travels by DPP (quad_perm inside a quad, one row_shr / row_shl
+// by four across the two quads of a group of eight): no LDS, no barrier.
 //
-//   R (compiled rank, ranks above the actual one are identity padding) and NL:  20 / 4,  24 / 4,  32 / 8
-//   registers of the matrix per lane: NL K (K + 1) / 2, K = R / NL:              60      84      80 doubles
+//   R (compiled rank, ranks above the actual one are identity padding) and NL:  16 / 2,  20 / 4,  24 / 4,  32 / 8
+//   registers of H per lane: NL K (K + 1) / 2, K = R / NL:                       72      60      84      80 doubles
 //
 // A row slot k of a lane (row i = NL k + q) keeps the columns 0 .. NL (k + 1) - 1: the lower triangle plus the rest of its
 // diagonal block, so that every lane of a group runs the same code on the same register indices; the entries above the
-// diagonal are scratch and are zeroed before P is used.
+// diagonal are scratch and are zeroed before X is used.
 #pragma once
-#ifndef QUAD_LB
-#define QUAD_LB 1
-#endif
 
 template <int CTRL, int BANK>
 __device__ __forceinline__ double quad_dpp(double old, double v) {
@@ -33,6 +30,32 @@ __device__ __forceinline__ double quad_dpp(double old, double v) {
     return r.d;
 }
 
+// the value lane S of every group of NL lanes holds, in all lanes of the group
+template <int NL, int S>
+__device__ __forceinline__ double quad_bcast_s(double v) {
+    if constexpr (NL == 2) {
+        return quad_dpp<(S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6)), 0xf>(v, v);
+    } else if constexpr (NL == 4) {
+        return quad_dpp<S * 0x55, 0xf>(v, v);
+    } else {
+        const double t = quad_dpp<(S & 3) * 0x55, 0xf>(v, v);  // every quad: its lane S & 3
+        if constexpr (S < 4) return quad_dpp<0x114, 0xA>(t, t);  // row_shr:4 into the upper quads
+        else return quad_dpp<0x104, 0x5>(t, t);                  // row_shl:4 into the lower quads
+    }
+}
+template <int NL>
+__device__ __forceinline__ double quad_bcast(double v, int s) {  // s: compile-time after unrolling
+    switch (s) {
+        case 0: return quad_bcast_s<NL, 0>(v);
+        case 1: return quad_bcast_s<NL, 1>(v);
+        case 2: if constexpr (NL > 2) return quad_bcast_s<NL, 2>(v); else return v;
+        case 3: if constexpr (NL > 2) return quad_bcast_s<NL, 3>(v); else return v;
+        case 4: if constexpr (NL > 4) return quad_bcast_s<NL, 4>(v); else return v;
+        case 5: if constexpr (NL > 4) return quad_bcast_s<NL, 5>(v); else return v;
+        case 6: if constexpr (NL > 4) return quad_bcast_s<NL, 6>(v); else return v;
+        default: if constexpr (NL > 4) return quad_bcast_s<NL, 7>(v); else return v;
+    }
+}
 // sum over the lanes of a group, the same bits in every lane (a butterfly of commutative additions)
 template <int NL>
 __device__ __forceinline__ double quad_sum(double v) {
@@ -56,67 +79,9 @@ struct QuadGeom {
     __host__ __device__ static constexpr int width(int k) { return NL * (k + 1); }
 };
 
-// Sweep KP of the symmetric Gauss-Jordan inversion (see quad_factor), then the next: the pivot index is a template
-// parameter -- as a `#pragma unroll` loop the body with its pins is past the unroller's budget, stays rolled, and the matrix,
-// indexed at run time, becomes a scratch array.
-template <int R, int NL, int KP, class HArr>
-__device__ __forceinline__ void quad_sweeps(HArr& h, double* xs, double* xq, int q, bool& ok) {
-    using Q = QuadGeom<R, NL>;
-    constexpr int K = Q::K, k = KP, kk = KP / NL, qk = KP % NL;
-    {   // (branch-free: a lane that has nothing to contribute writes to the second, unused half of its group's buffer)
-        double* dst = q == qk ? xs : xs + R;
-#pragma unroll
-        for (int j = 0; j <= k; j += 2) {
-            if (j + 1 <= k) *reinterpret_cast<double2*>(dst + j) = double2{h[Q::off(kk) + j], h[Q::off(kk) + j + 1]};
-            else dst[j] = h[Q::off(kk) + j];
-        }
-    }
-    // (every address = one of two lane-dependent bases + a constant: addresses formed per entry are all materialised
-    // up front by the compiler and spill the matrix)
-    (q > qk ? xq : xq + R)[NL * kk] = h[Q::off(kk) + k];
-#pragma unroll
-    for (int k2 = kk + 1; k2 < K; ++k2) xq[NL * k2] = h[Q::off(k2) + k];
-    tri_wave_order();
-    const double d = xs[k];
-    if (!(d > 0.0) || !(d < 1e300)) ok = false;
-    double dinv = __builtin_amdgcn_rcp(d);
-    {
-        double e = fma(-d, dinv, 1.0);
-        dinv = fma(dinv, e, dinv);
-        e = fma(-d, dinv, 1.0);
-        dinv = fma(dinv, e, dinv);
-    }
-    double f[K];
-#pragma unroll
-    for (int k2 = 0; k2 < K; ++k2) f[k2] = (k2 == kk && q == qk) ? 1.0 - dinv : xq[NL * k2] * dinv;
-#pragma unroll
-    for (int jb = 0; jb < R; jb += 2) {
-        const double2 p2 = *reinterpret_cast<const double2*>(xs + jb);
-#pragma unroll
-        for (int k2 = jb / NL; k2 < K; ++k2) {
-            h[Q::off(k2) + jb] = fma(-f[k2], p2.x, h[Q::off(k2) + jb]);
-            h[Q::off(k2) + jb + 1] = fma(-f[k2], p2.y, h[Q::off(k2) + jb + 1]);
-        }
-    }
-#pragma unroll
-    for (int k2 = kk; k2 < K; ++k2) h[Q::off(k2) + k] = f[k2];
-    if (q == qk) h[Q::off(kk) + k] = -dinv;
-    // evaluate the sweep HERE: left alone, the compiler defers the updates of the entries no later sweep reads soon and
-    // carries their operands -- every p and f of up to thirty sweeps -- in accumulation registers and 3.8 KB of scratch
-#pragma unroll
-    for (int k2 = 0; k2 < K; ++k2)
-#pragma unroll
-        for (int j = 0; j < Q::width(k2); ++j) asm volatile("" : "+v"(h[Q::off(k2) + j]));
-    tri_wave_order();
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KP + 1 < R) quad_sweeps<R, NL, KP + 1>(h, xs, xq, q, ok);
-}
-
 // LDS doubles of a factor launch of class (R, NL): G staged once per workgroup (T x R, zero beyond the rank) | per wave
-// its units' w / v ([unit][t], odd stride) | per group the R doubles of the sweeps' exchange (+ R of trash)
-__host__ __device__ inline size_t quad_lds_doubles(int T, int R, int NL) {
-    return (size_t)T * R + 4 * (size_t)(64 / NL) * (T | 1) + 4 * (size_t)(64 / NL) * 2 * R;
-}
+// its units' w / v ([unit][t], odd stride)
+__host__ __device__ inline size_t quad_lds_doubles(int T, int R, int NL) { return (size_t)T * R + 4 * (size_t)(64 / NL) * (T | 1); }
 
 // factor + variance of 4 x 64 / NL units of one latent: one workgroup, the four waves independent of each other
 template <int R, int NL>
@@ -169,38 +134,77 @@ __device__ __forceinline__ void quad_factor(const SplitArgs& A, int l, int r, co
     for (int k = 0; k < K; ++k)
 #pragma unroll
         for (int s = 0; s < NL; ++s) h[Q::off(k) + NL * k + s] += (s == q) ? 1.0 : 0.0;
-    // ---- P = (I + H)^-1 by symmetric Gauss-Jordan sweeps on the lower triangle.  Sweep k needs row / column k of the
-    // matrix in every lane of the group (p_m = a_{max(m, k), min(m, k)}): the owner of row k puts its entries m <= k, every
-    // lane the column-k entries of its rows m > k, into R doubles of LDS per group -- one round trip per sweep instead of
-    // a DPP broadcast per entry (a Cholesky + triangular inverse through DPP was the first version: ~12 k of the kernel's
-    // 16 k instructions at R = 32 went into 2 x 528 broadcasts).  With f_i = a_ik / a_kk (f_k = 1 - 1 / a_kk for the pivot
-    // row itself) ONE update a_ij -= f_i p_j covers every entry; afterwards column k <- f, a_kk <- -1 / a_kk.  All R sweeps
-    // done, h = -P.  Rows beyond the rank are the identity and sweep as such (pivot 1, no update).
-    double* xs = lds + (size_t)T * R + 4 * (size_t)UPW * TP + ((size_t)wid * UPW + gu) * 2 * R;
-    double* xq = xs + q;
+    // ---- Cholesky, right-looking, column by column; the diagonal keeps 1 / L_jj ----
     bool ok = true;
-    quad_sweeps<R, NL, 0>(h, xs, xq, q, ok);
-    // entries above the diagonal -> 0; the diagonal of the own rows, once
-    double hd[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        hd[k] = h[Q::off(k) + NL * k];
+    for (int j = 0; j < R; ++j) {
+        if (j < r) {  // (columns beyond the rank: identity)
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int kj = j / NL, qj = j % NL;
+            const double d = quad_bcast<NL>(h[Q::off(kj) + j], qj);
+            if (!(d > 0.0) || !(d < 1e300)) ok = false;
+            double y = __builtin_amdgcn_rsq(d);
+            {
+                double e = fma(-d * y, y, 1.0);
+                y = fma(y * 0.5, e, y);
+                e = fma(-d * y, y, 1.0);
+                y = fma(y * 0.5, e, y);
+            }
 #pragma unroll
-        for (int s = 1; s < NL; ++s) {
-            if (q == s) hd[k] = h[Q::off(k) + NL * k + s];
-            if (q < s) h[Q::off(k) + NL * k + s] = 0.0;
+            for (int k = kj; k < K; ++k) h[Q::off(k) + j] *= y;       // column j of L for the rows below (and scratch above)
+            if (q == qj) h[Q::off(kj) + j] = y;                       // the owner of row j: 1 / L_jj
+#pragma unroll
+            for (int c = j + 1; c < R; ++c) {
+                if (c < r) {
+                    const int kc = c / NL, qc = c % NL;
+                    const double b = quad_bcast<NL>(h[Q::off(kc) + j], qc);  // L_cj
+#pragma unroll
+                    for (int k = kc; k < K; ++k) h[Q::off(k) + c] = fma(-h[Q::off(k) + j], b, h[Q::off(k) + c]);
+                }
+            }
         }
     }
-    // ---- variance v_t = g_t'P g_t = sum_i g_i (2 sum_{j <= i} P_ij g_j - P_ii g_i), with h = -P ----
+    // the owner's slot of column j holds 1 / L_jj, and a trailing update read it as if it were L_ij for i = j: those
+    // products landed in entries above the diagonal only (c > j = i), which are scratch.
+    // ---- X = L^-1 in place, column by column: X_ij = -(1 / L_ii) sum_{k = j}^{i - 1} L_ik X_kj ----
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (j < r) {
+            const int kj = j / NL, qj = j % NL;
+            const double xjj = quad_bcast<NL>(h[Q::off(kj) + j], qj);  // X_jj = 1 / L_jj
+            double s[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) s[k] = k >= kj ? h[Q::off(k) + j] * xjj : 0.0;  // L_ij X_jj for the rows below j
+#pragma unroll
+            for (int c = j + 1; c < R; ++c) {
+                if (c < r) {
+                    const int kc = c / NL, qc = c % NL;
+                    // row c is complete: X_cj = -(1 / L_cc) s_c, in its owner
+                    const double xcj = -s[kc] * h[Q::off(kc) + c];
+                    if (q == qc) h[Q::off(kc) + j] = xcj;
+                    const double xb = quad_bcast<NL>(xcj, qc);
+#pragma unroll
+                    for (int k = kc; k < K; ++k) s[k] = fma(h[Q::off(k) + c], xb, s[k]);  // rows below c: + L_ic X_cj
+                    // (rows of slot kc at or above c added a product with a diagonal / scratch entry to an s they no longer
+                    // need: each s[k] is consumed when its own row completes, and slot kc's rows complete in order q)
+                }
+            }
+        }
+    }
+    // entries above the diagonal -> 0; rows / columns beyond the rank stay the identity (their diagonal is 1, the rest 0)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int s = 1; s < NL; ++s)
+            if (q < s) h[Q::off(k) + NL * k + s] = 0.0;
+    // ---- variance v_t = |X g_t|^2 ----
     if (A.do_v) {
         for (int t = 0; t < T; ++t) {
             const double* gr = Gs + t * R;
-            double z[K], gi[K];
+            double z[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                z[k] = 0.0;
-                gi[k] = gr[NL * k + q];
-            }
+            for (int k = 0; k < K; ++k) z[k] = 0.0;
 #pragma unroll
             for (int jb = 0; jb < R; jb += 2) {
                 const double2 g2 = *reinterpret_cast<const double2*>(gr + jb);
@@ -212,13 +216,12 @@ __device__ __forceinline__ void quad_factor(const SplitArgs& A, int l, int r, co
             }
             double vv = 0.0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) vv = fma(gi[k], fma(hd[k], gi[k], -2.0 * z[k]), vv);
+            for (int k = 0; k < K; ++k) vv = fma(z[k], z[k], vv);
             vv = quad_sum<NL>(vv);
             if (q == 0) wl[t] = vv;
         }
     }
-    // ---- hand-over: P = -h as packed lower-triangular rows (the layout of the wave-per-task launches' X; the mean
-    // launches are told by A.xsym that it is the symmetric inverse itself) ----
+    // ---- hand-over: packed lower-triangular rows, as the wave-per-task mean launches read them ----
     const int m = mw + gu;
     if (m < A.M) {
         double* xd = A.xg + (int64_t)(m * L + l) * A.pkg;
@@ -228,7 +231,7 @@ __device__ __forceinline__ void quad_factor(const SplitArgs& A, int l, int r, co
             double* xr = xd + tri_row_off(i);
 #pragma unroll
             for (int j = 0; j < Q::width(k); ++j)
-                if (j <= i) xr[j] = -h[Q::off(k) + j];
+                if (j <= i) xr[j] = h[Q::off(k) + j];
         }
         if (q == 0) {
             A.failg[m * L + l] = ok ? 0 : 1;
@@ -259,7 +262,7 @@ __device__ __forceinline__ void esplit_quad_body(const SplitArgs& A, double* sme
 }
 
 template <int R, int NL>
-__global__ void __launch_bounds__(256, QUAD_LB) esplit_quad(SplitArgs A) {
+__global__ void __launch_bounds__(256, 1) esplit_quad(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     esplit_quad_body<R, NL>(A, smem, blockIdx.x);
 }

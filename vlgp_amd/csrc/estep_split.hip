@@ -73,8 +73,7 @@ struct SplitArgs {
     int shg_rk[16];            // shared-G launches: rank and compact factor of lat[i] (no table lookups per wave)
     const double* shg_gl[16];
     int lat[16];       // their indices
-    int qblk0[16];     // lane-group factor launch (estep_quad.h): [0] = blocks per latent
-    int xsym;          // 1: the hand-over of this launch's latents holds P = (I + G'WG)^-1 (packed lower), not X = chol^-1
+    int qblk0[16];     // lane-group factor launch (estep_quad.h): first block of latent i of the launch
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -803,19 +802,15 @@ __device__ __forceinline__ void mean_task(const SplitArgs& A, const Task& K, int
     tri_wave_sync();
     double sol = 0.0;
     if (lane < RA) {
-        // A.xsym: the hand-over is P = (I + H)^-1 itself (lane-group factor launch, estep_quad.h), packed lower: the row
-        // part of P c is z, the column part runs over the rows below the diagonal with c instead of z
-        const int xo = A.xsym;
-        const double* src = xo ? vec2 : vec;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int q = 0; q < RA; q += 4) {
-            if (q >= lane + xo) s0 = fma(Xl[tri_row_off(q) + lane], src[q], s0);
-            if (q + 1 >= lane + xo) s1 = fma(Xl[tri_row_off(q + 1) + lane], src[q + 1], s1);
-            if (q + 2 >= lane + xo) s2 = fma(Xl[tri_row_off(q + 2) + lane], src[q + 2], s2);
-            if (q + 3 >= lane + xo) s3 = fma(Xl[tri_row_off(q + 3) + lane], src[q + 3], s3);
+            if (q >= lane) s0 = fma(Xl[tri_row_off(q) + lane], vec[q], s0);
+            if (q + 1 >= lane) s1 = fma(Xl[tri_row_off(q + 1) + lane], vec[q + 1], s1);
+            if (q + 2 >= lane) s2 = fma(Xl[tri_row_off(q + 2) + lane], vec[q + 2], s2);
+            if (q + 3 >= lane) s3 = fma(Xl[tri_row_off(q + 3) + lane], vec[q + 3], s3);
         }
-        sol = (s0 + s1) + (s2 + s3) + (xo ? z : 0.0);
+        sol = (s0 + s1) + (s2 + s3);
     }
     if (lane < RA) vec2[lane] = sol;  // (c was consumed before the previous barrier)
     tri_wave_sync();
@@ -1056,19 +1051,15 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
     tri_wave_sync();
     double sol = 0.0;
     if (lane < RA) {
-        // A.xsym: the hand-over is P = (I + H)^-1 itself (lane-group factor launch, estep_quad.h), packed lower: the row
-        // part of P c is z, the column part runs over the rows below the diagonal with c instead of z
-        const int xo = A.xsym;
-        const double* src = xo ? vec2 : vec;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int q = 0; q < RA; q += 4) {
-            if (q >= lane + xo) s0 = fma(Xl[tri_row_off(q) + lane], src[q], s0);
-            if (q + 1 >= lane + xo) s1 = fma(Xl[tri_row_off(q + 1) + lane], src[q + 1], s1);
-            if (q + 2 >= lane + xo) s2 = fma(Xl[tri_row_off(q + 2) + lane], src[q + 2], s2);
-            if (q + 3 >= lane + xo) s3 = fma(Xl[tri_row_off(q + 3) + lane], src[q + 3], s3);
+            if (q >= lane) s0 = fma(Xl[tri_row_off(q) + lane], vec[q], s0);
+            if (q + 1 >= lane) s1 = fma(Xl[tri_row_off(q + 1) + lane], vec[q + 1], s1);
+            if (q + 2 >= lane) s2 = fma(Xl[tri_row_off(q + 2) + lane], vec[q + 2], s2);
+            if (q + 3 >= lane) s3 = fma(Xl[tri_row_off(q + 3) + lane], vec[q + 3], s3);
         }
-        sol = (s0 + s1) + (s2 + s3) + (xo ? z : 0.0);
+        sol = (s0 + s1) + (s2 + s3);
     }
     tri_wave_sync();
     if (lane < RA) vec2[lane] = sol;
@@ -1737,7 +1728,7 @@ int run_latent_quad(vlgp_ctx* ctx, SplitArgs A) {
     if (A.n_lat == 0 || A.M == 0) return VLGP_OK;
     int rmax = 0;
     for (int i = 0; i < A.n_lat; ++i) rmax = A.shg_rk[i] > rmax ? A.shg_rk[i] : rmax;
-    const int R = rmax <= 20 ? 20 : (rmax <= 24 ? 24 : 32), NL = rmax <= 24 ? 4 : 8;
+    const int R = rmax <= 16 ? 16 : (rmax <= 20 ? 20 : (rmax <= 24 ? 24 : 32)), NL = rmax <= 16 ? 2 : (rmax <= 24 ? 4 : 8);
     const int upb = 4 * (64 / NL);
     A.qblk0[0] = (A.M + upb - 1) / upb;
     const unsigned nb = (unsigned)(A.qblk0[0] * A.n_lat);
@@ -1754,7 +1745,8 @@ int run_latent_quad(vlgp_ctx* ctx, SplitArgs A) {
                                             (int)lds));                                                               \
         hipLaunchKernelGGL(fn, dim3(nb), dim3(256), lds, st, A);                                                      \
     } while (0)
-    if (R == 20) ESPLIT_QUAD(20, 4);
+    if (R == 16) ESPLIT_QUAD(16, 2);
+    else if (R == 20) ESPLIT_QUAD(20, 4);
     else if (R == 24) ESPLIT_QUAD(24, 4);
     else ESPLIT_QUAD(32, 8);
 #undef ESPLIT_QUAD
@@ -1806,9 +1798,8 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
             Ahi.pkl = 0;
         }
         const char* qsw = getenv("VLGP_ESTEP_QUAD");
-        const bool quad = !mix && C.single && C.single_T > 0 && C.single_T <= 64 && !(qsw && qsw[0] == '0');
-        Ahi.xsym = quad ? 1 : 0;
-        if (quad && !mean) {
+        const bool quad = !mean && !mix && C.single && C.single_T > 0 && C.single_T <= 64 && !(qsw && qsw[0] == '0');
+        if (quad) {
             SplitArgs Aq = Ahi;
             for (int i = 0; i < n_hi; ++i) {
                 Aq.shg_rk[i] = C.single->rl[Ahi.lat[i]];
@@ -2007,7 +1998,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     if (C.lds_g_lo < 256) C.lds_g_lo = 256;
     A.lds_g = 256; A.pkl = pkg; A.n_lat = 0;
     A.shg = 0; A.shg_cap = 0; A.shg_T = 0;
-    A.do_v = 0; A.last = 0; A.xsym = 0;
+    A.do_v = 0; A.last = 0;
     *handled = lng ? 2 : 1;
     ctx->last_estep_mix = 0;
     HIPCHK(ctx, hipMemsetAsync(A.failg, 0, sizeof(int) * (size_t)us.M * L, ctx->stream));
