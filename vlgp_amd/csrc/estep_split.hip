@@ -73,7 +73,6 @@ struct SplitArgs {
     int shg_rk[16];            // shared-G launches: rank and compact factor of lat[i] (no table lookups per wave)
     const double* shg_gl[16];
     int lat[16];       // their indices
-    int qblk0[16];     // lane-group factor launch (estep_quad.h): first block of latent i of the launch
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1081,7 +1080,6 @@ __device__ __forceinline__ void mean_task_last(const SplitArgs& A, const Task& K
 }
 
 #include "estep_lane.h"
-#include "estep_quad.h"
 
 // MAXRA: largest register-array size compiled in (16: every latent of the launch has rank <= 16)
 // LASTSW (mean only): the last sweep of the call
@@ -1722,38 +1720,6 @@ int run_latent_mix(vlgp_ctx* ctx, const SplitArgs& Aln, const SplitArgs& Alt, in
     return VLGP_OK;
 }
 
-// factor + variance of the latents at ranks 15 .. 32 with a group of lanes per task (estep_quad.h); `A`: lat / shg_rk /
-// shg_gl / shg_T set for the latents of the launch
-int run_latent_quad(vlgp_ctx* ctx, SplitArgs A) {
-    if (A.n_lat == 0 || A.M == 0) return VLGP_OK;
-    int rmax = 0;
-    for (int i = 0; i < A.n_lat; ++i) rmax = A.shg_rk[i] > rmax ? A.shg_rk[i] : rmax;
-    const int R = rmax <= 16 ? 16 : (rmax <= 20 ? 20 : (rmax <= 24 ? 24 : 32)), NL = rmax <= 16 ? 2 : (rmax <= 24 ? 4 : 8);
-    const int upb = 4 * (64 / NL);
-    A.qblk0[0] = (A.M + upb - 1) / upb;
-    const unsigned nb = (unsigned)(A.qblk0[0] * A.n_lat);
-    const size_t lds = quad_lds_doubles(A.shg_T, R, NL) * 8;
-    if (lds > (size_t)ctx->lds_max)
-        return vlgp_fail(ctx, VLGP_ERR_ARG, "lane-group E-step launch needs %zu bytes of LDS, the device has %d", lds, ctx->lds_max);
-    NEED_LANE(ctx);
-    hipStream_t st = t_lane;
-#define ESPLIT_QUAD(RV, NLV)                                                                                          \
-    do {                                                                                                              \
-        auto fn = esplit_quad<RV, NLV>;                                                                                \
-        if (lds > 64 * 1024)                                                                                          \
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)lds));                                                               \
-        hipLaunchKernelGGL(fn, dim3(nb), dim3(256), lds, st, A);                                                      \
-    } while (0)
-    if (R == 16) ESPLIT_QUAD(16, 2);
-    else if (R == 20) ESPLIT_QUAD(20, 4);
-    else if (R == 24) ESPLIT_QUAD(24, 4);
-    else ESPLIT_QUAD(32, 8);
-#undef ESPLIT_QUAD
-    HIPCHK(ctx, hipGetLastError());
-    return VLGP_OK;
-}
-
 // long units: one workgroup per (unit, latent)
 int run_latent_long(vlgp_ctx* ctx, const SplitArgs& A, bool mean) {
     const unsigned tasks = (unsigned)(A.M * A.L);
@@ -1797,19 +1763,7 @@ int run_latent(vlgp_ctx* ctx, SplitArgs A, const LatentClasses& C, bool mean) {
             Ahi.lds_g = maxra_hi * (maxra_hi + 2);
             Ahi.pkl = 0;
         }
-        const char* qsw = getenv("VLGP_ESTEP_QUAD");
-        const bool quad = !mean && !mix && C.single && C.single_T > 0 && C.single_T <= 64 && !(qsw && qsw[0] == '0');
-        if (quad) {
-            SplitArgs Aq = Ahi;
-            for (int i = 0; i < n_hi; ++i) {
-                Aq.shg_rk[i] = C.single->rl[Ahi.lat[i]];
-                Aq.shg_gl[i] = C.single->d_compact + C.single->goff[Ahi.lat[i]];
-            }
-            Aq.shg_T = C.single_T;
-            CHK(run_latent_quad(ctx, Aq));
-        } else if (!mix) {
-            CHK(run_latent_class(ctx, Ahi, maxra_hi, mean));
-        }
+        if (!mix) CHK(run_latent_class(ctx, Ahi, maxra_hi, mean));
     }
     if (C.n_ln) {
         // ONE launch for all of them, the highest ranks first in the grid (their workgroups live longest)
