@@ -1191,7 +1191,10 @@ __device__ __forceinline__ void ltile_of(int tile, int& bi, int& bj) {  // lower
 // load -> multiply chain at two waves per SIMD, the register budget of the wave that factors).  (Measured alternatives at C3, 1000 tasks: the three phases as three launches with
 // the matrix through global memory -- lighter waves for the build and the variance -- 180 + 34 + 155 us against 320 us
 // for one kernel; the build's loads software-pipelined one step ahead of its matrix instructions: no change.)
-__global__ void __launch_bounds__(256, 4) elong_factor(SplitArgs A) {
+#ifndef ELONG_LB
+#define ELONG_LB 4
+#endif
+__global__ void __launch_bounds__(256, ELONG_LB) elong_factor(SplitArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Xp = smem;            // LPK
     double* red = smem + LPK;     // LRED: the second half's tiles (6 x 256), then its tail rows (2 x 2 x 64)

@@ -945,8 +945,11 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
 // (four waves per SIMD up to class 24: since phase 3 takes one kind of tiles at a time the class fits 128 registers
 // without scratch; ranks up to 20 then have four workgroups per CU -- their LDS allows it -- and two instead of one fit
 // beside a workgroup of the M-step lane.  Same box: 139.0 against 137.7 EM it/s.)
+#ifndef HLR64_LB
+#define HLR64_LB 4
+#endif
 template <int T, int NW, int RC, bool TABG = false>
-__global__ void __launch_bounds__(64 * NW, RC <= 24 ? 4 : 3) hstep_round_lr(HRoundArgs R) {
+__global__ void __launch_bounds__(64 * NW, RC <= 24 ? (T == 64 ? HLR64_LB : 4) : 3) hstep_round_lr(HRoundArgs R) {
     hstep_wave_prio(R.prio);
     constexpr bool ONESET = T == 50;
     constexpr int NK = T == 50 ? 7 : 8;
