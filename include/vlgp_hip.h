@@ -189,6 +189,12 @@ int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const doubl
 /* out[0] = sum mu^2, out[1] = sum dmu^2 over the set (and over ranks):
  * the convergence test of core.vem (vlgp/core.py:300-305,350-354). */
 int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]);
+/* The same in two halves: vlgp_norms_begin enqueues the sums behind everything already queued and returns;
+ * vlgp_norms_end waits for them.  core.vem takes the norms after the M- and H-step (vlgp/core.py:350-354), but mu
+ * and dmu are final once the E-step (and constrain_latent) are done: begun there, the pass runs beside the H-step
+ * rounds instead of behind them.  Every entry point that writes unit state waits for a pending pass first. */
+int vlgp_norms_begin(vlgp_ctx* ctx, int set);
+int vlgp_norms_end(vlgp_ctx* ctx, double out[2]);
 /* Initial latents of preprocess.initialize (vlgp/preprocess.py:30-41) on the device: for every row of the
  * set mu = y . proj - shift, proj (N, L) row-major the posterior-mean map of the factor-analysis fit
  * (FactorAnalysis.transform: (y - mean) W'Psi^-1 (I + W Psi^-1 W')^-1), shift = mean . proj (L).

@@ -121,6 +121,88 @@ def test_ichol_golden_bitwise(V, golden):
         assert rk[0] == int((np.abs(G).sum(0) > 0).sum())
 
 
+def test_ichol_one_wave_kernel_equals_block_kernel_and_oracle_bitwise(V, monkeypatch):
+    """Unit lengths of at most 64 bins (the windows of vem) are factored by one wave per latent
+    (ichol_exact_wave_kernel); VLGP_ICHOL_BLOCK=1 sends them through the workgroup kernel of the long lengths.  Every
+    length 2 ... 64, ranks below, at and above the length, smooth to white kernels: the two and the oracle
+    (math.ichol_gauss, vlgp/math.py:76-126) agree bit for bit, ranks included."""
+    rng = np.random.default_rng(11)
+    for T in list(range(2, 65)):
+        for R in sorted({max(1, T // 2), min(50, T + 3), 64}):
+            om = np.exp(rng.uniform(np.log(1e-5), np.log(8.0), 3))
+            sg = 0.5 + rng.random(3)
+            got = []
+            for block in (False, True):
+                if block:
+                    monkeypatch.setenv("VLGP_ICHOL_BLOCK", "1")
+                with V.Engine(4, 3, 1, R) as eng:
+                    eng.build_prior([T], om, sg)
+                    got.append(eng.get_prior(T, with_rank=True))
+                monkeypatch.delenv("VLGP_ICHOL_BLOCK", raising=False)
+            assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), (T, R)
+            for l in range(3):
+                Go = O.ichol_gauss(T, om[l], R) * sg[l]
+                assert np.array_equal(got[0][0][l], Go), (T, R, om[l])
+                assert got[0][1][l] == int((np.abs(Go).sum(0) > 0).sum())
+
+
+def test_iteration_tail_entry_points(V):
+    """The pieces of an EM iteration's tail that no longer wait for the device: vlgp_norms_begin / _end (the sums of the
+    stopping rule, vlgp/core.py:350-354, on their own stream) against vlgp_norms; vlgp_set_params and
+    vlgp_apply_latent_map staged without a stream synchronisation (back-to-back calls reuse the staging buffers);
+    the parameter snapshot the M-step lane leaves for vlgp_get_params, and what invalidates it."""
+    rng = np.random.default_rng(5)
+    N, L, T, M = 30, 4, 50, 600
+    a = 0.3 * rng.standard_normal((L, N))
+    b = np.log(0.4) + 0.1 * rng.standard_normal((1, N))
+    y = rng.poisson(0.5, (M, T, N)).astype(float)
+    mu = 0.3 * rng.standard_normal((M, T, L))
+    with V.Engine(N, L, 1, 50) as eng:
+        eng.set_params(a, b, np.ones(N))
+        eng.upload(0, [{"y": y[m], "mu": mu[m]} for m in range(M)])
+        eng.build_prior([T], np.array([1e-2, 3e-3, 2e-2, 5e-3]), np.ones(L))
+        eng.update_w(0)
+        eng.update_v(0)
+        eng.estep(0, 3)
+        ref = eng.norms(0)
+        eng.norms_begin(0)
+        assert eng.norms_end() == ref
+        with pytest.raises(V.VlgpError):
+            eng.norms_end()  # nothing pending
+        eng.norms_begin(0)
+        eng.norms_begin(0)  # the first pass is dropped
+        assert eng.norms_end() == ref
+        # a writer of unit state waits for a pending pass; the pass saw the state before it
+        eng.norms_begin(0)
+        eng.apply_latent_map(0, np.diag([2.0, 1.0, 0.5, 1.0]))
+        eng.apply_latent_map(0, np.diag([0.5, 1.0, 2.0, 1.0]), np.zeros(L))  # back to back: the staging buffer is reused
+        assert eng.norms_end() == ref
+        got = eng.download(0, keys=("mu",))["mu"]
+        # parameters: set twice back to back, the second wins; then the M-step's snapshot
+        eng.set_params(a + 1.0, b, np.ones(N))
+        eng.set_params(a, b - 0.5, 2 * np.ones(N))
+        a1, b1, n1, _, _ = eng.get_params()
+        assert np.array_equal(a1, a) and np.array_equal(b1, b - 0.5) and np.array_equal(n1, 2 * np.ones(N))
+        eng.set_params(a, b, np.ones(N))
+        eng.mstep_begin(0, 3)
+        bad, _ = eng.mstep_end()
+        snap = eng.get_params()  # from the lane's pinned snapshot
+        assert bad == 0 and not np.array_equal(snap[0], a)
+        eng.set_loading(snap[0] * 2.0)  # invalidates it: the next pull reads the device
+        a2, b2, _, da2, _ = eng.get_params()
+        assert np.array_equal(a2, snap[0] * 2.0) and np.array_equal(b2, snap[1]) and np.array_equal(da2, snap[3])
+    # the two latent maps composed: columns 0 and 2 scaled by 2 * 0.5 and 0.5 * 2
+    with V.Engine(N, L, 1, 50) as eng:
+        eng.set_params(a, b, np.ones(N))
+        eng.upload(0, [{"y": y[m], "mu": mu[m]} for m in range(M)])
+        eng.build_prior([T], np.array([1e-2, 3e-3, 2e-2, 5e-3]), np.ones(L))
+        eng.update_w(0)
+        eng.update_v(0)
+        eng.estep(0, 3)
+        plain = eng.download(0, keys=("mu",))["mu"]
+    assert np.allclose(got, plain, rtol=1e-15, atol=0)
+
+
 def test_ichol_device_vs_oracle_bitwise(V):
     """Several latents and lengths per call, sigma != 1, ranks, the compact copy's consumers (update_v)."""
     rng = np.random.default_rng(3)

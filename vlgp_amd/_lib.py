@@ -78,6 +78,8 @@ _SIGNATURES = {
     "vlgp_set_overlaps": (C.c_int, [_h, C.c_int, C.c_int, _ip, C.c_int, _ip, _ip]),
     "vlgp_unshare_mu": (C.c_int, [_h, C.c_int]),
     "vlgp_norms": (C.c_int, [_h, C.c_int, _dp]),
+    "vlgp_norms_begin": (C.c_int, [_h, C.c_int]),
+    "vlgp_norms_end": (C.c_int, [_h, _dp]),
     "vlgp_latent_moments": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "vlgp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "vlgp_comm_init": (C.c_int, [_h, C.c_char_p, C.c_int, C.c_int]),

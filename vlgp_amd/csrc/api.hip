@@ -63,6 +63,8 @@ int vlgp_ensure_work_m(vlgp_ctx* ctx, int64_t n) {
 }
 
 int vlgp_join_m(vlgp_ctx* ctx) {
+    // a pending norms pass (vlgp_norms_begin) reads mu, v, dmu on its own stream: the same callers wait for it
+    if (ctx->x_pending == 1) HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));
     if (!ctx->m_pending) return VLGP_OK;
     HIPCHK(ctx, hipEventSynchronize(ctx->ev_m_done));  // m_pending is cleared by vlgp_mstep_end
     return VLGP_OK;
@@ -569,6 +571,16 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
         if (ctx->elane[i]) (void)hipStreamDestroy(ctx->elane[i]);
     }
     if (ctx->mstream) (void)hipStreamDestroy(ctx->mstream); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
+    if (ctx->xstream) { (void)hipStreamSynchronize(ctx->xstream); (void)hipStreamDestroy(ctx->xstream); }
+    if (ctx->ev_x_fork) (void)hipEventDestroy(ctx->ev_x_fork);
+    if (ctx->ev_x_done) (void)hipEventDestroy(ctx->ev_x_done);
+    if (ctx->ev_stage_par) (void)hipEventDestroy(ctx->ev_stage_par);
+    if (ctx->ev_stage_map) (void)hipEventDestroy(ctx->ev_stage_map);
+    fr(ctx->d_xwork); fr(ctx->d_stage_map);
+    if (ctx->h_xres) (void)hipHostFree(ctx->h_xres);
+    if (ctx->h_msnap) (void)hipHostFree(ctx->h_msnap);
+    if (ctx->h_stage_par) (void)hipHostFree(ctx->h_stage_par);
+    if (ctx->h_stage_map) (void)hipHostFree(ctx->h_stage_map);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_hres) (void)hipHostFree(ctx->h_hres);
     if (ctx->h_prior_mb) (void)hipHostFree(ctx->h_prior_mb);
@@ -750,11 +762,33 @@ extern "C" int vlgp_free_units(vlgp_ctx* ctx, int set) {
 extern "C" int vlgp_set_params(vlgp_ctx* ctx, const double* a, const double* b, const double* noise) {
     NEED_CTX(ctx);
     CHK(vlgp_join_m(ctx));
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
     const int N = ctx->N, L = ctx->L, P = ctx->P;
-    if (a) HIPCHK(ctx, hipMemcpyAsync(ctx->d_a, a, sizeof(double) * L * N, hipMemcpyHostToDevice, ctx->stream));
-    if (b) HIPCHK(ctx, hipMemcpyAsync(ctx->d_b, b, sizeof(double) * P * N, hipMemcpyHostToDevice, ctx->stream));
-    if (noise) HIPCHK(ctx, hipMemcpyAsync(ctx->d_noise, noise, sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // through a pinned buffer of its own: the copies are truly asynchronous and nothing waits for them here (the E-step's
+    // launches follow on the same stream); the buffer is reused only after the event behind the last copy has fired
+    if (!ctx->h_stage_par) {
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage_par, sizeof(double) * ((size_t)(L + P) * N + N), hipHostMallocDefault));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_stage_par, hipEventDisableTiming));
+    }
+    if (ctx->stage_par_busy) HIPCHK(ctx, hipEventSynchronize(ctx->ev_stage_par));
+    double* ha = ctx->h_stage_par;
+    double* hb = ha + (size_t)L * N;
+    double* hn = hb + (size_t)P * N;
+    if (a) {
+        memcpy(ha, a, sizeof(double) * L * N);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_a, ha, sizeof(double) * L * N, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (b) {
+        memcpy(hb, b, sizeof(double) * P * N);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_b, hb, sizeof(double) * P * N, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (noise) {
+        memcpy(hn, noise, sizeof(double) * N);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_noise, hn, sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_stage_par, ctx->stream));
+    ctx->stage_par_busy = true;
+    ctx->msnap_valid = false;
     if (a && b && noise) ctx->have_params = true;
     return VLGP_OK;
 }
@@ -763,6 +797,16 @@ extern "C" int vlgp_get_params(vlgp_ctx* ctx, double* a, double* b, double* nois
     NEED_CTX(ctx);
     CHK(vlgp_join_m(ctx));
     const int N = ctx->N, L = ctx->L, P = ctx->P;
+    if (ctx->msnap_valid) {  // the M-step lane left them in pinned memory behind its last kernel (vlgp_mstep_begin)
+        const double* h = ctx->h_msnap;
+        const size_t ln[5] = {(size_t)L * N, (size_t)P * N, (size_t)N, (size_t)L * N, (size_t)P * N};
+        double* out[5] = {a, b, noise, da, db};
+        for (int i = 0; i < 5; ++i) {
+            if (out[i]) memcpy(out[i], h, sizeof(double) * ln[i]);
+            h += ln[i];
+        }
+        return VLGP_OK;
+    }
     // five small copies into pageable memory are five synchronous staged transfers (~90 us per EM iteration): gather
     // them in the pinned buffer with truly asynchronous copies, one synchronisation, then hand them out
     double* dst[5] = {a, b, noise, da, db};
@@ -1093,8 +1137,23 @@ extern "C" int vlgp_mstep_begin(vlgp_ctx* ctx, int set, int n_iter, int use_hess
     HIPCHK(ctx, hipStreamWaitEvent(ctx->mstream, ctx->ev_fork, 0));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_fail_m, 0, sizeof(int), ctx->mstream));
     HIPCHK(ctx, hipEventRecord(ctx->ev_m_start, ctx->mstream));
+    ctx->msnap_valid = false;
     if (n_iter >= 1)  // core.py:131-133
         CHK(launch_mstep(ctx, *us, n_iter, use_hessian, eps, lr, da_bound, db_bound));
+    {   // what the caller pulls afterwards (vlgp_get_params, the failure count), copied out by the lane itself
+        const int N = ctx->N, L = ctx->L, P = ctx->P;
+        const size_t ln[5] = {(size_t)L * N, (size_t)P * N, (size_t)N, (size_t)L * N, (size_t)P * N};
+        const double* src[5] = {ctx->d_a, ctx->d_b, ctx->d_noise, ctx->d_da, ctx->d_db};
+        if (!ctx->h_msnap)
+            HIPCHK(ctx, hipHostMalloc(&ctx->h_msnap, sizeof(double) * (2 * (size_t)(L + P) * N + N + 8), hipHostMallocDefault));
+        double* h = ctx->h_msnap;
+        for (int i = 0; i < 5; ++i) {
+            HIPCHK(ctx, hipMemcpyAsync(h, src[i], sizeof(double) * ln[i], hipMemcpyDeviceToHost, ctx->mstream));
+            h += ln[i];
+        }
+        HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_fail_m, sizeof(int), hipMemcpyDeviceToHost, ctx->mstream));
+        ctx->msnap_valid = true;  // (read only after vlgp_join_m; any vlgp_set_params in between clears it)
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev_m_done, ctx->mstream));
     // NO device-side join here: the H-step rounds and the prior rebuild queued on the main stream meanwhile
     // touch neither a, b nor anything the M-step writes, and every entry point that does joins on the host
@@ -1114,7 +1173,14 @@ extern "C" int vlgp_mstep_end(vlgp_ctx* ctx, int* n_failed, double* device_ms) {
         ctx->last_m_ms = ms;  // (vlgp_hstep_begin weighs it against the H-step bracket's duration)
         if (device_ms) *device_ms = ms;
     }
-    if (n_failed) HIPCHK(ctx, hipMemcpy(n_failed, ctx->d_fail_m, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_failed) {
+        if (ctx->msnap_valid) {
+            const int N = ctx->N, L = ctx->L, P = ctx->P;
+            memcpy(n_failed, ctx->h_msnap + 2 * (size_t)(L + P) * N + N, sizeof(int));
+        } else {
+            HIPCHK(ctx, hipMemcpy(n_failed, ctx->d_fail_m, sizeof(int), hipMemcpyDeviceToHost));
+        }
+    }
     return VLGP_OK;
 }
 
@@ -1169,16 +1235,25 @@ extern "C" int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, 
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us || !map) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad latent map arguments");
     const int L = ctx->L;
-    CHK(vlgp_ensure_work(ctx, L * L + L + 8));
-    CHK(vlgp_ensure_pinned(ctx, L * L + L + 8));
-    memcpy(ctx->h_pinned, map, sizeof(double) * L * L);
-    if (shift) memcpy(ctx->h_pinned + L * L, shift, sizeof(double) * L);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_pinned, sizeof(double) * (L * L + L), hipMemcpyHostToDevice, ctx->stream));
-    CHK(launch_latent_map(ctx, *us, ctx->d_work, shift ? ctx->d_work + L * L : nullptr));
+    // staged through a pinned and a device buffer of its own, reused after the event behind the last kernel that read
+    // them: nothing waits here (this is the first call of every EM iteration, constrain_loading)
+    if (!ctx->h_stage_map) {
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage_map, sizeof(double) * (L * L + L + 8), hipHostMallocDefault));
+        HIPCHK(ctx, hipMalloc(&ctx->d_stage_map, sizeof(double) * (L * L + L + 8)));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_stage_map, hipEventDisableTiming));
+    }
+    if (ctx->stage_map_busy) HIPCHK(ctx, hipEventSynchronize(ctx->ev_stage_map));
+    memcpy(ctx->h_stage_map, map, sizeof(double) * L * L);
+    if (shift) memcpy(ctx->h_stage_map + L * L, shift, sizeof(double) * L);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage_map, ctx->h_stage_map, sizeof(double) * (L * L + L), hipMemcpyHostToDevice, ctx->stream));
+    const double* d_map = ctx->d_stage_map;
+    const double* d_shift = shift ? ctx->d_stage_map + L * L : nullptr;
+    CHK(launch_latent_map(ctx, *us, d_map, d_shift));
     // the set's units are independent copies: an IN-PLACE constraint of the reference (everything but "svd", which
     // rebinds mu) visits a row shared by two overlapping segments twice -- the caller says so with vlgp_unshare_mu
-    CHK(launch_links_map(ctx, *us, ctx->d_work, shift ? ctx->d_work + L * L : nullptr));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // workspace and pinned buffer are reused
+    CHK(launch_links_map(ctx, *us, d_map, d_shift));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_stage_map, ctx->stream));
+    ctx->stage_map_busy = true;
     return VLGP_OK;
 }
 
@@ -1205,6 +1280,52 @@ extern "C" int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]) {
     for (int l = 0; l < L; ++l) s += m[t + 2 * L + l];
     out[0] = s;
     out[1] = m[t + 3 * L];
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_norms_begin(vlgp_ctx* ctx, int set) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    if (ctx->x_pending == 1) HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));  // never collected: dropped
+    ctx->x_pending = 0;
+    ctx->x_set = set;
+    if (ctx->world > 1) {  // the sums cross ranks on the main lane's communicator: computed when they are collected
+        ctx->x_pending = 2;
+        return VLGP_OK;
+    }
+    const int L = ctx->L, K = L * (L + 1) / 2 + 3 * L + 1;
+    if (!ctx->xstream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_x_fork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_x_done, hipEventDisableTiming));
+        HIPCHK(ctx, hipMalloc(&ctx->d_xwork, sizeof(double) * (257 * (size_t)K + 64)));
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_xres, sizeof(double) * (K + 8), hipHostMallocDefault));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_x_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->xstream, ctx->ev_x_fork, 0));
+    CHK(launch_moments_on(ctx, *us, ctx->xstream, ctx->d_xwork + K + 64, ctx->d_xwork));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_xres, ctx->d_xwork, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->xstream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_x_done, ctx->xstream));
+    ctx->x_pending = 1;
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_norms_end(vlgp_ctx* ctx, double out[2]) {
+    NEED_CTX(ctx);
+    if (!ctx->x_pending) return vlgp_fail(ctx, VLGP_ERR_STATE, "no norms pass pending (vlgp_norms_begin)");
+    if (ctx->x_pending == 2) {
+        ctx->x_pending = 0;
+        return vlgp_norms(ctx, ctx->x_set, out);
+    }
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));
+    ctx->x_pending = 0;
+    const int L = ctx->L, t = L * (L + 1) / 2;
+    double s = 0.0;
+    for (int l = 0; l < L; ++l) s += ctx->h_xres[t + 2 * L + l];
+    out[0] = s;
+    out[1] = ctx->h_xres[t + 3 * L];
     return VLGP_OK;
 }
 

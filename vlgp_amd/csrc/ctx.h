@@ -165,6 +165,25 @@ struct vlgp_ctx {
     int last_estep_mix = 0;       // that call ran mixed lane-per-task / wave-per-task launches (esplit_mix)
     int lds_max = 64 * 1024;      // hipDeviceAttributeMaxSharedMemoryPerBlock (gfx950: 160 KB)
 
+    // Pieces of an EM iteration's tail taken off its critical path (api.hip):
+    // (1) the norms of mu, dmu for the stopping rule run beside the H-step rounds on their own stream
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_x_fork = nullptr, ev_x_done = nullptr;
+    double* d_xwork = nullptr;    // K moments | 256 K partials
+    double* h_xres = nullptr;     // pinned, K moments
+    int x_pending = 0;            // 1: in flight on xstream, 2: deferred to vlgp_norms_end (several ranks)
+    int x_set = -1;
+    // (2) the M-step lane leaves a, b, noise, da, db and its failure count in pinned memory behind its last kernel
+    double* h_msnap = nullptr;
+    bool msnap_valid = false;
+    // (3) vlgp_set_params / vlgp_apply_latent_map stage through their own pinned (and device) buffers, reuse guarded by
+    // an event: no stream synchronisation in front of the E-step's first launch
+    double* h_stage_par = nullptr;
+    double* h_stage_map = nullptr;
+    double* d_stage_map = nullptr;
+    hipEvent_t ev_stage_par = nullptr, ev_stage_map = nullptr;
+    bool stage_par_busy = false, stage_map_busy = false;
+
     std::string err;
 };
 
@@ -224,6 +243,8 @@ int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const dou
 int launch_links_copy(vlgp_ctx* ctx, UnitSet& us, int l0, int l1, int dir);
 int launch_links_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
 int launch_moments(vlgp_ctx* ctx, UnitSet& us);  // tri(L) gram | sum mu | sum v | sum mu^2 | |dmu|^2 at ctx->d_work
+// the same sums of THIS rank's rows on any stream with the caller's buffers (d_out: K = tri(L) + 3 L + 1, d_partial: 256 K)
+int launch_moments_on(vlgp_ctx* ctx, UnitSet& us, hipStream_t st, double* d_partial, double* d_out);
 int launch_project(vlgp_ctx* ctx, UnitSet& us, const double* d_proj, const double* d_shift, double* d_part,
                    double* d_out);  // mu = y proj - shift; d_out = column sums of y
 int launch_gather(vlgp_ctx* ctx, UnitSet& src, UnitSet& dst, int window);

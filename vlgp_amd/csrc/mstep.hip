@@ -947,9 +947,8 @@ static void launch_lat_t(hipStream_t st, int G, int L, int64_t rows, const doubl
 }
 
 // d_out: tri(L) gram | L sum_mu | L sum_v | L sum_mu^2 | 1 |dmu|^2 ; all-reduced over ranks
-static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double* d_out, bool mlane) {
+static int latent_moments_st(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double* d_out, hipStream_t st) {
     const int L = ctx->L;
-    hipStream_t st = mlane ? ctx->mstream : ctx->stream;
     int G = (int)((us.rows + 255) / 256);
     if (G > 256) G = 256;
     if (G < 1) G = 1;
@@ -967,7 +966,15 @@ static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double*
     hipLaunchKernelGGL(sum_partials_kernel, dim3((K + 63) / 64), dim3(512), 0, st, d_partial, G,
                        (int64_t)K, d_out);
     HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double* d_out, bool mlane) {
+    CHK(latent_moments_st(ctx, us, d_partial, d_out, mlane ? ctx->mstream : ctx->stream));
+    const int K = tri(ctx->L) + 3 * ctx->L + 1;
     return mlane ? vlgp_allreduce_m(ctx, d_out, K) : vlgp_allreduce(ctx, d_out, K);
+}
+int launch_moments_on(vlgp_ctx* ctx, UnitSet& us, hipStream_t st, double* d_partial, double* d_out) {
+    return latent_moments_st(ctx, us, d_partial, d_out, st);
 }
 
 // result (K doubles, all-reduced) is left at the head of ctx->d_work; the partials use its tail.  The

@@ -211,6 +211,96 @@ __global__ void __launch_bounds__(NT) ichol_exact_kernel(IcholArgs A) {
     }
 }
 
+// The same factorisation for unit lengths of at most 64 bins (the windows of vem: one call per EM iteration, on the
+// critical path between the H-step's last round and the next E-step): ONE wave per latent, lane <-> permuted position,
+// the factor, the residuals and the permutation in LDS, no workgroup barrier and no single-thread section -- the
+// residual sum is one leaf of NumPy's pairwise recursion (ich_leaf8 by every group of eight lanes at once), the
+// arg-max a butterfly that leaves the first maximum on every lane.  Same primitives in the same order as the kernel
+// above: the same bits (tests/test_gpu_parity.py::test_ichol_*).  RS: row stride of the LDS copy (odd: no bank runs).
+__global__ void __launch_bounds__(64) ichol_exact_wave_kernel(IcholArgs A, int RS) {
+    extern __shared__ __attribute__((aligned(16))) char ich_smem[];
+    const int l = blockIdx.x, lane = threadIdx.x;
+    const int T = A.T, R = A.R;
+    double* Gs = reinterpret_cast<double*>(ich_smem);   // (T, RS)
+    double* d = Gs + (int64_t)T * RS;                   // 64
+    double* kv = d + 64;                                // 64
+    int* piv = reinterpret_cast<int*>(kv + 64);         // 64
+
+    const double om = A.omega[l];
+    const double tol_n = 1e-6 * (double)T;
+    for (int e = lane; e < T * RS; e += 64) Gs[e] = 0.0;
+    if (lane < T) {
+        d[lane] = 1.0;
+        piv[lane] = lane;
+        const double dx = (double)lane;
+        kv[lane] = npx_exp(-om * (dx * dx));
+    }
+    __syncthreads();
+
+    int i = 0;
+    for (; i < R; ++i) {
+        const int n = T - i;
+        if (n <= 0) break;  // (np.sum of nothing is 0.0: not above the tolerance)
+        const double total = 0.0 + ich_leaf8(d + i, n, lane & 7, lane & ~7);
+        if (!(total > tol_n)) break;
+        int jast = 0;
+        if (i > 0) {
+            double best = -INFINITY;
+            int bi = 0x7fffffff;
+            if (lane >= i && lane < T) { best = d[lane]; bi = lane; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            jast = bi;
+        }
+        const double pivot = sqrt(d[jast]);
+        const int rowi = piv[jast], rowo = piv[i];
+        __syncthreads();  // every lane has read d[jast], piv[] before they change
+        if (lane == 0) {
+            piv[i] = rowi;
+            piv[jast] = rowo;
+            Gs[rowi * RS + i] = pivot;
+        }
+        __syncthreads();
+        const int mo = n - 1;
+        if (lane < mo) {
+            const int p = i + 1 + lane, row = piv[p];
+            const int dist = row > rowi ? row - rowi : rowi - row;
+            d[p] = npx_ichol_row(Gs + row * RS, Gs + rowi * RS, i, lane, mo, kv[dist], pivot);
+        }
+        __syncthreads();
+    }
+    const int rank = i;
+    {
+        const double sg = A.sigma[l];
+        double* G = A.full + (int64_t)l * T * R;
+        double* C = A.compact + (int64_t)l * T * R;
+        for (int e = lane; e < T * R; e += 64) {
+            const int row = e / R, c = e - row * R;
+            const double v = Gs[row * RS + c] * sg;
+            G[e] = v;
+            if (c < rank) C[row * rank + c] = v;
+        }
+    }
+    if (lane == 0) {
+        if (A.rl_table) A.rl_table[l] = rank;
+        __hip_atomic_store(A.rank_dev + l, rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)A.L - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int q = 0; q < A.L; ++q)
+                A.rank_host[q] = __hip_atomic_load(A.rank_dev + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(A.flag_host, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // number of leading columns up to the last non-zero one, per latent (host-injected factors)
 __global__ void __launch_bounds__(256) prior_rank_kernel(int T, int R, const double* G, int* rank_out) {
     __shared__ int s_r;
@@ -301,7 +391,11 @@ int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double
             const int NL = ICH_LEAVES(pr.T);
             const size_t lds = 8 * (size_t)(16 + NL + (in_lds ? 2 * pr.T : 0)) + 4 * (size_t)(24 + 2 * NL + (in_lds ? pr.T : 0)) + 16;
             vlgp_prof_begin(ctx, VLGP_PROF_PRIOR);
-            if (pr.T <= 64) CHK(launch_ichol_t<64>(ctx, A, lds));
+            const int RS = R | 1;
+            const size_t lds_wave = 8 * ((size_t)pr.T * RS + 128) + 4 * 64;
+            if (pr.T <= 64 && lds_wave <= 60 * 1024 && !getenv("VLGP_ICHOL_BLOCK")) {
+                hipLaunchKernelGGL(ichol_exact_wave_kernel, dim3(L), dim3(64), lds_wave, ctx->stream, A, RS);
+            } else if (pr.T <= 64) CHK(launch_ichol_t<64>(ctx, A, lds));
             else if (pr.T <= 512) CHK(launch_ichol_t<256>(ctx, A, lds));
             else CHK(launch_ichol_t<1024>(ctx, A, lds));
             vlgp_prof_end(ctx, VLGP_PROF_PRIOR, (double)L);

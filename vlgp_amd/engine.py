@@ -326,6 +326,15 @@ class Engine:
         self._ck(self.lib.vlgp_norms(self.h, set_id, dptr(out)))
         return float(np.sqrt(out[0])), float(np.sqrt(out[1]))
 
+    def norms_begin(self, set_id):
+        """Enqueue the norms of mu, dmu (they run beside whatever follows on the main stream); norms_end collects."""
+        self._ck(self.lib.vlgp_norms_begin(self.h, set_id))
+
+    def norms_end(self):
+        out = np.empty(2)
+        self._ck(self.lib.vlgp_norms_end(self.h, dptr(out)))
+        return float(np.sqrt(out[0])), float(np.sqrt(out[1]))
+
     def latent_moments(self, set_id):
         s1, s2 = np.empty(self.L), np.empty(self.L)
         cnt = C.c_double(0)
@@ -817,6 +826,10 @@ def em_iteration(trials, params, config, runtime, echo=None):
     eng.synchronize(main_only=True)   # the E-step; the M-step lane is not waited for
     t1 = time.perf_counter()
     constrain_latent(trials, params, config)
+    # mu and dmu are final from here on (the M-step writes a, b; the H-step omega): the sums of the stopping rule
+    # (core.py:350-354) are enqueued now and run beside the H-step rounds instead of behind them
+    eng.norms_begin(sid)
+    norms_epoch = eng.state_epoch
     if m_async and not early_m:
         begin_m()
 
@@ -850,6 +863,7 @@ def em_iteration(trials, params, config, runtime, echo=None):
         echo("Iteration {:4d}, E-step {:.2f}s, M-step {:.2f}s".format(
             runtime["it"], runtime["e_elapsed"][-1], runtime["m_elapsed"][-1]))
 
+    norm_mu_now, norm_dmu = eng.norms_end()
     if config["callbacks"]:
         trials.pull()
         for cb in config["callbacks"]:
@@ -857,8 +871,8 @@ def em_iteration(trials, params, config, runtime, echo=None):
                 cb(trials, params, config)
             except RuntimeError:
                 logger.error("Callback {} failed".format(cb))
-
-    norm_mu_now, norm_dmu = eng.norms(sid)
+        if eng.state_epoch != norms_epoch:  # a callback changed the units: the reference takes the norms after it
+            norm_mu_now, norm_dmu = eng.norms(sid)
     trials._norm_cache = ((eng.state_epoch, sid), norm_mu_now)
     converged = (norm_dmu < tol * norm_mu
                  and np.linalg.norm(params["da"]) < tol * norm_a
