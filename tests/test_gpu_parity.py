@@ -494,6 +494,30 @@ def test_mstep_random_vs_oracle(V):
         assert relerr(params[k], r) < STAGE, k
 
 
+@pytest.mark.parametrize("L,P,generic", [(5, 1, False), (3, 3, False), (8, 2, True)])
+def test_noise_from_sufficient_statistics_vs_two_passes_and_oracle(V, L, P, generic, monkeypatch):
+    """Sets without Gaussian channels take noise = var(y - eta) (vlgp/core.py:177) from sums the M-step holds anyway
+    (y'y, 1'y, 1'x beside mu'y, x'y, x'mu, x'x and the moments of mu: noise_stats_kernel) instead of two more passes over
+    y; VLGP_NOISE_PASSES=1 keeps the passes.  The two agree to rounding (1e-12), both with the oracle (1e-9), a / b bit for
+    bit; regressors and the loop-based kernels included."""
+    if generic:
+        monkeypatch.setenv("VLGP_MSTEP_GENERIC", "1")
+    out = []
+    for passes in (False, True):
+        rng = np.random.default_rng(300 + L + P)
+        units, params, gauss = _random_problem(rng, [50, 120, 64, 50, 50, 77], 45, L, P, 0)
+        if passes:
+            monkeypatch.setenv("VLGP_NOISE_PASSES", "1")
+        cat = lambda k: np.concatenate([u[k] for u in units], axis=0)
+        want = O.mstep_arrays(cat("y"), cat("x"), cat("mu"), cat("v"), params["a"], params["b"], gauss, 4)
+        V.mstep(units, params, V.get_config(Mniter=4))
+        monkeypatch.delenv("VLGP_NOISE_PASSES", raising=False)
+        assert relerr(params["noise"], want[4]) < STAGE
+        out.append((params["a"].copy(), params["b"].copy(), params["noise"].copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert relerr(out[0][2], out[1][2]) < 1e-12
+
+
 @pytest.mark.parametrize("tag", ["p1", "p3", "mixed"])
 def test_mstep_golden_through_the_loop_based_kernels(V, golden, tag, monkeypatch):
     """The M-step fallback for more than 16 latents / 8 regressors (mstep_cache_gen, mstep_accum_gen, latent_moments_gen,

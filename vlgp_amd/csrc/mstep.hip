@@ -50,13 +50,13 @@ struct MArgs {
 __host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
 template <int LT, int PT, int KIND>
 __host__ __device__ constexpr int nacc() {
-    return KIND == K_PREP ? LT + PT + PT * LT + tri(PT)
+    return KIND == K_PREP ? LT + PT + PT * LT + tri(PT) + 2 + PT
          : KIND == K_NEWTON ? 2 * LT + tri(LT) + PT + tri(PT)
          : 1;
 }
 // runtime (exact L, P) number of statistics per channel
 static inline int nstat_rt(int L, int P, int kind) {
-    return kind == K_PREP ? L + P + P * L + tri(P) : kind == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+    return kind == K_PREP ? L + P + P * L + tri(P) + 2 + P : kind == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
 }
 
 // EXACT: L == LT, P == PT and x == 1 known at compile time -- the common case (3, 5, 8, 10 latents, no regressors):
@@ -154,6 +154,12 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
                 for (int i = 0; i < PT; ++i)
 #pragma unroll
                     for (int j = 0; j <= i; ++j) { acc[k] = fma(xv[i], xv[j], acc[k]); ++k; }
+                // y'y | 1'y | 1'x: with the moments of mu they give var(y - eta) without another pass over y
+                // (noise_stats_kernel below)
+                acc[k] = fma(yv, yv, acc[k]); ++k;
+                acc[k] += yv; ++k;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) { acc[k] += xv[j]; ++k; }
             } else {
                 double eta = 0.0;
 #pragma unroll
@@ -218,6 +224,10 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
             for (int i = 0; i < PT; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j, ++k) kex[k] = i < P ? ke++ : -1;
+            kex[k++] = ke++;
+            kex[k++] = ke++;
+#pragma unroll
+            for (int j = 0; j < PT; ++j, ++k) kex[k] = j < P ? ke++ : -1;
         } else if constexpr (KIND == K_NEWTON) {
 #pragma unroll
             for (int l = 0; l < LT; ++l, ++k) kex[k] = l < L ? ke++ : -1;
@@ -237,7 +247,7 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
             kex[0] = 0;
         }
     }
-    const int K = KIND == K_PREP ? L + P + P * L + tri(P) : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+    const int K = KIND == K_PREP ? L + P + P * L + tri(P) + 2 + P : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
     const int SC = S * CT;
 #pragma unroll
     for (int g0 = 0; g0 < NA; g0 += MS_GS) {
@@ -370,15 +380,18 @@ __device__ __forceinline__ void tri_ij(int k, int& i, int& j) {
 
 __device__ void mg_stat_code(int kind, int L, int P, int k, int& t1, int& i1, int& t2, int& i2, int& t3) {
     t1 = T_ONE; i1 = 0; t2 = T_ONE; i2 = 0; t3 = T_ONE;
-    if (kind == K_PREP) {  // mu'y | x'y | x'mu | x'x
+    if (kind == K_PREP) {  // mu'y | x'y | x'mu | x'x | y'y | 1'y | 1'x
         if (k < L) { t1 = T_MU; i1 = k; t2 = T_Y; return; }
         k -= L;
         if (k < P) { t1 = T_X; i1 = k; t2 = T_Y; return; }
         k -= P;
         if (k < P * L) { t1 = T_X; i1 = k / L; t2 = T_MU; i2 = k % L; return; }
         k -= P * L;
-        t1 = T_X; t2 = T_X;
-        tri_ij(k, i1, i2);
+        if (k < tri(P)) { t1 = T_X; t2 = T_X; tri_ij(k, i1, i2); return; }
+        k -= tri(P);
+        if (k == 0) { t1 = T_Y; t2 = T_Y; return; }  // y'y | 1'y | 1'x
+        if (k == 1) { t1 = T_Y; return; }
+        t1 = T_X; i1 = k - 2;
     } else if (kind == K_NEWTON) {  // (mu + v a)'r | (mu + v a)' diag(r) (mu + v a) | v'r | x'r | x' diag(r) x
         t3 = T_C;
         if (k < L) { t1 = T_MT; i1 = k; return; }
@@ -832,6 +845,48 @@ __global__ void noise_final_kernel(int N, double count, const double* s2, double
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n < N) noise[n] = s2[n] / count;
 }
+// noise = var(y - eta) per channel (core.py:177) from sums the M-step holds anyway -- no pass over y:
+//   sum (y - eta) = 1'y - a'(1'mu) - b'(1'x),   sum (y - eta)^2 = y'y - 2 (a'(mu'y) + b'(x'y)) + a'(mu'mu) a + 2 b'(x'mu) a + b'(x'x) b.
+// The differences cancel where the fit is close (a Gaussian channel at high signal-to-noise): taken only for sets without
+// Gaussian channels, whose noise is a by-product (y - log rate: residual and mean both O(1)); sets with Gaussian
+// channels keep the two passes (mean first, then the centred squares, like np.var).
+__global__ void noise_stats_kernel(int N, int L, int P, double count, const double* prep, const double* lat,
+                                   const double* a, const double* b, double* noise) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double* MtY = prep;
+    const double* XtY = prep + (int64_t)L * N;
+    const double* XtM = XtY + (int64_t)P * N;
+    const double* XtX = XtM + (int64_t)P * L * N;
+    const double* E = XtX + (int64_t)tri(P) * N;  // y'y | 1'y | 1'x
+    const double* gram = lat;
+    const double* smu = lat + tri(L);
+    double s_eta = 0.0, s_yeta = 0.0, s_eta2 = 0.0;
+    for (int l = 0; l < L; ++l) {
+        const double al = a[(int64_t)l * N + n];
+        s_eta = fma(al, smu[l], s_eta);
+        s_yeta = fma(al, MtY[(int64_t)l * N + n], s_yeta);
+        for (int m = 0; m < L; ++m) {
+            const int i = l > m ? l : m, j = l > m ? m : l;
+            s_eta2 = fma(al * a[(int64_t)m * N + n], gram[i * (i + 1) / 2 + j], s_eta2);
+        }
+    }
+    for (int j = 0; j < P; ++j) {
+        const double bj = b[(int64_t)j * N + n];
+        s_eta = fma(bj, E[(int64_t)(2 + j) * N + n], s_eta);
+        s_yeta = fma(bj, XtY[(int64_t)j * N + n], s_yeta);
+        for (int l = 0; l < L; ++l)
+            s_eta2 = fma(2.0 * bj * a[(int64_t)l * N + n], XtM[((int64_t)j * L + l) * N + n], s_eta2);
+        for (int q = 0; q < P; ++q) {
+            const int i = j > q ? j : q, k = j > q ? q : j;
+            s_eta2 = fma(bj * b[(int64_t)q * N + n], XtX[((int64_t)i * (i + 1) / 2 + k) * N + n], s_eta2);
+        }
+    }
+    const double s1 = E[(int64_t)N + n] - s_eta;
+    const double s2 = (E[n] - 2.0 * s_yeta) + s_eta2;
+    const double mean = s1 / count;
+    noise[n] = s2 / count - mean * mean;
+}
 __global__ void zero_kernel(int64_t n, double* p) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -1013,13 +1068,14 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     // Single rank, no per-launch timing: record the whole sequence once and replay it (see ctx.h).
     static const bool no_graph = getenv("VLGP_NO_MGRAPH") != nullptr;
     const bool use_graph = ctx->world == 1 && !ctx->prof_on && !no_graph;
+    const bool noise_passes = ctx->n_gauss > 0 || getenv("VLGP_NOISE_PASSES") != nullptr;  // (see noise_stats_kernel)
     std::vector<double> key;
     if (use_graph) {
         auto pk = [&](const void* p_) { key.push_back((double)(uintptr_t)p_); };
         pk(us.y); pk(us.x_ones ? nullptr : us.x); pk(us.mu); pk(us.v); pk(us.w); pk(us.dmu); pk(W); pk(ctx->d_a); pk(ctx->d_b);
         pk(ctx->d_noise); pk(ctx->d_da); pk(ctx->d_db); pk(ctx->d_fail_m); pk(ctx->d_gauss);
         for (double v_ : {(double)us.rows, (double)N, (double)L, (double)P, (double)ctx->n_gauss, (double)n_iter,
-                          (double)use_hessian, eps, lr, da_bound, db_bound})
+                          (double)use_hessian, eps, lr, da_bound, db_bound, (double)noise_passes})
             key.push_back(v_);
         if (ctx->m_graph_exec && key == ctx->m_graph_key) {
             HIPCHK(ctx, hipGraphLaunch(static_cast<hipGraphExec_t>(ctx->m_graph_exec), st));
@@ -1077,6 +1133,11 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     for (int it = 0; it < n_iter; ++it) {
         if (it == n_iter - 1) {
             // noise = var(y - eta) with the parameters entering the last iteration (core.py:177)
+            if (!noise_passes) {
+                hipLaunchKernelGGL(noise_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, L, P, total_rows,
+                                   d_prep, d_lat, ctx->d_a, ctx->d_b, ctx->d_noise);
+                HIPCHK(ctx, hipGetLastError());
+            } else {
             CHK(launch_accum(ctx, K_NOISE1, g, A, d_cache));
             CHK(reduce_to(1, d_s1));
             hipLaunchKernelGGL(noise_mean_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N,
@@ -1086,6 +1147,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
             hipLaunchKernelGGL(noise_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N,
                                total_rows, d_s1, ctx->d_noise);
             HIPCHK(ctx, hipGetLastError());
+            }
         }
         if (any_poisson) {
             vlgp_prof_begin(ctx, VLGP_PROF_MSTEP, st);
