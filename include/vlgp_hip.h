@@ -180,6 +180,12 @@ int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double dt, int n_ev
  * vlgp_hstep_objective call is self-contained. */
 int vlgp_hstep_begin(vlgp_ctx* ctx, int set, int window);
 int vlgp_hstep_end(vlgp_ctx* ctx);
+/* Optional, before vlgp_hstep_begin: enqueue what the bracket builds from the units alone (those second moments and
+ * the latent-major copy of w the round kernels read) right away -- core.vem runs the H-step after the E-step
+ * (vlgp/core.py:320-327), and both are final once the E-step is done, so called there they are ready before the
+ * first objective call instead of in front of its round.  Dropped if any entry point that may change the units runs
+ * before vlgp_hstep_begin; a no-op for sets the round kernels do not take. */
+int vlgp_hstep_prepare(vlgp_ctx* ctx, int set, int window);
 
 /* ---- constraints / norms --------------------------------------------- */
 /* mu <- (mu - shift) @ map for every unit (map (L, L) row-major, shift (L) or

@@ -494,12 +494,12 @@ def test_mstep_random_vs_oracle(V):
         assert relerr(params[k], r) < STAGE, k
 
 
-@pytest.mark.parametrize("L,P,generic", [(5, 1, False), (3, 3, False), (8, 2, True)])
+@pytest.mark.parametrize("L,P,generic", [(5, 1, False), (3, 2, False), (3, 3, False), (8, 2, True)])
 def test_noise_from_sufficient_statistics_vs_two_passes_and_oracle(V, L, P, generic, monkeypatch):
     """Sets without Gaussian channels take noise = var(y - eta) (vlgp/core.py:177) from sums the M-step holds anyway
     (y'y, 1'y, 1'x beside mu'y, x'y, x'mu, x'x and the moments of mu: noise_stats_kernel) instead of two more passes over
-    y; VLGP_NOISE_PASSES=1 keeps the passes.  The two agree to rounding (1e-12), both with the oracle (1e-9), a / b bit for
-    bit; regressors and the loop-based kernels included."""
+    y; VLGP_NOISE_PASSES=1 keeps the passes (as do more than two regressors: case (3, 3)).  The two agree to rounding
+    (1e-12), both with the oracle (1e-9), a / b bit for bit; regressors and the loop-based kernels included."""
     if generic:
         monkeypatch.setenv("VLGP_MSTEP_GENERIC", "1")
     out = []
@@ -608,6 +608,25 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
         again = eng.hstep_objective(0, T, 1.0, lat, logp + 0.0)
         eng.hstep_end()
         assert eng.last_hstep_path == "lowrank"
+        # vlgp_hstep_prepare: moments and the w copy enqueued ahead of the bracket -- the same numbers; dropped when an
+        # entry point that may change the units runs in between (here the units DO change: the stale moments must go)
+        eng.hstep_prepare(0, T)
+        eng.hstep_begin(0, T)
+        prepared = eng.hstep_objective(0, T, 1.0, lat, logp)
+        eng.hstep_end()
+        assert np.array_equal(prepared[0], plain[0]) and np.array_equal(prepared[1], plain[1])
+        eng.hstep_prepare(0, T)
+        eng.apply_latent_map(0, np.diag(np.full(L, 2.0)))
+        eng.hstep_begin(0, T)
+        scaled = eng.hstep_objective(0, T, 1.0, lat, logp)
+        eng.hstep_end()
+        eng.apply_latent_map(0, np.diag(np.full(L, 0.5)))  # (exact: back to the mu of the fixture)
+        fresh = None
+        with V.Engine(2, L, 1, 50) as eng2:
+            eng2.upload(0, [dict(u, mu=2.0 * u["mu"]) for u in units])
+            fresh = eng2.hstep_objective(0, T, 1.0, lat, logp)
+        assert np.array_equal(scaled[0], fresh[0]) and np.array_equal(scaled[1], fresh[1])
+        assert not np.array_equal(scaled[0], plain[0])
         monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
         eng.reload_switches()  # (the switches are cached when the handle is created)
         dense = eng.hstep_objective(0, T, 1.0, lat, logp)

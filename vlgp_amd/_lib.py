@@ -73,6 +73,7 @@ _SIGNATURES = {
     "vlgp_comm_rccl_ranks": (C.c_int, [_h, _ip, _ip]),
     "vlgp_project_units": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "vlgp_hstep_begin": (C.c_int, [_h, C.c_int, C.c_int]),
+    "vlgp_hstep_prepare": (C.c_int, [_h, C.c_int, C.c_int]),
     "vlgp_hstep_end": (C.c_int, [_h]),
     "vlgp_apply_latent_map": (C.c_int, [_h, C.c_int, _dp, _dp]),
     "vlgp_set_overlaps": (C.c_int, [_h, C.c_int, C.c_int, _ip, C.c_int, _ip, _ip]),

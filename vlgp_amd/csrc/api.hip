@@ -63,6 +63,7 @@ int vlgp_ensure_work_m(vlgp_ctx* ctx, int64_t n) {
 }
 
 int vlgp_join_m(vlgp_ctx* ctx) {
+    ++ctx->write_epoch;  // the callers are the entry points that read or write parameters / unit state (vlgp_hstep_prepare)
     // a pending norms pass (vlgp_norms_begin) reads mu, v, dmu on its own stream: the same callers wait for it
     if (ctx->x_pending == 1) HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));
     if (!ctx->m_pending) return VLGP_OK;
@@ -585,7 +586,7 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
     if (ctx->h_hres) (void)hipHostFree(ctx->h_hres);
     if (ctx->h_prior_mb) (void)hipHostFree(ctx->h_prior_mb);
     fr(ctx->d_prior_mb);
-    fr(ctx->d_hsync); fr(ctx->d_hmom);
+    fr(ctx->d_hsync); fr(ctx->d_hmom); fr(ctx->d_hmpart);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VLGP_OK;
@@ -1203,13 +1204,31 @@ extern "C" int vlgp_hstep_objective(vlgp_ctx* ctx, int set, int window, double d
     return launch_hstep(ctx, *us, window, dt, n_eval, latent, logp, ll, dll);
 }
 
+extern "C" int vlgp_hstep_prepare(vlgp_ctx* ctx, int set, int window) {
+    NEED_CTX(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->dev));
+    UnitSet* us = vlgp_get_set(ctx, set, true);
+    if (!us) return VLGP_ERR_ARG;
+    ctx->hprep = false;
+    if (ctx->hmom_bracket || window < 1) return VLGP_OK;
+    CHK(hstep_prepare(ctx, *us, window));
+    ctx->hprep = ctx->hmom_us == us;
+    ctx->hprep_epoch = ctx->write_epoch;
+    return VLGP_OK;
+}
+
 extern "C" int vlgp_hstep_begin(vlgp_ctx* ctx, int set, int window) {
     NEED_CTX(ctx);
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us) return VLGP_ERR_ARG;
-    (void)window;
     ctx->hmom_bracket = true;
-    ctx->hmom_us = nullptr;  // the first objective call inside the bracket builds the moments
+    // the first objective call inside the bracket builds the moments and the w copy -- unless vlgp_hstep_prepare did,
+    // for this set and window, and no entry point that may change the units ran since
+    if (!(ctx->hprep && ctx->hprep_epoch == ctx->write_epoch && ctx->hmom_us == us && ctx->hmom_T == window)) {
+        ctx->hmom_us = nullptr;
+        ctx->hwlm_valid = false;
+    }
+    ctx->hprep = false;
     // the rounds' waves take the high instruction priority unless the M-step lane was the longer one last time
     ctx->h_prio = (ctx->last_m_ms > 0.0 && ctx->last_h_ms > 0.0 && ctx->last_m_ms > ctx->last_h_ms) ? 0 : 1;
     ctx->h_t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -123,6 +123,9 @@ struct vlgp_ctx {
     double* h_hres = nullptr;     // 48 results + sequence word
     double* d_hres = nullptr;     // device view of h_hres
     unsigned h_seq = 0;
+    double* d_hmpart = nullptr;   // their partial sums by chunks of segments
+    bool hprep = false;           // vlgp_hstep_prepare built moments and the w copy for write_epoch hprep_epoch
+    uint64_t hprep_epoch = 0, write_epoch = 0;  // write_epoch: bumped by every entry point that may change unit state
     double* d_hmom = nullptr;     // (L, T, T) second moments of mu for the quadratic terms
     int64_t hmom_len = 0;
     const UnitSet* hmom_us = nullptr;
@@ -242,6 +245,7 @@ int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const dou
 // for the links [l0, l1); launch_links_map applies the latent map once more to both copies of every shared row
 int launch_links_copy(vlgp_ctx* ctx, UnitSet& us, int l0, int l1, int dir);
 int launch_links_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
+int hstep_prepare(vlgp_ctx* ctx, UnitSet& us, int T);  // moments of mu + w latent-major for the rounds (hstep.hip)
 int launch_moments(vlgp_ctx* ctx, UnitSet& us);  // tri(L) gram | sum mu | sum v | sum mu^2 | |dmu|^2 at ctx->d_work
 // the same sums of THIS rank's rows on any stream with the caller's buffers (d_out: K = tri(L) + 3 L + 1, d_partial: 256 K)
 int launch_moments_on(vlgp_ctx* ctx, UnitSet& us, hipStream_t st, double* d_partial, double* d_out);

@@ -608,7 +608,8 @@ template <int T>
 __global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, int Tr, const int64_t* off, const double* mu,
                                                            int nchunk, double* part) {
     constexpr int NE = (T * T + 255) / 256;
-    __shared__ double s[4][64];
+    constexpr int SG = 16;  // segments per stage: their loads are in flight together, the next stage's under this one's sums
+    __shared__ double s[SG][64];
     const int l = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const int per = (M + nchunk - 1) / nchunk;
     const int m0 = c * per, m1 = (m0 + per < M) ? m0 + per : M;
@@ -621,15 +622,26 @@ __global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, int Tr,
         jj[i] = idx < T * T ? idx / T : 0;
         kk[i] = idx < T * T ? idx - jj[i] * T : 0;
     }
-    for (int m = m0; m < m1; m += 4) {
-        __syncthreads();
-        {
-            const int sg = tid >> 6, t = tid & 63;
-            s[sg][t] = (m + sg < m1 && t < Tr) ? mu[(off[m + sg] + t) * L + l] : 0.0;
+    // (segments enter every sum in ascending order whatever the stage size: the same bits as the four-at-a-time loop this
+    // replaces, which waited for one strided load per four segments -- sixteen round trips to memory per block)
+    const int w4 = tid >> 6, t = tid & 63;
+    double nx[SG / 4];
+    auto fetch = [&](int m) {
+#pragma unroll
+        for (int q = 0; q < SG / 4; ++q) {
+            const int sg = w4 + 4 * q;
+            nx[q] = (m + sg < m1 && t < Tr) ? mu[(off[m + sg] + t) * L + l] : 0.0;
         }
+    };
+    if (m0 < m1) fetch(m0);
+    for (int m = m0; m < m1; m += SG) {
         __syncthreads();
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg)
+        for (int q = 0; q < SG / 4; ++q) s[w4 + 4 * q][t] = nx[q];
+        __syncthreads();
+        if (m + SG < m1) fetch(m + SG);
+#pragma unroll
+        for (int sg = 0; sg < SG; ++sg)
 #pragma unroll
             for (int i = 0; i < NE; ++i) acc[i] = fma(s[sg][jj[i]], s[sg][kk[i]], acc[i]);
     }
@@ -1076,6 +1088,64 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
     return launch_hstep_impl(ctx, us, window, dt, n_eval, latent, logp, ll, dll, false);
 }
 
+// What one gp.optimize run needs of the units before its first round and keeps until its last: the second moments
+// C_l of mu (hstep_moment_kernel + reduce) and, for the round kernels' coalesced reads, w latent-major.  Both depend on
+// the units only, so vlgp_hstep_prepare can enqueue them the moment the E-step is done -- under the host's way to the
+// first objective call -- instead of in front of the first round.  Buffers of their own (not the round workspace).
+static bool hstep_round_kernels_apply(vlgp_ctx* ctx, const UnitSet& us, int T) {
+    const HstepSwitches& sw = ctx->hsw;
+    return us.Tmin == T && us.Tmax == T && T <= 64 && T >= (sw.dense ? 24 : 4) && !sw.generic;
+}
+static int hstep_prepare_units(vlgp_ctx* ctx, UnitSet& us, int T, bool want_wlm, bool want_mom) {
+    const int L = ctx->L, M = us.M;
+    if (want_wlm && (!ctx->hwlm_valid || ctx->hmom_us != &us)) {
+        const int64_t n = us.rows * L;
+        if (ctx->hwlm_len < n) {
+            if (ctx->d_hwlm) HIPCHK(ctx, hipFree(ctx->d_hwlm));
+            ctx->d_hwlm = nullptr; ctx->hwlm_len = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->d_hwlm, sizeof(double) * (size_t)n));
+            ctx->hwlm_len = n;
+        }
+        hipLaunchKernelGGL(hstep_w_latent_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L,
+                           us.rows, us.w, ctx->d_hwlm);
+        HIPCHK(ctx, hipGetLastError());
+        ctx->hwlm_valid = true;
+    }
+    if (!want_mom) return VLGP_OK;
+    const int HT = T <= 50 ? 50 : 64;
+    constexpr int NCH = 64;
+    if (!ctx->d_hmom || ctx->hmom_len < (int64_t)L * HT * HT) {
+        if (ctx->d_hmom) HIPCHK(ctx, hipFree(ctx->d_hmom));
+        if (ctx->d_hmpart) HIPCHK(ctx, hipFree(ctx->d_hmpart));
+        ctx->d_hmom = nullptr; ctx->d_hmpart = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->d_hmom, sizeof(double) * L * HT * HT));
+        HIPCHK(ctx, hipMalloc(&ctx->d_hmpart, sizeof(double) * (size_t)L * NCH * HT * HT));
+        ctx->hmom_len = (int64_t)L * HT * HT;
+        ctx->hmom_us = nullptr;
+    }
+    if (ctx->hmom_us != &us || ctx->hmom_T != T) {
+        if (HT == 50)
+            hipLaunchKernelGGL((hstep_moment_kernel<50>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
+                               us.d_off, us.mu, NCH, ctx->d_hmpart);
+        else
+            hipLaunchKernelGGL((hstep_moment_kernel<64>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
+                               us.d_off, us.mu, NCH, ctx->d_hmpart);
+        hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, ctx->stream, NCH,
+                           HT * HT, ctx->d_hmpart, ctx->d_hmom);
+        HIPCHK(ctx, hipGetLastError());
+        ctx->hmom_us = &us;
+        ctx->hmom_T = T;
+    }
+    return VLGP_OK;
+}
+int hstep_prepare(vlgp_ctx* ctx, UnitSet& us, int T) {
+    static const bool no_wlm = getenv("VLGP_HSTEP_NO_WLM") != nullptr;
+    if (!hstep_round_kernels_apply(ctx, us, T)) return VLGP_OK;  // (the objective call reports what is wrong, if anything)
+    ctx->hmom_us = nullptr;  // units as they are NOW
+    ctx->hwlm_valid = false;
+    return hstep_prepare_units(ctx, us, T, !no_wlm, true);
+}
+
 static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
                              const double* logp, double* ll, double* dll, bool force_dense) {
     const int T = window, L = ctx->L, M = us.M;
@@ -1101,7 +1171,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
     const int64_t o_kinv = 0, o_q = o_kinv + n_eval * TT, o_dk = o_q + n_eval * TT, o_scal = o_dk + n_eval * TT;
     const int64_t o_out = o_scal + 4 * n_eval, o_red = o_out + 2LL * n_eval * M, o_logp = o_red + 3 * n_eval;
     const int64_t o_lat = o_logp + 3 * n_eval, o_qsum = o_lat + n_eval + 8, o_mpart = o_qsum + 2 * n_eval + 2;
-    const int64_t o_tm = o_mpart + (fast ? (int64_t)L * 64 * TT : 0);
+    const int64_t o_tm = o_mpart;  // (the moments' partial sums have a buffer of their own: hstep_prepare_units)
     // low-rank round: tables | meta | pair codes (doubles; each region 16-byte aligned)
     const int64_t o_km = o_tm + (T > 64 ? n_eval * TT : 0);
     const int64_t o_bmat = o_km + (huge ? (int64_t)n_eval * T * (T | 1) : 0);
@@ -1126,19 +1196,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         F.wlm = nullptr; F.wld = 0;
         static const bool no_wlm = getenv("VLGP_HSTEP_NO_WLM") != nullptr;
         if (ctx->hmom_bracket && !no_wlm) {  // mu, w are fixed inside the bracket: one transposed copy of w serves every round
-            if (!ctx->hwlm_valid || ctx->hmom_us != &us) {
-                const int64_t n = us.rows * L;
-                if (ctx->hwlm_len < n) {
-                    if (ctx->d_hwlm) HIPCHK(ctx, hipFree(ctx->d_hwlm));
-                    ctx->d_hwlm = nullptr; ctx->hwlm_len = 0;
-                    HIPCHK(ctx, hipMalloc(&ctx->d_hwlm, sizeof(double) * (size_t)n));
-                    ctx->hwlm_len = n;
-                }
-                hipLaunchKernelGGL(hstep_w_latent_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L,
-                                   us.rows, us.w, ctx->d_hwlm);
-                HIPCHK(ctx, hipGetLastError());
-                ctx->hwlm_valid = true;
-            }
+            CHK(hstep_prepare_units(ctx, us, T, true, false));
             F.wlm = ctx->d_hwlm; F.wld = us.rows;
         }
         double* hres = hp + 4 * n_eval + 8;
@@ -1150,29 +1208,9 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 memset(ctx->h_hres, 0, 64 * sizeof(double));
                 HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_hres), ctx->h_hres, 0));
             }
-            const int HT = TC;
-            constexpr int NCH = 64;
-            if (!ctx->d_hmom || ctx->hmom_len < (int64_t)L * HT * HT) {
-                if (ctx->d_hmom) HIPCHK(ctx, hipFree(ctx->d_hmom));
-                ctx->d_hmom = nullptr;
-                HIPCHK(ctx, hipMalloc(&ctx->d_hmom, sizeof(double) * L * HT * HT));
-                ctx->hmom_len = (int64_t)L * HT * HT;
-                ctx->hmom_us = nullptr;
-            }
-            if (!ctx->hmom_bracket || ctx->hmom_us != &us || ctx->hmom_T != T) {
-                // second moments of mu: once per vlgp_hstep_begin bracket, else per call
-                if (HT == 50)
-                    hipLaunchKernelGGL((hstep_moment_kernel<50>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
-                                       us.d_off, us.mu, NCH, W + o_mpart);
-                else
-                    hipLaunchKernelGGL((hstep_moment_kernel<64>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
-                                       us.d_off, us.mu, NCH, W + o_mpart);
-                hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, ctx->stream, NCH,
-                                   HT * HT, W + o_mpart, ctx->d_hmom);
-                HIPCHK(ctx, hipGetLastError());
-                ctx->hmom_us = &us;
-                ctx->hmom_T = T;
-            }
+            // second moments of mu: once per vlgp_hstep_begin bracket (or already there: vlgp_hstep_prepare), else per call
+            if (!ctx->hmom_bracket) ctx->hmom_us = nullptr;
+            CHK(hstep_prepare_units(ctx, us, T, false, true));
             HRoundArgs R;
             R.F = F;
             constexpr int MFMA_NW = 4;  // waves (= segments) per block of the matrix-pipe round kernel

@@ -50,13 +50,15 @@ struct MArgs {
 __host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
 template <int LT, int PT, int KIND>
 __host__ __device__ constexpr int nacc() {
-    return KIND == K_PREP ? LT + PT + PT * LT + tri(PT) + 2 + PT
+    return KIND == K_PREP ? LT + PT + PT * LT + tri(PT) + (PT <= 2 ? 2 + PT : 0)
          : KIND == K_NEWTON ? 2 * LT + tri(LT) + PT + tri(PT)
          : 1;
 }
 // runtime (exact L, P) number of statistics per channel
 static inline int nstat_rt(int L, int P, int kind) {
-    return kind == K_PREP ? L + P + P * L + tri(P) + 2 + P : kind == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+    // (K_PREP, at most two regressors: y'y | 1'y | 1'x ride along for noise_stats_kernel; with more the padded
+    // accumulators of the compiled kernels are out of registers and the noise keeps its two passes)
+    return kind == K_PREP ? L + P + P * L + tri(P) + (P <= 2 ? 2 + P : 0) : kind == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
 }
 
 // EXACT: L == LT, P == PT and x == 1 known at compile time -- the common case (3, 5, 8, 10 latents, no regressors):
@@ -126,8 +128,10 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
         const double* mu_t = smem;
         const double* v_t = mu_t + M_TILE * L;
         if (active && !(KIND == K_NEWTON && gch)) {  // Gaussian channels need no rate statistics
+        // two rows in flight: independent exp / FMA chains (the PREP pass with eight of its loads of y in flight:
+        // 99 against 95 us per launch, measured in round 6 -- not kept)
 #pragma unroll 2
-        for (int rr = s; rr < nr; rr += S) {  // two rows in flight: independent exp / FMA chains
+        for (int rr = s; rr < nr; rr += S) {
             const int64_t row = t0 + rr;
             double xv[PT];
 #pragma unroll
@@ -156,10 +160,12 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
                     for (int j = 0; j <= i; ++j) { acc[k] = fma(xv[i], xv[j], acc[k]); ++k; }
                 // y'y | 1'y | 1'x: with the moments of mu they give var(y - eta) without another pass over y
                 // (noise_stats_kernel below)
-                acc[k] = fma(yv, yv, acc[k]); ++k;
-                acc[k] += yv; ++k;
+                if constexpr (PT <= 2) {
+                    acc[k] = fma(yv, yv, acc[k]); ++k;
+                    acc[k] += yv; ++k;
 #pragma unroll
-                for (int j = 0; j < PT; ++j) { acc[k] += xv[j]; ++k; }
+                    for (int j = 0; j < PT; ++j) { acc[k] += xv[j]; ++k; }
+                }
             } else {
                 double eta = 0.0;
 #pragma unroll
@@ -224,10 +230,12 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
             for (int i = 0; i < PT; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j, ++k) kex[k] = i < P ? ke++ : -1;
-            kex[k++] = ke++;
-            kex[k++] = ke++;
+            if constexpr (PT <= 2) {
+                kex[k++] = ke++;
+                kex[k++] = ke++;
 #pragma unroll
-            for (int j = 0; j < PT; ++j, ++k) kex[k] = j < P ? ke++ : -1;
+                for (int j = 0; j < PT; ++j, ++k) kex[k] = j < P ? ke++ : -1;
+            }
         } else if constexpr (KIND == K_NEWTON) {
 #pragma unroll
             for (int l = 0; l < LT; ++l, ++k) kex[k] = l < L ? ke++ : -1;
@@ -247,7 +255,7 @@ __global__ void __launch_bounds__(512, (LT <= 5 ? 4 : (LT <= 8 ? 2 : 1))) mstep_
             kex[0] = 0;
         }
     }
-    const int K = KIND == K_PREP ? L + P + P * L + tri(P) + 2 + P : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
+    const int K = KIND == K_PREP ? L + P + P * L + tri(P) + (P <= 2 ? 2 + P : 0) : KIND == K_NEWTON ? 2 * L + tri(L) + P + tri(P) : 1;
     const int SC = S * CT;
 #pragma unroll
     for (int g0 = 0; g0 < NA; g0 += MS_GS) {
@@ -1068,7 +1076,7 @@ int launch_mstep(vlgp_ctx* ctx, UnitSet& us, int n_iter, int use_hessian, double
     // Single rank, no per-launch timing: record the whole sequence once and replay it (see ctx.h).
     static const bool no_graph = getenv("VLGP_NO_MGRAPH") != nullptr;
     const bool use_graph = ctx->world == 1 && !ctx->prof_on && !no_graph;
-    const bool noise_passes = ctx->n_gauss > 0 || getenv("VLGP_NOISE_PASSES") != nullptr;  // (see noise_stats_kernel)
+    const bool noise_passes = ctx->n_gauss > 0 || P > 2 || getenv("VLGP_NOISE_PASSES") != nullptr;  // (see noise_stats_kernel)
     std::vector<double> key;
     if (use_graph) {
         auto pk = [&](const void* p_) { key.push_back((double)(uintptr_t)p_); };

@@ -305,6 +305,10 @@ class Engine:
         self._ck(self.lib.vlgp_project_units(self.h, set_id, dptr(proj), dptr(shift), dptr(colsum)))
         return colsum
 
+    def hstep_prepare(self, set_id, window):
+        """Enqueue now what the H-step bracket builds from the units alone (see vlgp_hstep_prepare)."""
+        self._ck(self.lib.vlgp_hstep_prepare(self.h, set_id, int(window)))
+
     def hstep_begin(self, set_id, window):
         """Start of one gp.optimize run: mu, w of the set stay fixed until hstep_end."""
         self._ck(self.lib.vlgp_hstep_begin(self.h, set_id, int(window)))
@@ -826,6 +830,9 @@ def em_iteration(trials, params, config, runtime, echo=None):
     eng.synchronize(main_only=True)   # the E-step; the M-step lane is not waited for
     t1 = time.perf_counter()
     constrain_latent(trials, params, config)
+    m_first = m_async and ((eng.world > 1 and not eng.host_exchange) or bool(os.environ.get("VLGP_M_SEQUENTIAL")))
+    if config["Hstep"] and config.get("window") and not m_first:
+        eng.hstep_prepare(sid, config["window"])  # the H-step's moments of mu / copy of w: under the host's way to its first round
     # mu and dmu are final from here on (the M-step writes a, b; the H-step omega): the sums of the stopping rule
     # (core.py:350-354) are enqueued now and run beside the H-step rounds instead of behind them
     eng.norms_begin(sid)
@@ -844,7 +851,7 @@ def em_iteration(trials, params, config, runtime, echo=None):
     # under the H-step only when the H-step issues none itself, i.e. when its round sums are exchanged on
     # the host (Engine.host_exchange); otherwise two communicators would be in flight with no common
     # order across ranks, and the M-step is finished first.
-    if m_async and ((eng.world > 1 and not eng.host_exchange) or os.environ.get("VLGP_M_SEQUENTIAL")):
+    if m_first:
         m_ms = finish_m()
         m_async = False
     t2 = time.perf_counter()
