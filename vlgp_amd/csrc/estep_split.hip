@@ -81,39 +81,64 @@ template <int LT>
 constexpr int rec_len() { return (2 * LT + 3 + 1) & ~1; }
 
 __global__ void __launch_bounds__(256)
-esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double* b, const double* noise, const int* gauss,
-                   double* cols, double* wconst, double* ycoef) {
+esplit_cols_kernel(int N, int L, int LT, int REC, const double* __restrict__ a, const double* __restrict__ b,
+                   const double* __restrict__ noise, const int* __restrict__ gauss, double* __restrict__ cols,
+                   double* __restrict__ wconst, double* __restrict__ ycoef) {
+    // (one workgroup in front of every E-step call: every load of a thread is issued before its first store -- with
+    // pointers that might alias each load waited for the store before it, 21 us for a hundred channels)
     __shared__ int order[1024];
     __shared__ int gs[1024];
-    for (int n = threadIdx.x; n < N; n += 256) gs[n] = gauss[n];  // (one trip to memory: thread 0's loop below used to make N)
+    __shared__ double cinv[1024];  // 1 / noise on Gaussian channels, else 1
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const int g = gauss[n];
+        gs[n] = g;
+        cinv[n] = g ? 1.0 / noise[n] : 1.0;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int k = 0;
-        for (int n = 0; n < N; ++n)
-            if (!gs[n]) order[k++] = n;
-        for (int n = 0; n < N; ++n)
-            if (gs[n]) order[k++] = n;
+    // Poisson channels first, both groups in channel order: every channel counts the Gaussian ones before it (the loads
+    // of a thread are independent; one thread walking the list was a chain of 2 N dependent LDS accesses, 17 us at N = 100)
+    {
+        int total = 0;
+        for (int m = 0; m < N; ++m) total += gs[m];
+        for (int n = threadIdx.x; n < N; n += 256) {
+            int c = 0;
+            for (int m = 0; m < n; ++m) c += gs[m];
+            order[gs[n] ? (N - total) + c : n - c] = n;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < N; i += 256) {
         const int n = order[i];
+        double av[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) av[l] = (l < L && l < LT) ? a[l * N + n] : 0.0;
+        const double bn = b[n];
         double* rec = cols + (int64_t)i * REC;
-        for (int l = 0; l < LT; ++l) {
-            const double av = l < L ? a[l * N + n] : 0.0;
-            rec[l] = av;
-            rec[LT + l] = 0.5 * av * av;  // half squares: the rate's exponent is one chain b + mu.a + v.(a^2 / 2)
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            if (l < LT) {
+                rec[l] = av[l];
+                rec[LT + l] = 0.5 * av[l] * av[l];  // half squares: the rate's exponent is one chain b + mu.a + v.(a^2 / 2)
+            }
         }
-        rec[2 * LT] = b[n];
-        rec[2 * LT + 1] = gauss[n] ? 1.0 / noise[n] : 1.0;
+        rec[2 * LT] = bn;
+        rec[2 * LT + 1] = cinv[n];
         rec[2 * LT + 2] = __longlong_as_double((long long)n);  // channel id, read back as an integer
     }
     // channel-major coefficients of the y pass, ORIGINAL channel order: ycoef[n][l] = a_ln (1/noise_n or 1)
-    for (int n = threadIdx.x; n < N; n += 256)
-        for (int l = 0; l < LT; ++l) ycoef[n * LT + l] = l < L ? a[l * N + n] * (gauss[n] ? 1.0 / noise[n] : 1.0) : 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        double av[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) av[l] = (l < L && l < LT) ? a[l * N + n] : 0.0;
+        const double c = cinv[n];
+#pragma unroll
+        for (int l = 0; l < 16; ++l)
+            if (l < LT) ycoef[n * LT + l] = l < L ? av[l] * c : 0.0;
+    }
     if ((int)threadIdx.x < L) {  // w = U (a')^2 with U = 1/noise on Gaussian channels (core.py:103-104)
         double s = 0.0;
         for (int n = 0; n < N; ++n)
-            if (gs[n]) s = fma(a[threadIdx.x * N + n] * a[threadIdx.x * N + n], 1.0 / noise[n], s);
+            if (gs[n]) s = fma(a[threadIdx.x * N + n] * a[threadIdx.x * N + n], cinv[n], s);
         wconst[threadIdx.x] = s;
     }
 }
@@ -124,14 +149,17 @@ esplit_cols_kernel(int N, int L, int LT, int REC, const double* a, const double*
 // L1 line accesses per wave of the mean launch with the interleaved layout, most of them for 3 x 50 doubles).
 __global__ void __launch_bounds__(256)
 esplit_to_lm(int L, int64_t rows, const double* __restrict__ a0, const double* __restrict__ a1,
-             const double* __restrict__ a2, double* b0, double* b1, double* b2) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over rows * L, latent-major index
-    if (i >= rows * L) return;
-    const int64_t l = i / rows, row = i - l * rows;
-    const int64_t src = row * L + l;
-    b0[i] = a0[src];
-    b1[i] = a1[src];
-    b2[i] = a2[src];
+             const double* __restrict__ a2, double* __restrict__ b0, double* __restrict__ b1, double* __restrict__ b2) {
+    // a lane takes a row: a wave reads 64 L contiguous doubles per array and writes L runs of 64 (the first version went
+    // by latent-major index: 8 of every 8 L bytes per load, 30 us against the 9 us of the way back)
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    for (int l = 0; l < L; ++l) {
+        const double x0 = a0[row * L + l], x1 = a1[row * L + l], x2 = a2[row * L + l];
+        b0[l * rows + row] = x0;
+        b1[l * rows + row] = x1;
+        b2[l * rows + row] = x2;
+    }
 }
 __global__ void __launch_bounds__(256)
 esplit_from_lm(int L, int64_t rows, const double* __restrict__ b0, const double* __restrict__ b1,
@@ -1904,7 +1932,7 @@ int launch_estep_split(vlgp_ctx* ctx, UnitSet& us, EstepArgs E, int* handled) {
     A.ra = us.d_scratch; A.ya = A.ra + nRL; A.mu = A.ya + nRL; A.v = A.mu + nRL; A.w = A.v + nRL;
     A.xg = A.w + nRL; A.pkg = pkg;
     {
-        const unsigned nb = (unsigned)((nRL + 255) / 256);
+        const unsigned nb = (unsigned)((us.rows + 255) / 256);
         hipLaunchKernelGGL(esplit_to_lm, dim3(nb), dim3(256), 0, ctx->stream, L, us.rows, E.mu, E.v, E.w, A.mu, A.v, A.w);
         HIPCHK(ctx, hipGetLastError());
     }
