@@ -217,6 +217,45 @@ __global__ void __launch_bounds__(NT) ichol_exact_kernel(IcholArgs A) {
 // residual sum is one leaf of NumPy's pairwise recursion (ich_leaf8 by every group of eight lanes at once), the
 // arg-max a butterfly that leaves the first maximum on every lane.  Same primitives in the same order as the kernel
 // above: the same bits (tests/test_gpu_parity.py::test_ichol_*).  RS: row stride of the LDS copy (odd: no bank runs).
+// One row of one step (npx_ichol_row) for a wave whose lanes are the remaining rows: OpenBLAS' dgemv_t gives the
+// rows of a call three different summation orders (groups of four, a trailing pair, a trailing single row); taken as
+// three loops the wave walks each of them in turn -- here the loads are shared and only the arithmetic is selected.
+__device__ static inline double ich_row_wave(double* row, const double* prow, int i, int jj, int mo, double kvv, double piv) {
+    double dot;
+    if (i == 0) {
+        dot = 0.0;
+    } else if (mo == 1) {  // a single remaining row is cblas_ddot (wave-uniform branch)
+        dot = npx_dot_row([&](int l) { return row[l]; }, [&](int l) { return prow[l]; }, i, jj, mo);
+    } else {
+        const int k4 = i & ~3, n4 = (mo >> 2) << 2;
+        const int path = jj < n4 ? 0 : (((mo & 2) && jj < n4 + 2) ? 1 : 2);
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+        for (int l = 0; l < k4; l += 4) {
+            const double a0 = row[l], a1 = row[l + 1], a2 = row[l + 2], a3 = row[l + 3];
+            const double x0 = prow[l], x1 = prow[l + 1], x2 = prow[l + 2], x3 = prow[l + 3];
+            if (path == 0) {         // four outputs at a time: 4-lane FMA accumulator
+                c0 = fma(a0, x0, c0); c1 = fma(a1, x1, c1); c2 = fma(a2, x2, c2); c3 = fma(a3, x3, c3);
+            } else if (path == 1) {  // trailing pair: 2-lane multiply, add
+                c0 = c0 + a0 * x0; c1 = c1 + a1 * x1; c0 = c0 + a2 * x2; c1 = c1 + a3 * x3;
+            } else {                 // trailing single output: two 2-lane accumulators
+                c0 = c0 + a0 * x0; c1 = c1 + a1 * x1; c2 = c2 + a2 * x2; c3 = c3 + a3 * x3;
+            }
+        }
+        double t = 0.0;
+        if (k4) t = path == 1 ? c0 + c1 : (c0 + c2) + (c1 + c3);
+        double y = 0.0 + t;
+        const int r = i - k4;
+        if (r == 1) y = fma(row[k4], prow[k4], y);
+        else if (r == 2) y = y + fma(row[k4], prow[k4], row[k4 + 1] * prow[k4 + 1]);
+        else if (r == 3) y = y + fma(row[k4 + 2], prow[k4 + 2], fma(row[k4], prow[k4], row[k4 + 1] * prow[k4 + 1]));
+        dot = y;
+    }
+    const double g = (kvv - dot) / piv;
+    row[i] = g;
+    const double ss = 0.0 + npx_pairwise_leaf([&](int l) { const double v = row[l]; return v * v; }, i + 1);
+    return 1.0 - ss;
+}
+
 __global__ void __launch_bounds__(64) ichol_exact_wave_kernel(IcholArgs A, int RS) {
     extern __shared__ __attribute__((aligned(16))) char ich_smem[];
     const int l = blockIdx.x, lane = threadIdx.x;
@@ -241,6 +280,8 @@ __global__ void __launch_bounds__(64) ichol_exact_wave_kernel(IcholArgs A, int R
     for (; i < R; ++i) {
         const int n = T - i;
         if (n <= 0) break;  // (np.sum of nothing is 0.0: not above the tolerance)
+        // (every lane forming the whole sum from 64 preloaded values and selects instead of eight lanes and shuffles:
+        // measured 14 us SLOWER per launch at rank 11, same box -- tools/variant_ab.sh)
         const double total = 0.0 + ich_leaf8(d + i, n, lane & 7, lane & ~7);
         if (!(total > tol_n)) break;
         int jast = 0;
@@ -268,7 +309,7 @@ __global__ void __launch_bounds__(64) ichol_exact_wave_kernel(IcholArgs A, int R
         if (lane < mo) {
             const int p = i + 1 + lane, row = piv[p];
             const int dist = row > rowi ? row - rowi : rowi - row;
-            d[p] = npx_ichol_row(Gs + row * RS, Gs + rowi * RS, i, lane, mo, kv[dist], pivot);
+            d[p] = ich_row_wave(Gs + row * RS, Gs + rowi * RS, i, lane, mo, kv[dist], pivot);
         }
         __syncthreads();
     }
