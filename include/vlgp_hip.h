@@ -141,6 +141,9 @@ int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed);
  * iterations for every unit of the set.  n_failed may be NULL (no sync then). */
 int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb,
                int* n_failed);
+/* Wait for the launches of the most recent vlgp_estep call -- NOT for what has been queued behind them on the
+ * same stream since (vlgp_hstep_prepare: the timers of core.vem bracket the E-step alone, vlgp/core.py:308-312). */
+int vlgp_estep_wait(vlgp_ctx* ctx);
 
 /* ---- M-step ----------------------------------------------------------- */
 /* core.mstep (vlgp/core.py:129-249) over the concatenation of all units of
@@ -195,10 +198,11 @@ int vlgp_apply_latent_map(vlgp_ctx* ctx, int set, const double* map, const doubl
 /* out[0] = sum mu^2, out[1] = sum dmu^2 over the set (and over ranks):
  * the convergence test of core.vem (vlgp/core.py:300-305,350-354). */
 int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]);
-/* The same in two halves: vlgp_norms_begin enqueues the sums behind everything already queued and returns;
- * vlgp_norms_end waits for them.  core.vem takes the norms after the M- and H-step (vlgp/core.py:350-354), but mu
- * and dmu are final once the E-step (and constrain_latent) are done: begun there, the pass runs beside the H-step
- * rounds instead of behind them.  Every entry point that writes unit state waits for a pending pass first. */
+/* The same in two halves: vlgp_norms_begin enqueues the sums (one kernel, results in mapped host memory) behind
+ * everything already queued and returns; vlgp_norms_end waits for them.  core.vem takes the norms after the M- and
+ * H-step (vlgp/core.py:350-354), but mu and dmu are final once the E-step (and constrain_latent) are done: begun
+ * there -- even while the E-step still runs -- nothing is left to wait for at the end of the iteration.  Every entry
+ * point that writes unit state waits for a pending pass first. */
 int vlgp_norms_begin(vlgp_ctx* ctx, int set);
 int vlgp_norms_end(vlgp_ctx* ctx, double out[2]);
 /* Initial latents of preprocess.initialize (vlgp/preprocess.py:30-41) on the device: for every row of the

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vlgp_update_w": (C.c_int, [_h, C.c_int]),
     "vlgp_update_v": (C.c_int, [_h, C.c_int, C.c_int, _ip]),
     "vlgp_estep": (C.c_int, [_h, C.c_int, C.c_int, C.c_double, C.c_int, _ip]),
+    "vlgp_estep_wait": (C.c_int, [_h]),
     "vlgp_mstep": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                              C.c_double, _ip]),
     "vlgp_mstep_begin": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,

@@ -62,10 +62,30 @@ int vlgp_ensure_work_m(vlgp_ctx* ctx, int64_t n) {
     return VLGP_OK;
 }
 
+// wait for a queued norms pass (vlgp_norms_begin): its sequence word in mapped host memory
+static int wait_norms(vlgp_ctx* ctx) {
+    if (ctx->x_pending != 1) return VLGP_OK;
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->h_xres + 2);
+    unsigned spins = 0;
+    while (*flag != ctx->x_seq) {
+        if ((++spins & 0xfff) == 0) {  // a faulted kernel must not hang the host
+            const hipError_t qe = hipStreamQuery(ctx->stream);
+            if (qe == hipSuccess) {
+                if (*flag == ctx->x_seq) break;
+                if ((spins >> 12) > 64) return vlgp_fail(ctx, VLGP_ERR_HIP, "norms kernel finished without publishing");
+            } else if (qe != hipErrorNotReady) {
+                return vlgp_fail(ctx, VLGP_ERR_HIP, "norms kernel failed: %s", hipGetErrorString(qe));
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return VLGP_OK;
+}
+
 int vlgp_join_m(vlgp_ctx* ctx) {
     ++ctx->write_epoch;  // the callers are the entry points that read or write parameters / unit state (vlgp_hstep_prepare)
     // a pending norms pass (vlgp_norms_begin) reads mu, v, dmu on its own stream: the same callers wait for it
-    if (ctx->x_pending == 1) HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));
+    CHK(wait_norms(ctx));
     if (!ctx->m_pending) return VLGP_OK;
     HIPCHK(ctx, hipEventSynchronize(ctx->ev_m_done));  // m_pending is cleared by vlgp_mstep_end
     return VLGP_OK;
@@ -572,9 +592,7 @@ extern "C" int vlgp_destroy(vlgp_ctx* ctx) {
         if (ctx->elane[i]) (void)hipStreamDestroy(ctx->elane[i]);
     }
     if (ctx->mstream) (void)hipStreamDestroy(ctx->mstream); fr((void*)ctx->d_prior_base); fr(ctx->d_prior_rl); fr(ctx->d_prior_goff);
-    if (ctx->xstream) { (void)hipStreamSynchronize(ctx->xstream); (void)hipStreamDestroy(ctx->xstream); }
-    if (ctx->ev_x_fork) (void)hipEventDestroy(ctx->ev_x_fork);
-    if (ctx->ev_x_done) (void)hipEventDestroy(ctx->ev_x_done);
+    if (ctx->ev_e_done) (void)hipEventDestroy(ctx->ev_e_done);
     if (ctx->ev_stage_par) (void)hipEventDestroy(ctx->ev_stage_par);
     if (ctx->ev_stage_map) (void)hipEventDestroy(ctx->ev_stage_map);
     fr(ctx->d_xwork); fr(ctx->d_stage_map);
@@ -602,6 +620,13 @@ extern "C" int vlgp_synchronize(vlgp_ctx* ctx) {
 extern "C" int vlgp_synchronize_main(vlgp_ctx* ctx) {
     NEED_CTX(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VLGP_OK;
+}
+
+extern "C" int vlgp_estep_wait(vlgp_ctx* ctx) {
+    NEED_CTX(ctx);
+    if (ctx->e_done_valid) HIPCHK(ctx, hipEventSynchronize(ctx->ev_e_done));
+    else HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return VLGP_OK;
 }
 
@@ -1068,6 +1093,9 @@ extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, 
     const int mode = EM_FACTOR0 | EM_MEAN | EM_W | (vb ? EM_V : 0);
     if (us->stage_start.size() > 2) CHK(estep_staged(ctx, *us, mode, n_iter, dmu_bound, vb ? 1 : 0));
     else CHK(launch_estep(ctx, *us, mode, n_iter, dmu_bound, vb ? 1 : 0));
+    if (!ctx->ev_e_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_e_done, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_e_done, ctx->stream));  // (vlgp_estep_wait: this call's launches, not what is queued behind)
+    ctx->e_done_valid = true;
     return end_count(ctx, n_failed);
 }
 
@@ -1211,7 +1239,11 @@ extern "C" int vlgp_hstep_prepare(vlgp_ctx* ctx, int set, int window) {
     if (!us) return VLGP_ERR_ARG;
     ctx->hprep = false;
     if (ctx->hmom_bracket || window < 1) return VLGP_OK;
-    CHK(hstep_prepare(ctx, *us, window));
+    // On the MAIN stream, behind everything queued so far -- the call may come while the E-step still runs (the host
+    // then waits for the E-step alone: vlgp_estep_wait).  (Measured: the same work on the side stream, enqueued during the
+    // E-step, makes a fourth busy queue beside the E-step's two lanes and the M-step lane -- E-step 2.2 -> 4.0 ms, the
+    // queue pathology of DESIGN 4.1.)
+    CHK(hstep_prepare(ctx, *us, window, ctx->stream));
     ctx->hprep = ctx->hmom_us == us;
     ctx->hprep_epoch = ctx->write_epoch;
     return VLGP_OK;
@@ -1287,11 +1319,17 @@ static int moments_host(vlgp_ctx* ctx, UnitSet& us, std::vector<double>& out) {
     return VLGP_OK;
 }
 
+extern "C" int vlgp_norms_begin(vlgp_ctx* ctx, int set);
+extern "C" int vlgp_norms_end(vlgp_ctx* ctx, double out[2]);
 extern "C" int vlgp_norms(vlgp_ctx* ctx, int set, double out[2]) {
     NEED_CTX(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us) return VLGP_ERR_ARG;
+    if (ctx->world == 1) {  // one rank: the kernel of the two-halves form (the same sums, bit for bit)
+        CHK(vlgp_norms_begin(ctx, set));
+        return vlgp_norms_end(ctx, out);
+    }
     std::vector<double> m;
     CHK(moments_host(ctx, *us, m));
     const int L = ctx->L, t = L * (L + 1) / 2;
@@ -1307,26 +1345,22 @@ extern "C" int vlgp_norms_begin(vlgp_ctx* ctx, int set) {
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     UnitSet* us = vlgp_get_set(ctx, set, true);
     if (!us) return VLGP_ERR_ARG;
-    if (ctx->x_pending == 1) HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));  // never collected: dropped
+    CHK(wait_norms(ctx));  // (a pass never collected: dropped)
     ctx->x_pending = 0;
     ctx->x_set = set;
     if (ctx->world > 1) {  // the sums cross ranks on the main lane's communicator: computed when they are collected
         ctx->x_pending = 2;
         return VLGP_OK;
     }
-    const int L = ctx->L, K = L * (L + 1) / 2 + 3 * L + 1;
-    if (!ctx->xstream) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_x_fork, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_x_done, hipEventDisableTiming));
-        HIPCHK(ctx, hipMalloc(&ctx->d_xwork, sizeof(double) * (257 * (size_t)K + 64)));
-        HIPCHK(ctx, hipHostMalloc(&ctx->h_xres, sizeof(double) * (K + 8), hipHostMallocDefault));
+    if (!ctx->h_xres) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_xwork, sizeof(double) * (2 * 256 + 8)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_xwork, 0, sizeof(double) * (2 * 256 + 8), ctx->stream));
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_xres, sizeof(double) * 8, hipHostMallocMapped));
+        memset(ctx->h_xres, 0, sizeof(double) * 8);
+        HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_xres), ctx->h_xres, 0));
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_x_fork, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->xstream, ctx->ev_x_fork, 0));
-    CHK(launch_moments_on(ctx, *us, ctx->xstream, ctx->d_xwork + K + 64, ctx->d_xwork));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_xres, ctx->d_xwork, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->xstream));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_x_done, ctx->xstream));
+    ++ctx->x_seq;
+    CHK(launch_norms(ctx, *us, ctx->d_xwork, reinterpret_cast<unsigned*>(ctx->d_xwork + 2 * 256), ctx->d_xres, ctx->x_seq));
     ctx->x_pending = 1;
     return VLGP_OK;
 }
@@ -1338,13 +1372,10 @@ extern "C" int vlgp_norms_end(vlgp_ctx* ctx, double out[2]) {
         ctx->x_pending = 0;
         return vlgp_norms(ctx, ctx->x_set, out);
     }
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev_x_done));
+    CHK(wait_norms(ctx));
     ctx->x_pending = 0;
-    const int L = ctx->L, t = L * (L + 1) / 2;
-    double s = 0.0;
-    for (int l = 0; l < L; ++l) s += ctx->h_xres[t + 2 * L + l];
-    out[0] = s;
-    out[1] = ctx->h_xres[t + 3 * L];
+    out[0] = ctx->h_xres[0];
+    out[1] = ctx->h_xres[1];
     return VLGP_OK;
 }
 

@@ -125,6 +125,8 @@ struct vlgp_ctx {
     unsigned h_seq = 0;
     double* d_hmpart = nullptr;   // their partial sums by chunks of segments
     bool hprep = false;           // vlgp_hstep_prepare built moments and the w copy for write_epoch hprep_epoch
+    hipEvent_t ev_e_done = nullptr;  // behind the last launch of the most recent vlgp_estep call (vlgp_estep_wait)
+    bool e_done_valid = false;
     uint64_t hprep_epoch = 0, write_epoch = 0;  // write_epoch: bumped by every entry point that may change unit state
     double* d_hmom = nullptr;     // (L, T, T) second moments of mu for the quadratic terms
     int64_t hmom_len = 0;
@@ -169,12 +171,12 @@ struct vlgp_ctx {
     int lds_max = 64 * 1024;      // hipDeviceAttributeMaxSharedMemoryPerBlock (gfx950: 160 KB)
 
     // Pieces of an EM iteration's tail taken off its critical path (api.hip):
-    // (1) the norms of mu, dmu for the stopping rule run beside the H-step rounds on their own stream
-    hipStream_t xstream = nullptr;
-    hipEvent_t ev_x_fork = nullptr, ev_x_done = nullptr;
-    double* d_xwork = nullptr;    // K moments | 256 K partials
-    double* h_xres = nullptr;     // pinned, K moments
-    int x_pending = 0;            // 1: in flight on xstream, 2: deferred to vlgp_norms_end (several ranks)
+    // (1) the norms of mu, dmu for the stopping rule: one kernel queued behind the E-step, results in mapped host memory
+    double* d_xwork = nullptr;    // 256 x 2 partial sums | ticket
+    double* h_xres = nullptr;     // mapped: |mu|^2, |dmu|^2, sequence word
+    double* d_xres = nullptr;     // its device view
+    unsigned long long x_seq = 0;
+    int x_pending = 0;            // 1: queued (sequence x_seq), 2: deferred to vlgp_norms_end (several ranks)
     int x_set = -1;
     // (2) the M-step lane leaves a, b, noise, da, db and its failure count in pinned memory behind its last kernel
     double* h_msnap = nullptr;
@@ -241,14 +243,13 @@ int launch_sample_posterior(vlgp_ctx* ctx, int T, int n, const double* d_mu, con
 int launch_npx_probe(vlgp_ctx* ctx, int kind, int64_t n, const double* d_a, const double* d_b, double* d_out);
 int launch_xb(vlgp_ctx* ctx, UnitSet& us);
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
+int launch_norms(vlgp_ctx* ctx, UnitSet& us, double* d_part, unsigned* d_ticket, double* d_host, unsigned long long seq);
 // shared rows of overlapping segments: dir 0 copies first unit's tail -> second unit's head (mu if share_mu, v), dir 1 back,
 // for the links [l0, l1); launch_links_map applies the latent map once more to both copies of every shared row
 int launch_links_copy(vlgp_ctx* ctx, UnitSet& us, int l0, int l1, int dir);
 int launch_links_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
-int hstep_prepare(vlgp_ctx* ctx, UnitSet& us, int T);  // moments of mu + w latent-major for the rounds (hstep.hip)
+int hstep_prepare(vlgp_ctx* ctx, UnitSet& us, int T, hipStream_t st);  // moments of mu + w latent-major for the rounds (hstep.hip)
 int launch_moments(vlgp_ctx* ctx, UnitSet& us);  // tri(L) gram | sum mu | sum v | sum mu^2 | |dmu|^2 at ctx->d_work
-// the same sums of THIS rank's rows on any stream with the caller's buffers (d_out: K = tri(L) + 3 L + 1, d_partial: 256 K)
-int launch_moments_on(vlgp_ctx* ctx, UnitSet& us, hipStream_t st, double* d_partial, double* d_out);
 int launch_project(vlgp_ctx* ctx, UnitSet& us, const double* d_proj, const double* d_shift, double* d_part,
                    double* d_out);  // mu = y proj - shift; d_out = column sums of y
 int launch_gather(vlgp_ctx* ctx, UnitSet& src, UnitSet& dst, int window);

@@ -1096,7 +1096,7 @@ static bool hstep_round_kernels_apply(vlgp_ctx* ctx, const UnitSet& us, int T) {
     const HstepSwitches& sw = ctx->hsw;
     return us.Tmin == T && us.Tmax == T && T <= 64 && T >= (sw.dense ? 24 : 4) && !sw.generic;
 }
-static int hstep_prepare_units(vlgp_ctx* ctx, UnitSet& us, int T, bool want_wlm, bool want_mom) {
+static int hstep_prepare_units(vlgp_ctx* ctx, UnitSet& us, int T, bool want_wlm, bool want_mom, hipStream_t st) {
     const int L = ctx->L, M = us.M;
     if (want_wlm && (!ctx->hwlm_valid || ctx->hmom_us != &us)) {
         const int64_t n = us.rows * L;
@@ -1106,7 +1106,7 @@ static int hstep_prepare_units(vlgp_ctx* ctx, UnitSet& us, int T, bool want_wlm,
             HIPCHK(ctx, hipMalloc(&ctx->d_hwlm, sizeof(double) * (size_t)n));
             ctx->hwlm_len = n;
         }
-        hipLaunchKernelGGL(hstep_w_latent_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L,
+        hipLaunchKernelGGL(hstep_w_latent_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, L,
                            us.rows, us.w, ctx->d_hwlm);
         HIPCHK(ctx, hipGetLastError());
         ctx->hwlm_valid = true;
@@ -1125,12 +1125,12 @@ static int hstep_prepare_units(vlgp_ctx* ctx, UnitSet& us, int T, bool want_wlm,
     }
     if (ctx->hmom_us != &us || ctx->hmom_T != T) {
         if (HT == 50)
-            hipLaunchKernelGGL((hstep_moment_kernel<50>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
+            hipLaunchKernelGGL((hstep_moment_kernel<50>), dim3(NCH, L), dim3(256), 0, st, L, M, T,
                                us.d_off, us.mu, NCH, ctx->d_hmpart);
         else
-            hipLaunchKernelGGL((hstep_moment_kernel<64>), dim3(NCH, L), dim3(256), 0, ctx->stream, L, M, T,
+            hipLaunchKernelGGL((hstep_moment_kernel<64>), dim3(NCH, L), dim3(256), 0, st, L, M, T,
                                us.d_off, us.mu, NCH, ctx->d_hmpart);
-        hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, ctx->stream, NCH,
+        hipLaunchKernelGGL(hstep_moment_reduce, dim3((HT * HT + 255) / 256, L), dim3(256), 0, st, NCH,
                            HT * HT, ctx->d_hmpart, ctx->d_hmom);
         HIPCHK(ctx, hipGetLastError());
         ctx->hmom_us = &us;
@@ -1138,12 +1138,12 @@ static int hstep_prepare_units(vlgp_ctx* ctx, UnitSet& us, int T, bool want_wlm,
     }
     return VLGP_OK;
 }
-int hstep_prepare(vlgp_ctx* ctx, UnitSet& us, int T) {
+int hstep_prepare(vlgp_ctx* ctx, UnitSet& us, int T, hipStream_t st) {
     static const bool no_wlm = getenv("VLGP_HSTEP_NO_WLM") != nullptr;
     if (!hstep_round_kernels_apply(ctx, us, T)) return VLGP_OK;  // (the objective call reports what is wrong, if anything)
-    ctx->hmom_us = nullptr;  // units as they are NOW
+    ctx->hmom_us = nullptr;  // units as they are when everything queued so far is done
     ctx->hwlm_valid = false;
-    return hstep_prepare_units(ctx, us, T, !no_wlm, true);
+    return hstep_prepare_units(ctx, us, T, !no_wlm, true, st);
 }
 
 static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, const int* latent,
@@ -1196,7 +1196,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
         F.wlm = nullptr; F.wld = 0;
         static const bool no_wlm = getenv("VLGP_HSTEP_NO_WLM") != nullptr;
         if (ctx->hmom_bracket && !no_wlm) {  // mu, w are fixed inside the bracket: one transposed copy of w serves every round
-            CHK(hstep_prepare_units(ctx, us, T, true, false));
+            CHK(hstep_prepare_units(ctx, us, T, true, false, ctx->stream));
             F.wlm = ctx->d_hwlm; F.wld = us.rows;
         }
         double* hres = hp + 4 * n_eval + 8;
@@ -1210,7 +1210,7 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
             }
             // second moments of mu: once per vlgp_hstep_begin bracket (or already there: vlgp_hstep_prepare), else per call
             if (!ctx->hmom_bracket) ctx->hmom_us = nullptr;
-            CHK(hstep_prepare_units(ctx, us, T, false, true));
+            CHK(hstep_prepare_units(ctx, us, T, false, true, ctx->stream));
             HRoundArgs R;
             R.F = F;
             constexpr int MFMA_NW = 4;  // waves (= segments) per block of the matrix-pipe round kernel

@@ -108,6 +108,63 @@ int launch_xb(vlgp_ctx* ctx, UnitSet& us) {
     return VLGP_OK;
 }
 
+// ---- |mu|^2 and |dmu|^2 over the set (the stopping rule of core.vem, vlgp/core.py:300-305,350-354) ----
+// One launch on the main stream: per-block sums in a fixed order, the block that draws the last ticket adds the
+// partials (fixed tree) and publishes to mapped host memory with a sequence word -- no copy, no second kernel, nothing
+// the host has to wait for when it queues it behind an E-step.
+__global__ void __launch_bounds__(256)
+norms_kernel(int64_t n, const double* __restrict__ mu, const double* __restrict__ dmu, double* part, unsigned* ticket,
+             double* host, unsigned long long seq) {
+    __shared__ double red[2][256];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        const double m = mu[i], d = dmu ? dmu[i] : 0.0;
+        s0 = fma(m, m, s0);
+        s1 = fma(d, d, s1);
+    }
+    red[0][tid] = s0; red[1][tid] = s1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[2 * blockIdx.x] = red[0][0];
+        part[2 * blockIdx.x + 1] = red[1][0];
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    red[0][tid] = tid < (int)gridDim.x ? __hip_atomic_load(part + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    red[1][tid] = tid < (int)gridDim.x ? __hip_atomic_load(part + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *ticket = 0u;
+        host[0] = red[0][0];
+        host[1] = red[1][0];
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int launch_norms(vlgp_ctx* ctx, UnitSet& us, double* d_part, unsigned* d_ticket, double* d_host, unsigned long long seq) {
+    const int64_t n = us.rows * ctx->L;
+    int g = (int)((n + 255) / 256);
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(norms_kernel, dim3(g), dim3(256), 0, ctx->stream, n, us.mu, us.dmu, d_part, d_ticket, d_host, seq);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift) {
     const int L = ctx->L;
     const dim3 grid(grid_for(us.rows)), blk(256);

@@ -1036,9 +1036,6 @@ static int latent_moments(vlgp_ctx* ctx, UnitSet& us, double* d_partial, double*
     const int K = tri(ctx->L) + 3 * ctx->L + 1;
     return mlane ? vlgp_allreduce_m(ctx, d_out, K) : vlgp_allreduce(ctx, d_out, K);
 }
-int launch_moments_on(vlgp_ctx* ctx, UnitSet& us, hipStream_t st, double* d_partial, double* d_out) {
-    return latent_moments_st(ctx, us, d_partial, d_out, st);
-}
 
 // result (K doubles, all-reduced) is left at the head of ctx->d_work; the partials use its tail.  The
 // workspace may be reallocated in here: take ctx->d_work AFTER the call, never before.

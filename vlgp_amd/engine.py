@@ -253,6 +253,10 @@ class Engine:
                                      C.byref(n) if count else None))
         return n.value
 
+    def estep_wait(self):
+        """Wait for the most recent estep call's launches (not for work queued behind them since)."""
+        self._ck(self.lib.vlgp_estep_wait(self.h))
+
     def mstep(self, set_id, n_iter, use_hessian=True, eps=1e-8, learning_rate=1.0, da_bound=5.0,
               db_bound=5.0, count=True):
         n = C.c_int(0)
@@ -833,15 +837,25 @@ def em_iteration(trials, params, config, runtime, echo=None):
     early_m = m_async and not latent_constraint
     if early_m:
         begin_m()
-    eng.synchronize(main_only=True)   # the E-step; the M-step lane is not waited for
+    m_first = m_async and ((eng.world > 1 and not eng.host_exchange) or bool(os.environ.get("VLGP_M_SEQUENTIAL")))
+
+    # mu, dmu and w are final once the E-step (and constrain_latent) are done -- the M-step writes a, b; the H-step omega:
+    # the sums of the stopping rule (core.py:350-354) and the H-step's moments of mu / copy of w are queued behind the
+    # E-step while it still runs: nothing the host has to do between the E-step's end and the first round
+    prepare = bool(config["Hstep"]) and bool(config.get("window")) and not m_first
+
+    def after_estep():
+        eng.norms_begin(sid)
+        if prepare:
+            eng.hstep_prepare(sid, config["window"])
+
+    if not latent_constraint:
+        after_estep()
+    eng.estep_wait()   # the E-step alone: neither the M-step lane nor what is queued behind it
     t1 = time.perf_counter()
     constrain_latent(trials, params, config)
-    m_first = m_async and ((eng.world > 1 and not eng.host_exchange) or bool(os.environ.get("VLGP_M_SEQUENTIAL")))
-    if config["Hstep"] and config.get("window") and not m_first:
-        eng.hstep_prepare(sid, config["window"])  # the H-step's moments of mu / copy of w: under the host's way to its first round
-    # mu and dmu are final from here on (the M-step writes a, b; the H-step omega): the sums of the stopping rule
-    # (core.py:350-354) are enqueued now and run beside the H-step rounds instead of behind them
-    eng.norms_begin(sid)
+    if latent_constraint:
+        after_estep()
     norms_epoch = eng.state_epoch
     if m_async and not early_m:
         begin_m()
