@@ -554,6 +554,7 @@ extern "C" int vlgp_create(int device, int N, int L, int P, int R, const uint8_t
 }
 
 static void free_priors(vlgp_ctx* ctx) {
+    ctx->prior_pending.clear();  // (every caller has synchronised the stream; the ranks go with the priors)
     for (auto& kv : ctx->priors) {
         if (kv.second.d_full) (void)hipFree(kv.second.d_full);
         if (kv.second.d_compact) (void)hipFree(kv.second.d_compact);
@@ -859,6 +860,7 @@ extern "C" int vlgp_get_params(vlgp_ctx* ctx, double* a, double* b, double* nois
 
 // ---- prior -----------------------------------------------------------------
 static int rebuild_prior_table(vlgp_ctx* ctx) {
+    CHK(vlgp_prior_collect(ctx));
     const int L = ctx->L;
     const int rows = (int)ctx->priors.size();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -927,6 +929,7 @@ extern "C" int vlgp_build_prior(vlgp_ctx* ctx, int n_lengths, const int* lengths
     NEED_CTX(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     if (n_lengths < 1 || !lengths || !omega || !sigma) return vlgp_fail(ctx, VLGP_ERR_ARG, "bad build_prior arguments");
+    CHK(vlgp_prior_collect(ctx));
     // the reference replaces the whole dict on every call (gp.py:158).  Same set of lengths as the table holds
     // (every H-step): the factors are rebuilt in place and the kernel refreshes the ranks of the table rows --
     // no allocation, no copy.  Otherwise: drop the lengths not listed, add the new ones, rebuild the table.
@@ -952,7 +955,9 @@ extern "C" int vlgp_build_prior(vlgp_ctx* ctx, int n_lengths, const int* lengths
         CHK(new_prior(ctx, lengths[i], &pr));
         if (std::find(prs.begin(), prs.end(), pr) == prs.end()) prs.push_back(pr);
     }
-    CHK(launch_ichol_all(ctx, prs, omega, sigma, same));
+    // same lengths as the table holds (the rebuild of every EM iteration): nothing here needs the ranks on the host --
+    // the next consumer of Prior::rl (an E-step dispatch, vlgp_get_prior) takes them
+    CHK(launch_ichol_all(ctx, prs, omega, sigma, same, same));
     return same ? VLGP_OK : rebuild_prior_table(ctx);
 }
 
@@ -960,6 +965,7 @@ extern "C" int vlgp_set_prior(vlgp_ctx* ctx, int T, const double* G) {
     NEED_CTX(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
     if (!G) return vlgp_fail(ctx, VLGP_ERR_ARG, "null G");
+    CHK(vlgp_prior_collect(ctx));
     Prior* pr = nullptr;
     CHK(new_prior(ctx, T, &pr));
     const int64_t n = (int64_t)ctx->L * T * ctx->R;
@@ -971,6 +977,7 @@ extern "C" int vlgp_set_prior(vlgp_ctx* ctx, int T, const double* G) {
 
 extern "C" int vlgp_get_prior(vlgp_ctx* ctx, int T, double* G, int* rank_out) {
     NEED_CTX(ctx);
+    CHK(vlgp_prior_collect(ctx));
     auto it = ctx->priors.find(T);
     if (it == ctx->priors.end()) return vlgp_fail(ctx, VLGP_ERR_STATE, "no prior factor for length %d", T);
     const int64_t n = (int64_t)ctx->L * T * ctx->R;
@@ -1020,6 +1027,7 @@ static int end_count(vlgp_ctx* ctx, int* n_failed) {
 
 extern "C" int vlgp_update_w(vlgp_ctx* ctx, int set) {
     NEED_CTX(ctx);
+    CHK(vlgp_prior_collect(ctx));
     ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
@@ -1031,6 +1039,7 @@ extern "C" int vlgp_update_w(vlgp_ctx* ctx, int set) {
 
 extern "C" int vlgp_update_v(vlgp_ctx* ctx, int set, int vb, int* n_failed) {
     NEED_CTX(ctx);
+    CHK(vlgp_prior_collect(ctx));
     CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->dev));
@@ -1080,6 +1089,7 @@ static int estep_staged(vlgp_ctx* ctx, UnitSet& us, int mode, int n_iter, double
 
 extern "C" int vlgp_estep(vlgp_ctx* ctx, int set, int n_iter, double dmu_bound, int vb, int* n_failed) {
     NEED_CTX(ctx);
+    CHK(vlgp_prior_collect(ctx));
     ctx->hmom_us = nullptr;  // unit state changes: cached H-step moments are stale
     CHK(vlgp_join_m(ctx));
     NEED_PARAMS(ctx);

@@ -93,6 +93,8 @@ struct vlgp_ctx {
     int* d_prior_mb_host = nullptr;         // device view of h_prior_mb
     int* d_prior_mb = nullptr;              // device slots + arrival counter
     unsigned long long prior_seq = 0;
+    std::vector<struct Prior*> prior_pending;   // launched, host-side ranks not taken yet (vlgp_prior_collect)
+    unsigned long long prior_pending_seq = 0;
 
     UnitSet sets[VLGP_MAX_SETS];
 
@@ -236,7 +238,8 @@ int launch_hstep(vlgp_ctx* ctx, UnitSet& us, int window, double dt, int n_eval, 
                  const double* logp, double* ll, double* dll);
 // factor the listed priors (bit-exact ichol_gauss), ranks and compact copies included; returns with pr.rl set
 int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
-                     bool in_table);
+                     bool in_table, bool lazy = false);
+int vlgp_prior_collect(vlgp_ctx* ctx);  // host-side ranks of a lazy launch_ichol_all (call before reading Prior::rl)
 int launch_compact_prior(vlgp_ctx* ctx, Prior& pr);  // host-injected d_full -> rl, d_compact
 int launch_sample_posterior(vlgp_ctx* ctx, int T, int n, const double* d_mu, const double* d_w, const double* d_G,
                             const double* d_eps, double* d_z, double* d_out);

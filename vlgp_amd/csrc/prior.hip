@@ -398,12 +398,43 @@ static int launch_ichol_t(vlgp_ctx* ctx, const IcholArgs& A, size_t lds) {
 
 // Factor every listed prior (all already present in ctx->priors) with the given hyper-parameters and wait for
 // the ranks.  in_table: the priors' rows of the device table are current, the kernel refreshes their ranks.
-int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
-                     bool in_table) {
-    const int L = ctx->L, R = ctx->R;
-    CHK(ensure_mailbox(ctx));
+// the ranks of a launch whose wait was left for later (launch_ichol_all, lazy): wait for its sequence word, take them
+static int prior_wait_seq(vlgp_ctx* ctx, unsigned long long last) {
     int* flag_words = ctx->h_prior_mb + VLGP_PRIOR_SLOTS * VLGP_MAX_L;
     volatile unsigned long long* h_flag = reinterpret_cast<volatile unsigned long long*>(flag_words);
+    unsigned spins = 0;
+    while (*h_flag != last) {
+        if ((++spins & 0xfff) == 0) {  // a faulted kernel must not hang the host
+            const hipError_t qe = hipStreamQuery(ctx->stream);
+            if (qe == hipSuccess) {
+                if (*h_flag == last) break;
+                if ((spins >> 12) > 64) return vlgp_fail(ctx, VLGP_ERR_HIP, "prior kernel finished without publishing its ranks");
+            } else if (qe != hipErrorNotReady) {
+                return vlgp_fail(ctx, VLGP_ERR_HIP, "prior kernel failed: %s", hipGetErrorString(qe));
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return VLGP_OK;
+}
+int vlgp_prior_collect(vlgp_ctx* ctx) {
+    if (ctx->prior_pending.empty()) return VLGP_OK;
+    std::vector<Prior*> prs;
+    prs.swap(ctx->prior_pending);
+    CHK(prior_wait_seq(ctx, ctx->prior_pending_seq));
+    for (size_t j = 0; j < prs.size(); ++j)
+        prs[j]->rl.assign(ctx->h_prior_mb + j * VLGP_MAX_L, ctx->h_prior_mb + j * VLGP_MAX_L + ctx->L);
+    return VLGP_OK;
+}
+
+// lazy: (one batch, priors in the table) return right behind the launches; the host-side ranks are taken by
+// vlgp_prior_collect, which every consumer of Prior::rl calls first -- the rebuild of an EM iteration then runs under the
+// host's way to the next E-step instead of in front of it.
+int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double* omega, const double* sigma,
+                     bool in_table, bool lazy) {
+    const int L = ctx->L, R = ctx->R;
+    CHK(ensure_mailbox(ctx));
+    CHK(vlgp_prior_collect(ctx));
     unsigned long long* d_flag = reinterpret_cast<unsigned long long*>(ctx->d_prior_mb_host + VLGP_PRIOR_SLOTS * VLGP_MAX_L);
     unsigned* d_ticket = reinterpret_cast<unsigned*>(ctx->d_prior_mb + VLGP_PRIOR_SLOTS * VLGP_MAX_L);
     // global scratch for the lengths whose residuals / pivots do not fit LDS
@@ -442,19 +473,12 @@ int launch_ichol_all(vlgp_ctx* ctx, const std::vector<Prior*>& prs, const double
             vlgp_prof_end(ctx, VLGP_PROF_PRIOR, (double)L);
             HIPCHK(ctx, hipGetLastError());
         }
-        unsigned spins = 0;
-        while (*h_flag != last) {
-            if ((++spins & 0xfff) == 0) {  // a faulted kernel must not hang the host
-                const hipError_t qe = hipStreamQuery(ctx->stream);
-                if (qe == hipSuccess) {
-                    if (*h_flag == last) break;
-                    if ((spins >> 12) > 64) return vlgp_fail(ctx, VLGP_ERR_HIP, "prior kernel finished without publishing its ranks");
-                } else if (qe != hipErrorNotReady) {
-                    return vlgp_fail(ctx, VLGP_ERR_HIP, "prior kernel failed: %s", hipGetErrorString(qe));
-                }
-            }
+        if (lazy && in_table && prs.size() <= (size_t)VLGP_PRIOR_SLOTS) {
+            ctx->prior_pending.assign(prs.begin(), prs.end());
+            ctx->prior_pending_seq = last;
+            return VLGP_OK;
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        CHK(prior_wait_seq(ctx, last));
         for (size_t j = 0; j < cnt; ++j) {
             Prior& pr = *prs[base + j];
             pr.rl.assign(ctx->h_prior_mb + j * VLGP_MAX_L, ctx->h_prior_mb + j * VLGP_MAX_L + L);
