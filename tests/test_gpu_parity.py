@@ -627,6 +627,14 @@ def test_hstep_bracket_and_paths_agree(V, golden, monkeypatch):
             fresh = eng2.hstep_objective(0, T, 1.0, lat, logp)
         assert np.array_equal(scaled[0], fresh[0]) and np.array_equal(scaled[1], fresh[1])
         assert not np.array_equal(scaled[0], plain[0])
+        # VLGP_HSTEP_FUSE_TABLES=1: every round workgroup factors the two folded kernel blocks itself instead of reading
+        # the tables of a launch in front (measured, not faster: DESIGN 4.3) -- the same arithmetic, the same bits
+        monkeypatch.setenv("VLGP_HSTEP_FUSE_TABLES", "1")
+        eng.reload_switches()
+        fused = eng.hstep_objective(0, T, 1.0, lat, logp)
+        assert eng.last_hstep_path == "lowrank"
+        assert np.array_equal(fused[0], plain[0]) and np.array_equal(fused[1], plain[1])
+        monkeypatch.delenv("VLGP_HSTEP_FUSE_TABLES")
         monkeypatch.setenv("VLGP_HSTEP_DENSE", "1")
         eng.reload_switches()  # (the switches are cached when the handle is created)
         dense = eng.hstep_objective(0, T, 1.0, lat, logp)

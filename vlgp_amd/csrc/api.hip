@@ -1481,6 +1481,7 @@ void vlgp_read_switches(vlgp_ctx* ctx) {
     w.lowrank = getenv("VLGP_HSTEP_LOWRANK") != nullptr;
     w.generic_seg = getenv("VLGP_HSTEP_GENERIC_SEG") != nullptr;
     w.debug_occ = getenv("VLGP_DEBUG_OCC") != nullptr;
+    w.fuse_tables = getenv("VLGP_HSTEP_FUSE_TABLES") != nullptr;
     w.lr_tol = getenv("VLGP_HSTEP_LR_TOL") ? atof(getenv("VLGP_HSTEP_LR_TOL")) : 1e-12;
 }
 

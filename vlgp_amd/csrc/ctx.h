@@ -60,7 +60,7 @@ struct UnitSet {
 // created and again on vlgp_debug_reload_switches: the objective call itself -- ~40 times per EM iteration, on the
 // optimiser's critical path -- reads this struct, not the environment.
 struct HstepSwitches {
-    bool dense = false, generic = false, lowrank = false, generic_seg = false, debug_occ = false;
+    bool dense = false, generic = false, lowrank = false, generic_seg = false, debug_occ = false, fuse_tables = false;
     double lr_tol = 1e-12;
 };
 void vlgp_read_switches(struct vlgp_ctx* ctx);

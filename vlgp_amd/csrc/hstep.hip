@@ -672,6 +672,7 @@ __global__ void __launch_bounds__(256) hstep_moment_reduce(int nchunk, int TT, c
 struct HRoundArgs {
     HFastArgs F;
     int n_eval, nb;        // nb = segment blocks per evaluation
+    int lds_doubles;       // dynamic LDS of the low-rank launch (fused tables: scratch at its end)
     unsigned seq;          // launch sequence number published with the results
     unsigned* sync;        // [16]: finished-block counter
     const double* mom;     // (L, T, T) second moments of mu
@@ -960,7 +961,7 @@ __global__ void __launch_bounds__(128) hstep_lr_tables(HRoundArgs R) {
 #ifndef HLR64_LB
 #define HLR64_LB 4
 #endif
-template <int T, int NW, int RC, bool TABG = false>
+template <int T, int NW, int RC, bool TABG = false, bool TABF = false>
 __global__ void __launch_bounds__(64 * NW, RC <= 24 ? (T == 64 ? HLR64_LB : 4) : 3) hstep_round_lr(HRoundArgs R) {
     hstep_wave_prio(R.prio);
     constexpr bool ONESET = T == 50;
@@ -982,6 +983,13 @@ __global__ void __launch_bounds__(64 * NW, RC <= 24 ? (T == 64 ? HLR64_LB : 4) :
         double tr = 0.0, cs = 0.0;
         const double eps = exp(A.logp[3 * e + 2]);
         // (w indexed as w[row * L + l]: the latent-major copy enters as its latent's column with L = 1, l = 0)
+        if constexpr (TABF)
+            lr_group<RC, NK, NW, false, true>(nullptr, LrMeta{}, nullptr,
+                             A.wlm ? A.wlm + (int64_t)A.latent[e] * A.wld : A.w, A.off, A.wlm ? 1 : A.L,
+                             A.wlm ? 0 : A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs,
+                             b == 0 ? R.clk : nullptr, &R.lr, e, exp(A.logp[3 * e + 0]), exp(A.logp[3 * e + 1]),
+                             R.lds_doubles, bx == 0);
+        else
         lr_group<RC, NK, NW, TABG>(R.lr.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP, R.lr.meta[e], R.lr.pairs + (int64_t)e * LR_NPAIR,
                              A.wlm ? A.wlm + (int64_t)A.latent[e] * A.wld : A.w, A.off, A.wlm ? 1 : A.L,
                              A.wlm ? 0 : A.latent[e], A.M, A.Tr, eps, 16 * bx, lds_dyn, lane, wid, tr, cs,
@@ -1064,19 +1072,19 @@ static const std::vector<double>& lr_thresholds(vlgp_ctx* ctx, int T, double dt,
 constexpr int LR_NW = 4;  // waves per workgroup of the low-rank round (sixteen segments)
 static inline int n_lr_or_all(bool lr, int n_lr, int n_eval) { return lr ? n_lr : n_eval; }
 
-template <int T, int RC, bool TABG = false>
+template <int T, int RC, bool TABG = false, bool TABF = false>
 static int launch_round_lr(vlgp_ctx* ctx, const HRoundArgs& R, int grid, size_t lds_bytes) {
     constexpr int NW = LR_NW;
     // the dynamic-LDS ceiling is a per-DEVICE attribute of the function: remembered per handle (one handle = one device),
     // not per process (a second engine on another device never got it)
-    const void* fn = reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC, TABG>);
+    const void* fn = reinterpret_cast<const void*>(hstep_round_lr<T, NW, RC, TABG, TABF>);
     bool have = false;
     for (const void* f : ctx->lds_attr_done) have = have || f == fn;
     if (!have) {
         HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512)));
         ctx->lds_attr_done.push_back(fn);
     }
-    hipLaunchKernelGGL((hstep_round_lr<T, NW, RC, TABG>), dim3(grid), dim3(64 * NW), lds_bytes, ctx->stream, R);
+    hipLaunchKernelGGL((hstep_round_lr<T, NW, RC, TABG, TABF>), dim3(grid), dim3(64 * NW), lds_bytes, ctx->stream, R);
     return VLGP_OK;
 }
 
@@ -1289,7 +1297,8 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                 // (Measured: the tables built by blocks of the round kernel itself, the segment blocks waiting on a flag,
                 // is SLOWER than this extra launch -- 57 against 26 + 12 us for one evaluation: the waiting blocks fill
                 // the chip before the table blocks finish.)
-                {
+                const bool fuse_tables = sw.fuse_tables && rmax <= 24;  // (the classes without tables in global memory)
+                if (!fuse_tables) {
                     HRoundArgs Rt = R;
                     int k = 0;
                     for (int e = 0; e < n_eval; ++e)
@@ -1349,7 +1358,13 @@ static int launch_hstep_impl(vlgp_ctx* ctx, UnitSet& us, int window, double dt, 
                     if (need < 2 * 64 * NW) need = 2 * 64 * NW;
                     const size_t lds_bytes = (size_t)need * 8;
                     const int grid = Rc.k_blocks + Rc.lr_nev * R.nb;
-                    if (TC == 50) {
+                    Rc.lds_doubles = need;
+                    const bool fuse = sw.fuse_tables && rmax <= 24;
+                    if (fuse && TC == 50 && ci == 0) CHK((launch_round_lr<50, 16, false, true>(ctx, Rc, grid, lds_bytes)));
+                    else if (fuse && TC == 50 && ci == 1) CHK((launch_round_lr<50, 24, false, true>(ctx, Rc, grid, lds_bytes)));
+                    else if (fuse && ci == 0) CHK((launch_round_lr<64, 16, false, true>(ctx, Rc, grid, lds_bytes)));
+                    else if (fuse && ci == 1) CHK((launch_round_lr<64, 24, false, true>(ctx, Rc, grid, lds_bytes)));
+                    else if (TC == 50) {
                         if (ci == 0) CHK((launch_round_lr<50, 16>(ctx, Rc, grid, lds_bytes)));
                         else if (ci == 1) CHK((launch_round_lr<50, 24>(ctx, Rc, grid, lds_bytes)));
                         else if (ci == 2 && tabg) CHK((launch_round_lr<50, 28, true>(ctx, Rc, grid, lds_bytes)));

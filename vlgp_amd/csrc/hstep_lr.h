@@ -108,35 +108,16 @@ __device__ __forceinline__ double lr_row_sum_to15(double v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Tables of one evaluation: pivoted Cholesky of the even and of the odd block of K_0 = exp(-omega D^2) (one wave
-// each, lane <-> folded time row, factor columns in registers, pivot row entries by v_readlane), differentiated
-// along ln(omega) step by step.  Even block: Ke[t][p] = s_t s_p (k(t - p) + k(t + p - (T - 1))), s = 1 / sqrt 2 at
-// the middle row of an odd window and 1 elsewhere; odd block: Ko[t][p] = k(t - p) - k(t + p - (T - 1)), t, p < T / 2.
-// ---------------------------------------------------------------------------------------------------------
-// Called by every thread of a block of NT >= 128 threads; the first two waves factor, the others help with the fills.
-// kv, dkv: 2 x 64 doubles of LDS; s_i: 4 ints of LDS.
-template <int NT>
-__device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, double sigmasq, double omega, double* kv,
-                                                double* dkv, int* s_i) {
-    int* s_r = s_i;
-    int* s_cap = s_i + 2;
-    const int lane = threadIdx.x & 63, par = threadIdx.x >> 6;
-    const bool fac = par < 2;  // this wave factors a block (0: even, 1: odd)
-    const int T = A.T, h = T >> 1, nt = (T + 1) >> 1;
+// The pivoted Cholesky of one folded block with its omega-tangent, by one wave (par 0: even block, 1: odd block, other
+// waves fall through with r = 0): factor columns g, gd in registers (lane <-> folded time row tau), rank r, `capped` = the
+// capacity LR_RH ran out before the tolerance was met.  kv, dkv: exp(-omega d^2) and its derivative along ln(omega) by
+// distance (64 doubles of LDS each, filled by the caller).
+__device__ __forceinline__ void lr_factor_wave(int T, double tol, int par, int lane, const double* kv, const double* dkv,
+                                               double (&g)[LR_RH], double (&gd)[LR_RH], int& r_out, int& capped_out,
+                                               bool& rowin_out, int& tau_out) {
+    const int h = T >> 1, nt = (T + 1) >> 1;
     const bool oddT = (T & 1) != 0;
-    double* U = A.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP;
-    double* Ud = U + LR_TROWS * LR_RCAP;
-    unsigned short* pairs = A.pairs + (int64_t)e * LR_NPAIR;
-    for (int i = threadIdx.x; i < 2 * LR_TROWS * LR_RCAP; i += NT) U[i] = 0.0;
-    for (int q = threadIdx.x; q < LR_NPAIR; q += NT) pairs[q] = 0xffffu;
-    if (threadIdx.x < 64) {
-        const double d = lane * A.dt, d2 = d * d;
-        const double k = lane < T ? exp(-omega * d2) : 0.0;
-        kv[lane] = k;
-        dkv[lane] = -omega * d2 * k;
-    }
-    __syncthreads();
+    struct { double tol; } A{tol};
     const int n = par == 0 ? nt : (par == 1 ? h : 0);
     const bool rowin = lane < n;
     const int tau = rowin ? lane : 0;
@@ -154,7 +135,6 @@ __device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, doub
             dk = da - db;
         }
     };
-    double g[LR_RH], gd[LR_RH];
 #pragma unroll
     for (int k = 0; k < LR_RH; ++k) {
         g[k] = 0.0;
@@ -215,6 +195,45 @@ __device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, doub
         wave_argmax(bv, bi);
         capped = bv > A.tol;
     }
+    r_out = r;
+    capped_out = capped;
+    rowin_out = rowin;
+    tau_out = tau;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tables of one evaluation: pivoted Cholesky of the even and of the odd block of K_0 = exp(-omega D^2) (one wave
+// each, lane <-> folded time row, factor columns in registers, pivot row entries by v_readlane), differentiated
+// along ln(omega) step by step.  Even block: Ke[t][p] = s_t s_p (k(t - p) + k(t + p - (T - 1))), s = 1 / sqrt 2 at
+// the middle row of an odd window and 1 elsewhere; odd block: Ko[t][p] = k(t - p) - k(t + p - (T - 1)), t, p < T / 2.
+// ---------------------------------------------------------------------------------------------------------
+// Called by every thread of a block of NT >= 128 threads; the first two waves factor, the others help with the fills.
+// kv, dkv: 2 x 64 doubles of LDS; s_i: 4 ints of LDS.
+template <int NT>
+__device__ __forceinline__ void lr_tables_block(const HLrTabArgs& A, int e, double sigmasq, double omega, double* kv,
+                                                double* dkv, int* s_i) {
+    int* s_r = s_i;
+    int* s_cap = s_i + 2;
+    const int lane = threadIdx.x & 63, par = threadIdx.x >> 6;
+    const bool fac = par < 2;  // this wave factors a block (0: even, 1: odd)
+    const int T = A.T, h = T >> 1, nt = (T + 1) >> 1;
+    const bool oddT = (T & 1) != 0;
+    double* U = A.tab + (int64_t)e * 2 * LR_TROWS * LR_RCAP;
+    double* Ud = U + LR_TROWS * LR_RCAP;
+    unsigned short* pairs = A.pairs + (int64_t)e * LR_NPAIR;
+    for (int i = threadIdx.x; i < 2 * LR_TROWS * LR_RCAP; i += NT) U[i] = 0.0;
+    for (int q = threadIdx.x; q < LR_NPAIR; q += NT) pairs[q] = 0xffffu;
+    if (threadIdx.x < 64) {
+        const double d = lane * A.dt, d2 = d * d;
+        const double k = lane < T ? exp(-omega * d2) : 0.0;
+        kv[lane] = k;
+        dkv[lane] = -omega * d2 * k;
+    }
+    __syncthreads();
+    double g[LR_RH], gd[LR_RH];
+    int r, capped, tau;
+    bool rowin;
+    lr_factor_wave(T, A.tol, par, lane, kv, dkv, g, gd, r, capped, rowin, tau);
     if (lane == 0 && fac) {
         s_r[par] = r;
         s_cap[par] = capped;
@@ -308,12 +327,18 @@ __host__ __device__ inline LrGeom lr_geom(int r, int ntp, int nw, bool tab_globa
 // One group of 16 segments (seg0 ... seg0 + 15, those >= M masked) of one evaluation, by a workgroup of NW waves.
 // RC: register class (rank <= RC); NK: depth steps (4 NK >= folded rows).  Returns the group's sums of tr and cs
 // in lane 0 of wave 0 (other threads: garbage).
-template <int RC, int NK, int NW, bool TABG = false>
+// TABF: the tables are not read -- the workgroup factors the two folded blocks itself (lr_factor_wave by its first two
+// waves) straight into its LDS carve, from (sigma^2, omega) of evaluation e; fa (rcap, tol, dt, meta) are the table
+// kernel's arguments, lds_doubles the size of the dynamic LDS (scratch of the factorisation at its end), publish: this
+// workgroup writes the evaluation's meta record for the round's final block (overflow flag).
+template <int RC, int NK, int NW, bool TABG = false, bool TABF = false>
 __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const LrMeta mt,
                                          const unsigned short* __restrict__ pairs_e, const double* __restrict__ w,
                                          const int64_t* __restrict__ off, int L, int l, int M, int T, double eps,
                                          int seg0, double* lds, int lane, int wid, double& out_tr, double& out_cs,
-                                         unsigned long long* clk = nullptr) {
+                                         unsigned long long* clk = nullptr, const HLrTabArgs* fa = nullptr, int e = 0,
+                                         double sigmasq = 0.0, double omega = 0.0, int lds_doubles = 0, bool publish = false) {
+    static_assert(!(TABG && TABF), "fused tables live in LDS");
     // debug (vlgp_debug_phase_clock): cycles per phase of one workgroup, thread 0
     long long tck = clk ? clock64() : 0;
     auto stamp = [&](int slot) {
@@ -333,15 +358,56 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     const int64_t r0 = sval ? (int64_t)gs * T : 0;  // (every unit has T rows: off[m] = m T, no load)
     (void)off;
     double wpre1[NK], wpre2[NK];
+    auto load_w = [&]() {
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-        const int tau = 4 * kk + g;
-        wpre1[kk] = (sval && tau < nt) ? w[(r0 + tau) * L + l] : 0.0;
-        wpre2[kk] = (sval && tau < h) ? w[(r0 + T - 1 - tau) * L + l] : 0.0;
-    }
-    constexpr int TPRE = TABG ? 1 : (4 * NK * LR_RCAP + 64 * NW - 1) / (64 * NW);
+        for (int kk = 0; kk < NK; ++kk) {
+            const int tau = 4 * kk + g;
+            wpre1[kk] = (sval && tau < nt) ? w[(r0 + tau) * L + l] : 0.0;
+            wpre2[kk] = (sval && tau < h) ? w[(r0 + T - 1 - tau) * L + l] : 0.0;
+        }
+    };
+    if constexpr (!TABF) load_w();  // (fused tables: behind the factorisation, whose forty column registers need the room)
+    constexpr int TPRE = (TABG || TABF) ? 1 : (4 * NK * LR_RCAP + 64 * NW - 1) / (64 * NW);
     double tpre[TPRE][2];
-    if constexpr (!TABG) {
+    LrMeta mloc = mt;
+    constexpr int FR = TABF ? LR_RH : 1;
+    double fg[FR], fgd[FR];
+    int f_r = 0, f_cap = 0, f_tau = 0, f_re = 0;
+    bool f_rowin = false;
+    if constexpr (TABF) {
+        double* kv = lds + lds_doubles - 136;
+        double* dkv = kv + 64;
+        int* s_i = reinterpret_cast<int*>(dkv + 64);
+        if (threadIdx.x < 64) {  // (as lr_tables_block)
+            const double d = lane * fa->dt, d2 = d * d;
+            const double k = lane < T ? exp(-omega * d2) : 0.0;
+            kv[lane] = k;
+            dkv[lane] = -omega * d2 * k;
+        }
+        __syncthreads();
+        lr_factor_wave(T, fa->tol, wid, lane, kv, dkv, fg, fgd, f_r, f_cap, f_rowin, f_tau);
+        if (lane == 0 && wid < 2) {
+            s_i[wid] = f_r;
+            s_i[2 + wid] = f_cap;
+        }
+        __syncthreads();
+        int re = s_i[0], ro = s_i[1];
+        int overflow = s_i[2] | s_i[3];
+        if (re + ro > fa->rcap[e] || re + ro > LR_RCAP) overflow = 1;
+        if (overflow) re = ro = 0;
+        const int n_ee = re * (re + 1) / 2, n_oo = ro * (ro + 1) / 2;
+        const int ns16 = (n_ee + n_oo + 15) & ~15, nc16 = (re * ro + 15) & ~15;
+        mloc.re = re; mloc.ro = ro; mloc.r = re + ro;
+        mloc.ns_tiles = ns16 >> 4;
+        mloc.n_tiles = (ns16 + nc16) >> 4;
+        mloc.overflow = overflow;
+        mloc.pad0 = mloc.pad1 = 0;
+        f_re = re;
+        if (publish && threadIdx.x == 0) fa->meta[e] = mloc;
+        __syncthreads();  // (the scratch at the end of the LDS is dead from here: the pair codes take its place)
+        load_w();
+    }
+    if constexpr (!TABG && !TABF) {
 #pragma unroll
         for (int q = 0; q < TPRE; ++q) {
             const int x = threadIdx.x + q * 64 * NW;
@@ -351,8 +417,8 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
         }
     }
     // wave-uniform by construction; said explicitly so that the rank guards below are scalar branches
-    const int r = __builtin_amdgcn_readfirstlane(mt.r);
-    const int ns_tiles = __builtin_amdgcn_readfirstlane(mt.ns_tiles), n_tiles = __builtin_amdgcn_readfirstlane(mt.n_tiles);
+    const int r = __builtin_amdgcn_readfirstlane(mloc.r);
+    const int ns_tiles = __builtin_amdgcn_readfirstlane(mloc.ns_tiles), n_tiles = __builtin_amdgcn_readfirstlane(mloc.n_tiles);
     // TABG: the tables stay in global memory (L1 / L2: 13 KB per evaluation, shared by its 250 workgroups) and the LDS
     // they would take goes to a third workgroup per CU (ranks 25 ... 31); needs a zero column, i.e. r < LR_RCAP
     const LrGeom G = lr_geom(r, 4 * NK, NW, TABG, RC);
@@ -362,10 +428,46 @@ __device__ __forceinline__ void lr_group(const double* __restrict__ tab_e, const
     double* xb = lds + G.o_xb + wid * lr_xs_per_wave(RC);
     double* red = lds + G.o_red;
     unsigned short* codes = reinterpret_cast<unsigned short*>(lds + G.o_codes);
-    for (int x = threadIdx.x; x < 16 * n_tiles; x += 64 * NW) codes[x] = pairs_e[x];  // (the tile loops read them from LDS)
+    if constexpr (!TABF)
+        for (int x = threadIdx.x; x < 16 * n_tiles; x += 64 * NW) codes[x] = pairs_e[x];  // (the tile loops read them from LDS)
     const int LDU = G.LDU, NPS = G.NPS;
     const int NPZ = r * (r + 1) / 2;  // the zero slot of a packed matrix; NPZ + 1: trash
-    if constexpr (!TABG) {
+    if constexpr (TABF) {
+        double* Uw = lds + G.o_u;
+        double* Udw = lds + G.o_ud;
+        for (int x = threadIdx.x; x < 4 * NK * LDU; x += 64 * NW) {
+            Uw[x] = 0.0;
+            Udw[x] = 0.0;
+        }
+        for (int x = threadIdx.x; x < 16 * n_tiles; x += 64 * NW) codes[x] = 0xffffu;
+        __syncthreads();
+        const int re = f_re, ro = r - f_re;
+        if (f_rowin && wid < 2) {
+            const int coff = wid == 0 ? 0 : re, rw = wid == 0 ? re : ro;
+            const double sig = sqrt(sigmasq);
+#pragma unroll
+            for (int k = 0; k < LR_RH; ++k)
+                if (k < rw) {
+                    Uw[f_tau * LDU + coff + k] = sig * fg[k];
+                    Udw[f_tau * LDU + coff + k] = sig * fgd[k];
+                }
+        }
+        const int n_ee = re * (re + 1) / 2;
+        const int ns16 = 16 * ns_tiles;
+        for (int i = wid; i < r; i += NW) {  // (as lr_tables_block: row i by wave, column j by lane)
+            const int j = lane;
+            if (j <= i) {
+                const bool io = i >= re, jo = j >= re;
+                int pos;
+                if (io == jo)
+                    pos = io ? n_ee + (i - re) * (i - re + 1) / 2 + (j - re) : i * (i + 1) / 2 + j;
+                else
+                    pos = ns16 + (i - re) * re + j;
+                codes[pos] = (unsigned short)((i << 8) | j);
+            }
+        }
+    }
+    if constexpr (!TABG && !TABF) {
         double* Uw = lds + G.o_u;
         double* Udw = lds + G.o_ud;
 #pragma unroll
