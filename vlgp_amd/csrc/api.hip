@@ -1179,18 +1179,13 @@ extern "C" int vlgp_mstep_begin(vlgp_ctx* ctx, int set, int n_iter, int use_hess
     ctx->msnap_valid = false;
     if (n_iter >= 1)  // core.py:131-133
         CHK(launch_mstep(ctx, *us, n_iter, use_hessian, eps, lr, da_bound, db_bound));
-    {   // what the caller pulls afterwards (vlgp_get_params, the failure count), copied out by the lane itself
+    {   // what the caller pulls afterwards (vlgp_get_params, the failure count), written out by the lane itself
         const int N = ctx->N, L = ctx->L, P = ctx->P;
-        const size_t ln[5] = {(size_t)L * N, (size_t)P * N, (size_t)N, (size_t)L * N, (size_t)P * N};
-        const double* src[5] = {ctx->d_a, ctx->d_b, ctx->d_noise, ctx->d_da, ctx->d_db};
-        if (!ctx->h_msnap)
-            HIPCHK(ctx, hipHostMalloc(&ctx->h_msnap, sizeof(double) * (2 * (size_t)(L + P) * N + N + 8), hipHostMallocDefault));
-        double* h = ctx->h_msnap;
-        for (int i = 0; i < 5; ++i) {
-            HIPCHK(ctx, hipMemcpyAsync(h, src[i], sizeof(double) * ln[i], hipMemcpyDeviceToHost, ctx->mstream));
-            h += ln[i];
+        if (!ctx->h_msnap) {
+            HIPCHK(ctx, hipHostMalloc(&ctx->h_msnap, sizeof(double) * (2 * (size_t)(L + P) * N + N + 8), hipHostMallocMapped));
+            HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_msnap), ctx->h_msnap, 0));
         }
-        HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_fail_m, sizeof(int), hipMemcpyDeviceToHost, ctx->mstream));
+        CHK(launch_snapshot_params(ctx, ctx->mstream, ctx->d_msnap));
         ctx->msnap_valid = true;  // (read only after vlgp_join_m; any vlgp_set_params in between clears it)
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_m_done, ctx->mstream));
@@ -1363,14 +1358,14 @@ extern "C" int vlgp_norms_begin(vlgp_ctx* ctx, int set) {
         return VLGP_OK;
     }
     if (!ctx->h_xres) {
-        HIPCHK(ctx, hipMalloc(&ctx->d_xwork, sizeof(double) * (2 * 256 + 8)));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_xwork, 0, sizeof(double) * (2 * 256 + 8), ctx->stream));
+        HIPCHK(ctx, hipMalloc(&ctx->d_xwork, sizeof(double) * (2 * 1024 + 8)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_xwork, 0, sizeof(double) * (2 * 1024 + 8), ctx->stream));
         HIPCHK(ctx, hipHostMalloc(&ctx->h_xres, sizeof(double) * 8, hipHostMallocMapped));
         memset(ctx->h_xres, 0, sizeof(double) * 8);
         HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_xres), ctx->h_xres, 0));
     }
     ++ctx->x_seq;
-    CHK(launch_norms(ctx, *us, ctx->d_xwork, reinterpret_cast<unsigned*>(ctx->d_xwork + 2 * 256), ctx->d_xres, ctx->x_seq));
+    CHK(launch_norms(ctx, *us, ctx->d_xwork, reinterpret_cast<unsigned*>(ctx->d_xwork + 2 * 1024), ctx->d_xres, ctx->x_seq));
     ctx->x_pending = 1;
     return VLGP_OK;
 }

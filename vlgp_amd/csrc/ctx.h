@@ -174,14 +174,15 @@ struct vlgp_ctx {
 
     // Pieces of an EM iteration's tail taken off its critical path (api.hip):
     // (1) the norms of mu, dmu for the stopping rule: one kernel queued behind the E-step, results in mapped host memory
-    double* d_xwork = nullptr;    // 256 x 2 partial sums | ticket
+    double* d_xwork = nullptr;    // 1024 x 2 partial sums | ticket
     double* h_xres = nullptr;     // mapped: |mu|^2, |dmu|^2, sequence word
     double* d_xres = nullptr;     // its device view
     unsigned long long x_seq = 0;
     int x_pending = 0;            // 1: queued (sequence x_seq), 2: deferred to vlgp_norms_end (several ranks)
     int x_set = -1;
     // (2) the M-step lane leaves a, b, noise, da, db and its failure count in pinned memory behind its last kernel
-    double* h_msnap = nullptr;
+    double* h_msnap = nullptr;    // mapped host memory
+    double* d_msnap = nullptr;    // its device view
     bool msnap_valid = false;
     // (3) vlgp_set_params / vlgp_apply_latent_map stage through their own pinned (and device) buffers, reuse guarded by
     // an event: no stream synchronisation in front of the E-step's first launch
@@ -246,6 +247,7 @@ int launch_sample_posterior(vlgp_ctx* ctx, int T, int n, const double* d_mu, con
 int launch_npx_probe(vlgp_ctx* ctx, int kind, int64_t n, const double* d_a, const double* d_b, double* d_out);
 int launch_xb(vlgp_ctx* ctx, UnitSet& us);
 int launch_latent_map(vlgp_ctx* ctx, UnitSet& us, const double* d_map, const double* d_shift);
+int launch_snapshot_params(vlgp_ctx* ctx, hipStream_t st, double* d_host);  // a | b | noise | da | db | failure count
 int launch_norms(vlgp_ctx* ctx, UnitSet& us, double* d_part, unsigned* d_ticket, double* d_host, unsigned long long seq);
 // shared rows of overlapping segments: dir 0 copies first unit's tail -> second unit's head (mu if share_mu, v), dir 1 back,
 // for the links [l0, l1); launch_links_map applies the latent map once more to both copies of every shared row

@@ -108,6 +108,35 @@ int launch_xb(vlgp_ctx* ctx, UnitSet& us) {
     return VLGP_OK;
 }
 
+// ---- parameter snapshot of the M-step lane: a | b | noise | da | db | failure count into mapped host memory, one launch
+// (six device-to-host copies of a few KB each are six 5 us steps at the end of the lane) ----
+__global__ void __launch_bounds__(256)
+snapshot_params_kernel(int na, int nb, int nn, const double* __restrict__ a, const double* __restrict__ b,
+                       const double* __restrict__ noise, const double* __restrict__ da, const double* __restrict__ db,
+                       const int* __restrict__ fail, double* __restrict__ host) {
+    const int total = 2 * na + 2 * nb + nn;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        double v;
+        if (i < na) v = a[i];
+        else if (i < na + nb) v = b[i - na];
+        else if (i < na + nb + nn) v = noise[i - na - nb];
+        else if (i < 2 * na + nb + nn) v = da[i - na - nb - nn];
+        else v = db[i - 2 * na - nb - nn];
+        host[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<int*>(host + total) = *fail;
+}
+int launch_snapshot_params(vlgp_ctx* ctx, hipStream_t st, double* d_host) {
+    const int na = ctx->L * ctx->N, nb = ctx->P * ctx->N, nn = ctx->N;
+    const int total = 2 * na + 2 * nb + nn;
+    int g = (total + 255) / 256;
+    if (g > 64) g = 64;
+    hipLaunchKernelGGL(snapshot_params_kernel, dim3(g), dim3(256), 0, st, na, nb, nn, ctx->d_a, ctx->d_b, ctx->d_noise, ctx->d_da,
+                       ctx->d_db, ctx->d_fail_m, d_host);
+    HIPCHK(ctx, hipGetLastError());
+    return VLGP_OK;
+}
+
 // ---- |mu|^2 and |dmu|^2 over the set (the stopping rule of core.vem, vlgp/core.py:300-305,350-354) ----
 // One launch on the main stream: per-block sums in a fixed order, the block that draws the last ticket adds the
 // partials (fixed tree) and publishes to mapped host memory with a sequence word -- no copy, no second kernel, nothing
@@ -119,10 +148,22 @@ norms_kernel(int64_t n, const double* __restrict__ mu, const double* __restrict_
     __shared__ int s_last;
     const int tid = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
-        const double m = mu[i], d = dmu ? dmu[i] : 0.0;
-        s0 = fma(m, m, s0);
-        s1 = fma(d, d, s1);
+    {   // four strided elements per step: eight loads in flight per lane (one at a time: 19 us for 16 MB, bound by latency)
+        const int64_t st = (int64_t)gridDim.x * 256;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += 4 * st) {
+            double m[4], d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t j = i + q * st;
+                m[q] = j < n ? mu[j] : 0.0;
+                d[q] = (dmu && j < n) ? dmu[j] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s0 = fma(m[q], m[q], s0);
+                s1 = fma(d[q], d[q], s1);
+            }
+        }
     }
     red[0][tid] = s0; red[1][tid] = s1;
     __syncthreads();
@@ -139,8 +180,15 @@ norms_kernel(int64_t n, const double* __restrict__ mu, const double* __restrict_
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    red[0][tid] = tid < (int)gridDim.x ? __hip_atomic_load(part + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    red[1][tid] = tid < (int)gridDim.x ? __hip_atomic_load(part + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    {
+        double p0 = 0.0, p1 = 0.0;
+        for (int b = tid; b < (int)gridDim.x; b += 256) {  // (fixed order: block b of every 256)
+            p0 += __hip_atomic_load(part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p1 += __hip_atomic_load(part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        red[0][tid] = p0;
+        red[1][tid] = p1;
+    }
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
@@ -157,8 +205,10 @@ norms_kernel(int64_t n, const double* __restrict__ mu, const double* __restrict_
 
 int launch_norms(vlgp_ctx* ctx, UnitSet& us, double* d_part, unsigned* d_ticket, double* d_host, unsigned long long seq) {
     const int64_t n = us.rows * ctx->L;
-    int g = (int)((n + 255) / 256);
-    if (g > 256) g = 256;
+    // (at most 256 blocks: every block ends with an atomic on ONE ticket word, ~25 ns each -- 977 blocks: 31 us)
+    static const int gmax = getenv("VLGP_NORMS_BLOCKS") ? atoi(getenv("VLGP_NORMS_BLOCKS")) : 256;
+    int g = (int)((n + 1023) / 1024);
+    if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(norms_kernel, dim3(g), dim3(256), 0, ctx->stream, n, us.mu, us.dmu, d_part, d_ticket, d_host, seq);
     HIPCHK(ctx, hipGetLastError());
