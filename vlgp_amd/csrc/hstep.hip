@@ -607,23 +607,22 @@ struct HFastArgs {
 template <int T>
 __global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, int Tr, const int64_t* off, const double* mu,
                                                            int nchunk, double* part) {
-    constexpr int NE = (T * T + 255) / 256;
+    // thread <-> (row j of C_l, a run of CW columns): one LDS read of mu_j and CW / 2 wide reads of the run per segment for
+    // CW multiply-adds (an entry per thread in index order cost two reads per multiply-add)
+    constexpr int CW = (T * T + 255) / 256;    // 10 at T = 50, 16 at T = 64
+    constexpr int NG = (T + CW - 1) / CW;      // column runs: 5, 4
+    static_assert(T * NG <= 256, "one thread per (row, run)");
     constexpr int SG = 16;  // segments per stage: their loads are in flight together, the next stage's under this one's sums
-    __shared__ double s[SG][64];
+    __shared__ __attribute__((aligned(16))) double s[SG][64];
     const int l = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const int per = (M + nchunk - 1) / nchunk;
     const int m0 = c * per, m1 = (m0 + per < M) ? m0 + per : M;
-    double acc[NE];
-    int jj[NE], kk[NE];
+    const bool act = tid < T * NG;
+    const int j = act ? tid % T : 0, k0 = act ? (tid / T) * CW : 0;
+    double acc[CW];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int idx = tid + 256 * i;
-        acc[i] = 0.0;
-        jj[i] = idx < T * T ? idx / T : 0;
-        kk[i] = idx < T * T ? idx - jj[i] * T : 0;
-    }
-    // (segments enter every sum in ascending order whatever the stage size: the same bits as the four-at-a-time loop this
-    // replaces, which waited for one strided load per four segments -- sixteen round trips to memory per block)
+    for (int i = 0; i < CW; ++i) acc[i] = 0.0;
+    // (segments enter every sum in ascending order: the same bits whatever the stage size or the thread mapping)
     const int w4 = tid >> 6, t = tid & 63;
     double nx[SG / 4];
     auto fetch = [&](int m) {
@@ -641,14 +640,16 @@ __global__ void __launch_bounds__(256) hstep_moment_kernel(int L, int M, int Tr,
         __syncthreads();
         if (m + SG < m1) fetch(m + SG);
 #pragma unroll
-        for (int sg = 0; sg < SG; ++sg)
+        for (int sg = 0; sg < SG; ++sg) {
+            const double a = s[sg][j];
 #pragma unroll
-            for (int i = 0; i < NE; ++i) acc[i] = fma(s[sg][jj[i]], s[sg][kk[i]], acc[i]);
+            for (int i = 0; i < CW; ++i) acc[i] = fma(a, (k0 + i < 64) ? s[sg][k0 + i] : 0.0, acc[i]);
+        }
     }
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < T * T) part[((int64_t)l * nchunk + c) * T * T + idx] = acc[i];
+        for (int i = 0; i < CW; ++i)
+            if (k0 + i < T) part[((int64_t)l * nchunk + c) * T * T + j * T + k0 + i] = acc[i];
     }
 }
 
