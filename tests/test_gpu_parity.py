@@ -164,7 +164,12 @@ def test_iteration_tail_entry_points(V):
         eng.update_w(0)
         eng.update_v(0)
         eng.estep(0, 3)
+        eng.norms_begin(0)          # queued behind the running E-step
+        eng.hstep_prepare(0, T)     # likewise
+        eng.estep_wait()            # the E-step's own launches (vlgp_estep_wait), not what is queued behind them
+        first = eng.norms_end()
         ref = eng.norms(0)
+        assert first == ref
         eng.norms_begin(0)
         assert eng.norms_end() == ref
         with pytest.raises(V.VlgpError):
